@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz from the reference's OWN sources.
+
+Run in the build container (needs /root/reference and `make -C oracle ref`):
+
+    python tests/golden/make_golden.py
+
+Each fixture holds a seeded synthetic capture in the .rspduo wire layout
+(int16 I1 Q1 I2 Q2, /root/reference/src/capture/rspduo/RspDuo.cpp:512-526) and
+what the compiled reference (oracle/_ref/libblah2ref.so) produced for it:
+the derived sizes, both axes, the complex128 map of Ambiguity::process, the
+Map::set_metrics pair, the CfarDetector1D / Centroid / Interpolate detection
+lists and the WienerHopf-filtered surveillance channel.  The GPU box has no
+/root/reference, so these files are what `-m gpu` parity tests compare with.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import blah2_oracle as O  # noqa: E402
+from oracle import ref_lib as R  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# name -> (fs, n, delayMin, delayMax, dopplerMin, dopplerMax, roundHamming, seed, targets, clutter(dMin,dMax))
+CASES = {
+    "small_sym": (200_000, 20_000, -3, 20, -50, 50, True, 11, ((7, -40.0, 0.05),), (-3, 20)),
+    "small_nohamming": (200_000, 20_000, -3, 20, -50, 50, False, 12, ((5, 20.0, 0.05),), (-3, 20)),
+    "small_asym": (200_000, 20_000, -2, 30, -20, 60, True, 13, ((11, 40.0, 0.06),), (-2, 30)),
+    "medium": (1_000_000, 100_000, -10, 100, -100, 100, True, 14,
+               ((37, -63.0, 0.05), (80, 30.0, 0.03)), (-10, 100)),
+    "delay_pos_only": (200_000, 30_000, 0, 40, -30, 30, True, 15, ((20, 10.0, 0.05),), (0, 40)),
+}
+DET = dict(pfa=1e-5, n_guard=2, n_train=6, min_delay=5, min_doppler=15.0, n_centroid=6)
+
+
+def main():
+    if not R.available():
+        sys.exit("oracle/_ref/libblah2ref.so missing: run `make -C oracle ref` first")
+    for name, (fs, n, dmin, dmax, fmin, fmax, rh, seed, targets, clut) in CASES.items():
+        x, y = O.synth_iq(n, seed=seed, fs=fs, targets=targets)
+        iq = np.empty((n, 4), dtype=np.int16)
+        iq[:, 0], iq[:, 1], iq[:, 2], iq[:, 3] = x.real, x.imag, y.real, y.imag
+        amb = R.RefAmbiguity(dmin, dmax, fmin, fmax, fs, n, rh)
+        m, delay, doppler, noise, peak, left = amb.process(x, y)
+        tcpi = n / fs
+        det0 = amb.detect(DET["pfa"], DET["n_guard"], DET["n_train"], DET["min_delay"],
+                          DET["min_doppler"], stage=0)
+        det1 = amb.detect(DET["pfa"], DET["n_guard"], DET["n_train"], DET["min_delay"],
+                          DET["min_doppler"], DET["n_centroid"], 1.0 / tcpi, stage=1)
+        det2 = amb.detect(DET["pfa"], DET["n_guard"], DET["n_train"], DET["min_delay"],
+                          DET["min_doppler"], DET["n_centroid"], 1.0 / tcpi, stage=2)
+        ok, yf, _ = R.wiener_hopf(x, y, clut[0], clut[1])
+        # the full chain as blah2.cpp:268-287 runs it: clutter filter, then ambiguity
+        amb2 = R.RefAmbiguity(dmin, dmax, fmin, fmax, fs, n, rh)
+        m2, _, _, noise2, peak2, _ = amb2.process(x, yf)
+        det_chain = amb2.detect(DET["pfa"], DET["n_guard"], DET["n_train"], DET["min_delay"],
+                                DET["min_doppler"], stage=0)
+        out = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(
+            out, iq=iq,
+            params=np.array([fs, n, dmin, dmax, fmin, fmax, int(rh)], dtype=np.int64),
+            dims=np.array([amb.n_doppler_bins, amb.n_delay_bins, amb.n_corr, amb.nfft], dtype=np.int64),
+            cpi=np.float64(amb.cpi), doppler_middle=np.float64(amb.doppler_middle),
+            leftover=np.array(left, dtype=np.int64),
+            delay=delay, doppler=doppler, map=m, metrics=np.array([noise, peak]),
+            det_params=np.array([DET["pfa"], DET["n_guard"], DET["n_train"], DET["min_delay"],
+                                 DET["min_doppler"], DET["n_centroid"], 1.0 / tcpi]),
+            cfar=np.stack(det0), centroid=np.stack(det1), interp=np.stack(det2),
+            clutter_params=np.array(clut, dtype=np.int64), clutter_ok=np.bool_(ok), clutter_y=yf,
+            chain_map=m2, chain_metrics=np.array([noise2, peak2]), chain_cfar=np.stack(det_chain))
+        print(f"{name}: nD={amb.n_doppler_bins} nDelay={amb.n_delay_bins} nCorr={amb.n_corr} "
+              f"nfft={amb.nfft} cfar={det0[0].size} centroid={det1[0].size} interp={det2[0].size} "
+              f"clutter_ok={ok} chain_cfar={det_chain[0].size} -> {os.path.getsize(out)/1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()
