@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Benchmark of the cross-ambiguity hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the device-resident chain (range kernel -> Doppler
+kernel -> metrics) over one batch of --batch synthetic CPIs already resident in
+HBM.  Workload at N=1: BASELINE.json configs[1] (2 MS/s, 1 s CPI, +-256 Hz ->
+513 Doppler bins x 411 delay bins, complex fp32 IQ).  CPIs shard one stream per
+GPU with no data-path collective (weak scaling); rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+CONFIGS = {
+    # name: (delayMin, delayMax, dopplerMin, dopplerMax, fs, n)
+    "cfg2": (-10, 400, -256, 256, 2_000_000, 2_000_000),
+    "test": (-10, 300, -300, 300, 2_000_000, 1_000_000),
+    "cfg3": (-24, 2023, -512, 512, 10_000_000, 10_000_000),
+}
+
+
+def synth_batch(torch, n_cpi, n, seed, fs, device):
+    """Seeded synthetic IQ, int16-valued like the .rspduo wire format, as complex64 planes."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    x = 300.0 * torch.randn((n_cpi, n, 2), generator=g, device=device)
+    noise = 30.0 * torch.randn((n_cpi, n, 2), generator=g, device=device)
+    xc = torch.view_as_complex(x)
+    t = torch.arange(n, device=device, dtype=torch.float64) / fs
+    d, f, a = 37, -63.0, 0.05
+    ph = torch.exp(2j * torch.pi * f * t).to(torch.complex64)
+    xd = torch.roll(xc, d, dims=1)
+    xd[:, :d] = 0
+    yc = 0.8 * xc + a * xd * ph + torch.view_as_complex(noise)
+    q = lambda v: torch.view_as_complex(torch.clamp(torch.round(torch.view_as_real(v)), -32768, 32767).contiguous())
+    return q(xc).contiguous(), q(yc).contiguous()
+
+
+def cpu_baseline(args_amb, budget_s=20.0):
+    """The reference's own Ambiguity::process + set_metrics (oracle/_ref, shim FFT)
+    or, if that library is absent, the NumPy restatement -- timed on the host cores."""
+    import numpy as np
+    from oracle import blah2_oracle as O
+    from oracle import ref_lib as R
+    dmin, dmax, fmin, fmax, fs, n = args_amb
+    x, y = O.synth_iq(n, fs=fs)
+    times = []
+    if R.available():
+        a = R.RefAmbiguity(dmin, dmax, fmin, fmax, fs, n, True)
+        t_end = time.time() + budget_s
+        while time.time() < t_end and len(times) < 12:
+            a.process(x, y)
+            times.append(a.last_seconds)
+        kind = "reference"
+        what = ("reference Ambiguity.cpp + Map::set_metrics compiled from /root/reference/src with the "
+                "fp64 shim FFT (FFTW is not installed in this image), 1 thread")
+    else:
+        d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
+        t_end = time.time() + budget_s
+        while time.time() < t_end and len(times) < 12:
+            t0 = time.time()
+            m = O.ambiguity_process(d, x, y)
+            O.map_metrics(m)
+            times.append(time.time() - t0)
+        kind = "port"
+        what = "NumPy/pocketfft fp64 restatement (oracle/blah2_oracle.py), 1 thread"
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "CPIs/s", "cores": 1, "kind": kind,
+            "sample": f"{len(times)} CPIs of the same workload, median {med*1e3:.0f} ms/CPI; {what}",
+            "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="CPIs per step (per GPU)")
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--fmt", default="c32", choices=["c32", "i16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import blah2_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = CONFIGS[a.config]
+    dmin, dmax, fmin, fmax, fs, n = cfg
+    B = a.batch
+    amb = blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B)
+    nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
+    cells = nD * nC
+    s_in = 8 if a.fmt == "c32" else 4
+    # ring of distinct batches > 512 MB so every CPI read is real HBM traffic
+    # (the 256 MB Infinity Cache would otherwise hold a 32 MB CPI)
+    bytes_per_batch = 2 * n * s_in * B
+    ring = max(2, -(-int(600e6) // bytes_per_batch))
+    xs, ys, iqs = [], [], []
+    for r in range(ring):
+        x, y = synth_batch(torch, B, n, 1000 + 17 * rank + r, fs, dev)
+        if a.fmt == "c32":
+            xs.append(x)
+            ys.append(y)
+        else:
+            iq = torch.stack([x.real, x.imag, y.real, y.imag], dim=-1).to(torch.int16).contiguous()
+            iqs.append(iq)
+    out = torch.zeros((B, nD, nC), dtype=torch.complex64, device=dev)
+    met = torch.zeros((B, 2), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream()
+    st = stream.cuda_stream
+
+    def step(i):
+        r = i % ring
+        if a.fmt == "c32":
+            amb.process_dev(blah2_amd.FMT_C32, xs[r].data_ptr(), ys[r].data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
+        else:
+            amb.process_dev(blah2_amd.FMT_I16, iqs[r].data_ptr(), 0, B, n, out.data_ptr(), met.data_ptr(), st)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # second, identical region with every kernel bracketed by HIP events on the
+    # launch stream: per-kernel durations for the roofline line
+    amb.set_timing(True)
+    for i in range(a.steps):
+        step(a.warmup + i)
+    torch.cuda.synchronize()
+    kt = amb.get_timing()
+    amb.set_timing(False)
+    range_ms, range_n = kt["range"]
+    avg_range_s = (range_ms / max(range_n, 1)) * 1e-3
+    # algorithmic bytes per launch of the range kernel: every input
+    # sample once + the nD x nDelay complex fp32 range map once, x batch
+    algo_bytes = (2 * n * s_in + cells * 8) * B
+    achieved = algo_bytes / avg_range_s / 1e9 if avg_range_s > 0 else 0.0
+    chain_s = sum(v[0] for v in kt.values()) * 1e-3 / max(range_n, 1)
+
+    # sanity: the timed outputs are real (metrics of the last batch are finite, target visible)
+    mt = met.cpu().numpy()
+    ok = bool((mt == mt).all() and (mt[:, 1] > 0).all())
+
+    if rank == 0:
+        total_cpis = world * B * a.steps
+        res = {
+            "metric": "CPIs/s", "value": total_cpis / elapsed, "unit": "CPIs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: 2 MS/s, 1 s CPI, +-256 Hz -> {nD} Doppler x {nC} delay bins, "
+                                   f"synthetic {a.fmt} IQ resident in HBM" if a.config == "cfg2" else a.config,
+                       "batch_cpis_per_step": B, "fmt": a.fmt, "n_samples": n, "fs": fs,
+                       "n_doppler_bins": nD, "n_delay_bins": nC, "n_corr": amb.get_n_corr(),
+                       "fft_len": amb.dims.fft_len, "n_seg": amb.dims.n_seg, "seg_len": amb.dims.seg_len,
+                       "ring_batches": ring, "sharding": f"{world} independent CPI streams, one per GPU"},
+            "cells_per_s": total_cpis * cells / elapsed,
+            "us_per_cpi": elapsed / (B * a.steps) * 1e6,
+            "outputs_valid": ok,
+            "roofline": {"bound": "hbm", "kernel": "range_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "avg_launch_us": avg_range_s * 1e6, "launches_timed": range_n,
+                         "kernel_us_per_step": {k: v[0] / max(v[1], 1) * 1e3 for k, v in kt.items() if v[1]},
+                         "chain_us_per_step": chain_s * 1e6},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

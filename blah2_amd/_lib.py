@@ -1,0 +1,95 @@
+"""ctypes binding of include/blah2hip.h.
+
+The HIP library is the product; there is no CPU fallback.  Importing this
+module fails loudly when ``libblah2hip.so`` has not been built, and every call
+raises :class:`Blah2HipError` on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libblah2hip.so")
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_UNDERFLOW, ERR_NO_DEVICE, ERR_CAPACITY = -1, -2, -3, -4, -5, -6
+FMT_C32, FMT_I16 = 0, 1
+K_RANGE, K_DOPPLER, K_METRICS, K_CFAR, K_COUNT = 0, 1, 2, 3, 8
+KERNEL_NAMES = {K_RANGE: "range", K_DOPPLER: "doppler", K_METRICS: "metrics", K_CFAR: "cfar"}
+
+
+class Blah2HipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"blah2hip error {code}: {msg}")
+        self.code = code
+
+
+class AmbDims(C.Structure):
+    _fields_ = [("n_doppler_bins", C.c_uint32), ("n_delay_bins", C.c_uint32), ("n_corr", C.c_uint32),
+                ("nfft", C.c_uint32), ("n_samples", C.c_uint32), ("n_used", C.c_uint32),
+                ("cpi", C.c_double), ("doppler_middle", C.c_double), ("fft_len", C.c_uint32),
+                ("n_seg", C.c_uint32), ("seg_len", C.c_uint32), ("max_batch", C.c_uint32)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("row", C.c_int32), ("col", C.c_int32), ("snr", C.c_double)]
+
+
+# every symbol include/blah2hip.h declares: name -> (restype, argtypes)
+_vp, _u32, _i32, _dbl = C.c_void_p, C.c_uint32, C.c_int32, C.c_double
+SYMBOLS = {
+    "blah2hip_last_error": (C.c_char_p, []),
+    "blah2hip_version": (C.c_char_p, []),
+    "blah2hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "blah2hip_next_hamming": (_u32, [_u32]),
+    "blah2hip_amb_create": (C.c_int, [_i32, _i32, _i32, _i32, _u32, _u32, C.c_int, C.c_int, _u32, C.POINTER(_vp)]),
+    "blah2hip_amb_destroy": (C.c_int, [_vp]),
+    "blah2hip_amb_get_dims": (C.c_int, [_vp, C.POINTER(AmbDims)]),
+    "blah2hip_amb_get_axes": (C.c_int, [_vp, _vp, _vp]),
+    "blah2hip_amb_process_c64": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp]),
+    "blah2hip_amb_process_c32": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp]),
+    "blah2hip_amb_process_i16": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
+    "blah2hip_amb_process_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _u32, C.c_uint64, _vp, _vp, _vp]),
+    "blah2hip_amb_read_last": (C.c_int, [_vp, _u32, _vp, _vp]),
+    "blah2hip_cfar1d_dev": (C.c_int, [_vp, _vp, _vp, _u32, _dbl, _i32, _i32, _i32, _dbl, _vp, _u32, _vp, _vp]),
+    "blah2hip_cfar1d_process": (C.c_int, [_vp, _u32, _dbl, _i32, _i32, _i32, _dbl, _vp, _vp, _vp, _u32, C.POINTER(_u32)]),
+    "blah2hip_clutter_create": (C.c_int, [_i32, _i32, _u32, C.c_int, _u32, C.POINTER(_vp)]),
+    "blah2hip_clutter_destroy": (C.c_int, [_vp]),
+    "blah2hip_clutter_process_c64": (C.c_int, [_vp, _vp, _vp, _u32, _vp, C.POINTER(C.c_int)]),
+    "blah2hip_clutter_process_c32": (C.c_int, [_vp, _vp, _vp, _u32, _vp, C.POINTER(C.c_int)]),
+    "blah2hip_clutter_process_dev": (C.c_int, [_vp, _vp, _vp, _u32, C.c_uint64, _vp, _vp, _vp]),
+    "blah2hip_amb_set_timing": (C.c_int, [_vp, C.c_int]),
+    "blah2hip_amb_get_timing": (C.c_int, [_vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libblah2hip.so (built by ``python -m blah2_amd.build``) or raises."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m blah2_amd.build` "
+            "(there is no CPU fallback for the HIP path)")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)  # AttributeError when the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != OK:
+        raise Blah2HipError(rc, load().blah2hip_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = load().blah2hip_device_count(C.byref(n))
+    return n.value if rc == OK else 0

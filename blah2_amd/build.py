@@ -1,0 +1,87 @@
+"""Builds the HIP library (and the host-side C++ classes) in-tree for gfx950.
+
+    python -m blah2_amd.build            # build everything that is stale
+    python -m blah2_amd.build --force
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the
+resulting ``blah2_amd/libblah2hip.so`` travels to the GPU box with the tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(PKG, "host")
+LIB = os.path.join(PKG, "libblah2hip.so")
+HOSTLIB = os.path.join(PKG, "libblah2host.so")
+ARCH = "gfx950"
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _sources(d, exts):
+    out = []
+    for base, _, files in os.walk(d):
+        for f in files:
+            if f.endswith(exts):
+                out.append(os.path.join(base, f))
+    return sorted(out)
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP library cannot be built")
+    return exe
+
+
+def build_hip(force=False, verbose=True):
+    srcs = _sources(CSRC, (".hip",))
+    deps = srcs + _sources(CSRC, (".hpp",)) + [os.path.join(ROOT, "include", "blah2hip.h")]
+    if not force and not _newer(LIB, deps):
+        return LIB
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-I", CSRC, *srcs, "-o", LIB]
+    if verbose:
+        print("[blah2_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_host(force=False, verbose=True):
+    """C++ classes with the reference's own surface (Ambiguity, Map, IqData, ...)."""
+    srcs = _sources(HOST, (".cpp",))
+    srcs = [s for s in srcs if not os.path.basename(s).startswith("test_")]
+    if not srcs:
+        return None
+    deps = srcs + _sources(HOST, (".h",)) + [os.path.join(ROOT, "include", "blah2hip.h"), LIB]
+    if not force and not _newer(HOSTLIB, deps):
+        return HOSTLIB
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"),
+           "-I", HOST, *srcs, "-o", HOSTLIB, "-L", PKG, "-lblah2hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print("[blah2_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HOSTLIB
+
+
+def build_all(force=False, verbose=True):
+    out = [build_hip(force, verbose)]
+    h = build_host(force, verbose)
+    if h:
+        out.append(h)
+    return out
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,616 @@
+// C-ABI implementation of include/blah2hip.h: handle management, execution
+// planning, table generation and kernel launches.  gfx950 only; links against
+// libamdhip64 and nothing else.
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+using namespace blah2;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(BLAH2HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+// exp(-2*pi*i*k/n) from the exactly reduced angle, fp64 -> fp32
+cf root_of_unity(int64_t k, int64_t n)
+{
+  k %= n;
+  if (k < 0) k += n;
+  const double a = -2.0 * M_PI * (double)k / (double)n;
+  // octant folding keeps the argument of sin/cos small; fp64 is ample for an fp32 result
+  return cmake((float)std::cos(a), (float)std::sin(a));
+}
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+} // namespace
+
+struct blah2hip_amb_s {
+  int device = 0;
+  blah2hip_amb_dims_t dims{};
+  int32_t delayMin = 0, delayMax = 0, dopplerMin = 0, dopplerMax = 0;
+  uint32_t fs = 0;
+  int r3 = 8;
+  RangePlan plan{};
+  std::vector<int32_t> delayAxis;
+  std::vector<double> dopplerAxis;
+  hipStream_t stream = nullptr;
+  int numCU = 256;
+  int rangeGridCap = 1024;
+  size_t rangeLds = 0;
+
+  cf *d_tw = nullptr;
+  cf *d_dopW = nullptr;
+  cf *d_R = nullptr;
+  cf *d_map = nullptr;
+  double *d_partSum = nullptr;
+  float *d_partMax = nullptr;
+  double *d_metrics = nullptr;
+  double *d_doppler = nullptr;
+  double *d_alpha = nullptr;
+  void *d_in = nullptr; // staging for the host entry points
+  size_t d_in_bytes = 0;
+  cf *d_rot = nullptr; // rotated reference / converted planes for asymmetric Doppler limits
+  blah2hip_hit_t *d_hits = nullptr;
+  uint32_t *d_count = nullptr;
+  uint32_t hitCap = 0;
+  int dopTilesX = 0, dopTilesY = 0;
+
+  bool timing = false;
+  std::vector<EventPair> ev[BLAH2HIP_K_COUNT];
+  std::vector<EventPair> evPool;
+};
+
+namespace {
+
+// ---------------------------------------------------------------- planning --
+// Ambiguity::Ambiguity, Ambiguity.cpp:11-82 (same fp64 expressions, same
+// uint16 narrowing of nDelayBins / nDopplerBins / nCorr, Ambiguity.h:80-89)
+void derive_dims(blah2hip_amb_s *h, uint32_t n, bool roundHamming)
+{
+  auto &d = h->dims;
+  d.n_samples = n;
+  d.n_delay_bins = (uint16_t)(h->delayMax - h->delayMin + 1);
+  d.doppler_middle = (h->dopplerMin + h->dopplerMax) / 2.0;
+  std::deque<double> doppler;
+  double res = 1.0 / ((double)n / (double)h->fs);
+  doppler.push_back(d.doppler_middle);
+  int i = 1;
+  while (d.doppler_middle + (i * res) <= h->dopplerMax) {
+    doppler.push_back(d.doppler_middle + (i * res));
+    doppler.push_front(d.doppler_middle - (i * res));
+    i++;
+  }
+  d.n_doppler_bins = (uint16_t)doppler.size();
+  d.n_corr = (uint16_t)(n / d.n_doppler_bins);
+  d.cpi = ((double)d.n_corr * d.n_doppler_bins) / h->fs;
+  res = 1.0 / d.cpi;
+  h->delayAxis.resize(d.n_delay_bins);
+  for (uint32_t j = 0; j < d.n_delay_bins; j++) h->delayAxis[j] = h->delayMin + (int32_t)j;
+  std::deque<double> ax;
+  ax.push_front(d.doppler_middle);
+  i = 1;
+  while (ax.size() < d.n_doppler_bins) {
+    ax.push_back(d.doppler_middle + (i * res));
+    ax.push_front(d.doppler_middle - (i * res));
+    i++;
+  }
+  h->dopplerAxis.assign(ax.begin(), ax.end());
+  d.nfft = 2 * d.n_corr - 1;
+  if (roundHamming) d.nfft = blah2hip_next_hamming(d.nfft);
+  d.n_used = d.n_corr * d.n_doppler_bins;
+}
+
+// pick F = 256*R3 and the segmentation minimising (2*nSeg+1) * F*log2(F)
+bool choose_plan(blah2hip_amb_s *h)
+{
+  const int nCorr = h->dims.n_corr, nDelay = h->dims.n_delay_bins;
+  int forced = 0;
+  if (const char *e = std::getenv("BLAH2HIP_FFT_LEN")) forced = std::atoi(e);
+  double best = 1e300;
+  bool found = false;
+  for (int r3 : {4, 8, 16}) {
+    const int F = 256 * r3;
+    if (forced && F != forced) continue;
+    const int lmax = F - nDelay + 1;
+    if (lmax < 16) continue;
+    const int nSeg = (nCorr + lmax - 1) / lmax;
+    const int segLen = (nCorr + nSeg - 1) / nSeg;
+    const double cost = (2.0 * nSeg + 1.0) * F * std::log2((double)F);
+    if (cost < best) {
+      best = cost;
+      found = true;
+      h->r3 = r3;
+      h->plan.nSeg = nSeg;
+      h->plan.segLen = segLen;
+      h->plan.scale = 1.0f / (float)F;
+    }
+  }
+  if (!found) return false;
+  h->plan.nCorr = nCorr;
+  h->plan.nDoppler = h->dims.n_doppler_bins;
+  h->plan.nDelay = nDelay;
+  h->plan.delayMin = h->delayMin;
+  h->dims.fft_len = 256 * h->r3;
+  h->dims.n_seg = h->plan.nSeg;
+  h->dims.seg_len = h->plan.segLen;
+  return true;
+}
+
+template <int R3, class In> int launch_range_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
+{
+  using W = WgFft<R3>;
+  const size_t lds = (size_t)(W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
+  auto kern = range_kernel<R3, In>;
+  static thread_local const void *configured = nullptr;
+  if (configured != (const void *)kern) {
+    HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = (const void *)kern;
+  }
+  const int grid = std::min<int>(a.nPulses, h->rangeGridCap);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(W::T), lds, st, a, in);
+  HIPCHK(hipGetLastError());
+  return BLAH2HIP_OK;
+}
+
+template <class In> int launch_range(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
+{
+  switch (h->r3) {
+  case 4: return launch_range_t<4>(h, a, in, st);
+  case 8: return launch_range_t<8>(h, a, in, st);
+  default: return launch_range_t<16>(h, a, in, st);
+  }
+}
+
+int tic(blah2hip_amb_s *h, int k, hipStream_t st)
+{
+  if (!h->timing) return BLAH2HIP_OK;
+  EventPair p;
+  if (!h->evPool.empty()) {
+    p = h->evPool.back();
+    h->evPool.pop_back();
+  } else {
+    HIPCHK(hipEventCreate(&p.a));
+    HIPCHK(hipEventCreate(&p.b));
+  }
+  HIPCHK(hipEventRecord(p.a, st));
+  h->ev[k].push_back(p);
+  return BLAH2HIP_OK;
+}
+
+int toc(blah2hip_amb_s *h, int k, hipStream_t st)
+{
+  if (!h->timing) return BLAH2HIP_OK;
+  HIPCHK(hipEventRecord(h->ev[k].back().b, st));
+  return BLAH2HIP_OK;
+}
+
+int ensure_staging(blah2hip_amb_s *h, size_t bytes)
+{
+  if (h->d_in_bytes >= bytes) return BLAH2HIP_OK;
+  if (h->d_in) HIPCHK(hipFree(h->d_in));
+  h->d_in = nullptr;
+  h->d_in_bytes = 0;
+  HIPCHK(hipMalloc(&h->d_in, bytes));
+  h->d_in_bytes = bytes;
+  return BLAH2HIP_OK;
+}
+
+int host_tail(blah2hip_amb_s *h, float *map_out, double *metrics)
+{
+  const size_t cells = (size_t)h->dims.n_doppler_bins * h->dims.n_delay_bins;
+  if (map_out) HIPCHK(hipMemcpyAsync(map_out, h->d_map, cells * sizeof(cf), hipMemcpyDeviceToHost, h->stream));
+  if (metrics) HIPCHK(hipMemcpyAsync(metrics, h->d_metrics, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return BLAH2HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *blah2hip_last_error(void) { return g_err.c_str(); }
+const char *blah2hip_version(void) { return "blah2hip 0.1 (gfx950)"; }
+
+int blah2hip_device_count(int *count)
+{
+  if (!count) return fail(BLAH2HIP_ERR_INVALID, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return fail(BLAH2HIP_ERR_NO_DEVICE, hipGetErrorString(e)); }
+  *count = n;
+  return BLAH2HIP_OK;
+}
+
+// HammingNumber.cpp:38-48: first 5-smooth number strictly above v.
+uint32_t blah2hip_next_hamming(uint32_t v)
+{
+  uint64_t best = 0;
+  for (uint64_t a = 1; a <= 2 * (uint64_t)v + 2; a *= 2)
+    for (uint64_t b = a; b <= 2 * (uint64_t)v + 2; b *= 3)
+      for (uint64_t c = b; c <= 2 * (uint64_t)v + 2; c *= 5)
+        if (c > v && (best == 0 || c < best)) best = c;
+  return (uint32_t)best;
+}
+
+int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_min,
+                        int32_t doppler_max, uint32_t fs, uint32_t n, int round_hamming, int device,
+                        uint32_t max_batch, blah2hip_amb_t *out)
+{
+  if (!out) return fail(BLAH2HIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (fs == 0 || n == 0) return fail(BLAH2HIP_ERR_INVALID, "fs and n must be positive");
+  if (delay_max < delay_min) return fail(BLAH2HIP_ERR_INVALID, "delayMax < delayMin");
+  if (doppler_max < doppler_min) return fail(BLAH2HIP_ERR_INVALID, "dopplerMax < dopplerMin");
+  // the reference's lag gather (Ambiguity.cpp:132-146) is only in range for these
+  if (delay_min > 1 || delay_max < -1)
+    return fail(BLAH2HIP_ERR_UNSUPPORTED, "reference requires delayMin <= 1 and delayMax >= -1");
+  if (max_batch == 0) max_batch = 1;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(BLAH2HIP_ERR_NO_DEVICE, "no HIP device visible (the HIP path is the only path)");
+  if (device < 0 || device >= ndev) return fail(BLAH2HIP_ERR_INVALID, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+
+  auto *h = new blah2hip_amb_s;
+  h->device = device;
+  h->delayMin = delay_min; h->delayMax = delay_max;
+  h->dopplerMin = doppler_min; h->dopplerMax = doppler_max;
+  h->fs = fs;
+  derive_dims(h, n, round_hamming != 0);
+  h->dims.max_batch = max_batch;
+  if (h->dims.n_corr == 0) { delete h; return fail(BLAH2HIP_ERR_INVALID, "nCorr == 0"); }
+  if (!choose_plan(h)) {
+    delete h;
+    return fail(BLAH2HIP_ERR_UNSUPPORTED, "nDelayBins too large for the on-chip transform lengths (<= 4096)");
+  }
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  h->numCU = prop.multiProcessorCount;
+  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+
+  const uint32_t nD = h->dims.n_doppler_bins, nDelay = h->dims.n_delay_bins;
+  const int F = h->dims.fft_len;
+  // range kernel residency: LDS-limited
+  {
+    const size_t lds = (h->r3 == 4 ? (size_t)(WgFft<4>::A_ELEMS + WgFft<4>::B_ELEMS)
+                        : h->r3 == 8 ? (size_t)(WgFft<8>::A_ELEMS + WgFft<8>::B_ELEMS)
+                                     : (size_t)(WgFft<16>::A_ELEMS + WgFft<16>::B_ELEMS)) * sizeof(cf);
+    h->rangeLds = lds;
+    int perCU = (int)((160 * 1024) / lds);
+    const int wavesPerWg = (16 * h->r3) / 64;
+    perCU = std::min(perCU, 32 / wavesPerWg);
+    perCU = std::max(perCU, 1);
+    h->rangeGridCap = perCU * h->numCU;
+    if (const char *e = std::getenv("BLAH2HIP_RANGE_GRID")) h->rangeGridCap = std::max(1, std::atoi(e));
+  }
+
+  std::vector<cf> tw(F);
+  for (int k = 0; k < F; k++) tw[k] = root_of_unity(k, F);
+  std::vector<cf> dw(nD);
+  for (uint32_t k = 0; k < nD; k++) dw[k] = root_of_unity(k, nD);
+  const size_t cells = (size_t)nD * nDelay;
+  h->dopTilesX = (nDelay + 63) / 64;
+  h->dopTilesY = (nD + DOP_KPT - 1) / DOP_KPT;
+  const size_t nTiles = (size_t)h->dopTilesX * h->dopTilesY;
+
+  HIPCHK(hipMalloc(&h->d_tw, F * sizeof(cf)));
+  HIPCHK(hipMalloc(&h->d_dopW, nD * sizeof(cf)));
+  HIPCHK(hipMalloc(&h->d_R, cells * max_batch * sizeof(cf)));
+  HIPCHK(hipMalloc(&h->d_map, cells * max_batch * sizeof(cf)));
+  HIPCHK(hipMalloc(&h->d_partSum, nTiles * max_batch * sizeof(double)));
+  HIPCHK(hipMalloc(&h->d_partMax, nTiles * max_batch * sizeof(float)));
+  HIPCHK(hipMalloc(&h->d_metrics, 2 * max_batch * sizeof(double)));
+  HIPCHK(hipMalloc(&h->d_doppler, nD * sizeof(double)));
+  HIPCHK(hipMalloc(&h->d_alpha, 256 * sizeof(double)));
+  HIPCHK(hipMalloc(&h->d_count, max_batch * sizeof(uint32_t)));
+  HIPCHK(hipMemcpy(h->d_tw, tw.data(), F * sizeof(cf), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_dopW, dw.data(), nD * sizeof(cf), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_doppler, h->dopplerAxis.data(), nD * sizeof(double), hipMemcpyHostToDevice));
+  *out = h;
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_amb_destroy(blah2hip_amb_t h)
+{
+  if (!h) return BLAH2HIP_OK;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (void *p : {(void *)h->d_tw, (void *)h->d_dopW, (void *)h->d_R, (void *)h->d_map,
+                  (void *)h->d_partSum, (void *)h->d_partMax, (void *)h->d_metrics,
+                  (void *)h->d_doppler, (void *)h->d_alpha, h->d_in, (void *)h->d_rot,
+                  (void *)h->d_hits, (void *)h->d_count})
+    if (p) hipFree(p);
+  for (auto &v : h->ev)
+    for (auto &p : v) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto &p : h->evPool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_amb_get_dims(blah2hip_amb_t h, blah2hip_amb_dims_t *dims)
+{
+  if (!h || !dims) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  *dims = h->dims;
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler)
+{
+  if (!h) return fail(BLAH2HIP_ERR_INVALID, "NULL handle");
+  if (delay) std::memcpy(delay, h->delayAxis.data(), h->delayAxis.size() * sizeof(int32_t));
+  if (doppler) std::memcpy(doppler, h->dopplerAxis.data(), h->dopplerAxis.size() * sizeof(double));
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const void *d_y,
+                             uint32_t n_cpi, uint64_t cpi_stride, void *d_map, double *d_metrics,
+                             void *stream)
+{
+  if (!h) return fail(BLAH2HIP_ERR_INVALID, "NULL handle");
+  if (n_cpi == 0 || n_cpi > h->dims.max_batch) return fail(BLAH2HIP_ERR_INVALID, "n_cpi outside [1, max_batch]");
+  if (fmt != BLAH2HIP_FMT_C32 && fmt != BLAH2HIP_FMT_I16) return fail(BLAH2HIP_ERR_INVALID, "unknown sample format");
+  if (!d_x || (fmt == BLAH2HIP_FMT_C32 && !d_y)) return fail(BLAH2HIP_ERR_INVALID, "NULL input pointer");
+  if (n_cpi > 1 && cpi_stride < h->dims.n_used) return fail(BLAH2HIP_ERR_INVALID, "cpi_stride < samples used per CPI");
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t nD = h->dims.n_doppler_bins, nDelay = h->dims.n_delay_bins;
+  cf *map = d_map ? (cf *)d_map : h->d_map;
+  double *met = d_metrics ? d_metrics : h->d_metrics;
+
+  RangeArgs ra;
+  ra.plan = h->plan;
+  ra.tw = h->d_tw;
+  ra.out = h->d_R;
+  ra.cpiStride = (int64_t)cpi_stride;
+  ra.nPulses = (int32_t)(n_cpi * nD);
+
+  const int32_t m2 = h->dopplerMin + h->dopplerMax;
+  int rc;
+  if (m2 != 0) {
+    // Ambiguity.cpp:95-102: rotate the reference channel about the Doppler centre.
+    // Rare (asymmetric limits only): one extra pass writes both channels as
+    // complex fp32 planes with stride n_samples, then the range kernel runs on those.
+    const size_t plane = (size_t)h->dims.n_samples;
+    if (!h->d_rot) HIPCHK(hipMalloc(&h->d_rot, 2 * plane * h->dims.max_batch * sizeof(cf)));
+    cf *xo = h->d_rot, *yo = h->d_rot + plane * h->dims.max_batch;
+    const uint32_t nrot = h->dims.n_used; // later samples are never read by the range loop
+    dim3 grid(std::min<uint32_t>((nrot + 255) / 256, 2048), n_cpi);
+    if (fmt == BLAH2HIP_FMT_C32) {
+      InC32 in{(const cf *)d_x, (const cf *)d_y};
+      hipLaunchKernelGGL(rotate_kernel<InC32>, grid, dim3(256), 0, st, in, xo, yo,
+                         (int64_t)cpi_stride, (int64_t)plane, nrot, m2, h->fs);
+    } else {
+      InI16 in{(const int16_t *)d_x};
+      hipLaunchKernelGGL(rotate_kernel<InI16>, grid, dim3(256), 0, st, in, xo, yo,
+                         (int64_t)cpi_stride, (int64_t)plane, nrot, m2, h->fs);
+    }
+    HIPCHK(hipGetLastError());
+    ra.cpiStride = (int64_t)plane;
+    InC32 in2{xo, yo};
+    if ((rc = tic(h, BLAH2HIP_K_RANGE, st))) return rc;
+    if ((rc = launch_range(h, ra, in2, st))) return rc;
+    if ((rc = toc(h, BLAH2HIP_K_RANGE, st))) return rc;
+  } else {
+    if ((rc = tic(h, BLAH2HIP_K_RANGE, st))) return rc;
+    if (fmt == BLAH2HIP_FMT_C32) {
+      InC32 in{(const cf *)d_x, (const cf *)d_y};
+      rc = launch_range(h, ra, in, st);
+    } else {
+      InI16 in{(const int16_t *)d_x};
+      rc = launch_range(h, ra, in, st);
+    }
+    if (rc) return rc;
+    if ((rc = toc(h, BLAH2HIP_K_RANGE, st))) return rc;
+  }
+
+  DopplerArgs da;
+  da.R = h->d_R;
+  da.map = map;
+  da.W = h->d_dopW;
+  da.partSum = h->d_partSum;
+  da.partMax = h->d_partMax;
+  da.nD = (int32_t)nD;
+  da.nDelay = (int32_t)nDelay;
+  if ((rc = tic(h, BLAH2HIP_K_DOPPLER, st))) return rc;
+  hipLaunchKernelGGL(doppler_dft_kernel, dim3(h->dopTilesX, h->dopTilesY, n_cpi), dim3(64 * DOP_WAVES), 0, st, da);
+  HIPCHK(hipGetLastError());
+  if ((rc = toc(h, BLAH2HIP_K_DOPPLER, st))) return rc;
+
+  if ((rc = tic(h, BLAH2HIP_K_METRICS, st))) return rc;
+  hipLaunchKernelGGL(metrics_kernel, dim3(n_cpi), dim3(256), 0, st, h->d_partSum, h->d_partMax,
+                     h->dopTilesX * h->dopTilesY, (double)nD * (double)nDelay, met);
+  HIPCHK(hipGetLastError());
+  if ((rc = toc(h, BLAH2HIP_K_METRICS, st))) return rc;
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_amb_read_last(blah2hip_amb_t h, uint32_t cpi, float *map_out, double *metrics)
+{
+  if (!h) return fail(BLAH2HIP_ERR_INVALID, "NULL handle");
+  if (cpi >= h->dims.max_batch) return fail(BLAH2HIP_ERR_INVALID, "cpi index out of range");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  const size_t cells = (size_t)h->dims.n_doppler_bins * h->dims.n_delay_bins;
+  if (map_out) HIPCHK(hipMemcpy(map_out, h->d_map + cells * cpi, cells * sizeof(cf), hipMemcpyDeviceToHost));
+  if (metrics) HIPCHK(hipMemcpy(metrics, h->d_metrics + 2 * cpi, 2 * sizeof(double), hipMemcpyDeviceToHost));
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_amb_process_c32(blah2hip_amb_t h, const float *x, const float *y, uint32_t n,
+                             float *map_out, double *metrics)
+{
+  if (!h || !x || !y) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (n < h->dims.n_used) return fail(BLAH2HIP_ERR_UNDERFLOW, "Attempting to pop from an empty deque");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t bytes = (size_t)n * sizeof(cf);
+  int rc;
+  if ((rc = ensure_staging(h, 2 * bytes))) return rc;
+  char *dx = (char *)h->d_in, *dy = dx + bytes;
+  HIPCHK(hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, h->stream));
+  if ((rc = blah2hip_amb_process_dev(h, BLAH2HIP_FMT_C32, dx, dy, 1, n, nullptr, nullptr, h->stream))) return rc;
+  return host_tail(h, map_out, metrics);
+}
+
+int blah2hip_amb_process_c64(blah2hip_amb_t h, const double *x, const double *y, uint32_t n,
+                             float *map_out, double *metrics)
+{
+  if (!h || !x || !y) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (n < h->dims.n_used) return fail(BLAH2HIP_ERR_UNDERFLOW, "Attempting to pop from an empty deque");
+  // IqData holds complex<double>; the kernels compute in fp32 (BASELINE.json)
+  std::vector<float> fx(2 * (size_t)n), fy(2 * (size_t)n);
+  for (size_t i = 0; i < 2 * (size_t)n; i++) { fx[i] = (float)x[i]; fy[i] = (float)y[i]; }
+  return blah2hip_amb_process_c32(h, fx.data(), fy.data(), n, map_out, metrics);
+}
+
+int blah2hip_amb_process_i16(blah2hip_amb_t h, const int16_t *iq, uint32_t n, float *map_out,
+                             double *metrics)
+{
+  if (!h || !iq) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (n < h->dims.n_used) return fail(BLAH2HIP_ERR_UNDERFLOW, "Attempting to pop from an empty deque");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t bytes = (size_t)n * 4 * sizeof(int16_t);
+  int rc;
+  if ((rc = ensure_staging(h, bytes))) return rc;
+  HIPCHK(hipMemcpyAsync(h->d_in, iq, bytes, hipMemcpyHostToDevice, h->stream));
+  if ((rc = blah2hip_amb_process_dev(h, BLAH2HIP_FMT_I16, h->d_in, nullptr, 1, n, nullptr, nullptr, h->stream))) return rc;
+  return host_tail(h, map_out, metrics);
+}
+
+// ------------------------------------------------------------------- CFAR --
+int blah2hip_cfar1d_dev(blah2hip_amb_t h, const void *d_map, const double *d_metrics,
+                        uint32_t n_cpi, double pfa, int32_t n_guard, int32_t n_train,
+                        int32_t min_delay, double min_doppler, blah2hip_hit_t *d_hits, uint32_t cap,
+                        uint32_t *d_count, void *stream)
+{
+  if (!h || !d_hits || !d_count) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (n_cpi == 0 || n_cpi > h->dims.max_batch) return fail(BLAH2HIP_ERR_INVALID, "n_cpi outside [1, max_batch]");
+  // CfarDetector1D's ctor parameters are int8_t (CfarDetector1D.h:46)
+  if (n_guard < 0 || n_guard > 127 || n_train < 0 || n_train > 127 || min_delay < -128 || min_delay > 127)
+    return fail(BLAH2HIP_ERR_INVALID, "nGuard/nTrain/minDelay outside int8 range");
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  // alpha = nCells*(pow(pfa,-1/nCells)-1)  (CfarDetector1D.cpp:76), same libm call
+  double alpha[256];
+  alpha[0] = std::nan("");
+  for (int n = 1; n <= 2 * n_train; n++) alpha[n] = n * (pow(pfa, -1.0 / n) - 1);
+  HIPCHK(hipMemcpyAsync(h->d_alpha, alpha, (2 * n_train + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(d_count, 0, n_cpi * sizeof(uint32_t), st));
+  CfarArgs a;
+  a.map = d_map ? (const cf *)d_map : h->d_map;
+  a.metrics = d_metrics ? d_metrics : h->d_metrics;
+  a.doppler = h->d_doppler;
+  a.alpha = h->d_alpha;
+  a.hits = d_hits;
+  a.count = d_count;
+  a.nD = (int32_t)h->dims.n_doppler_bins;
+  a.nDelay = (int32_t)h->dims.n_delay_bins;
+  a.delayMin = h->delayMin;
+  a.nGuard = n_guard; a.nTrain = n_train; a.minDelay = min_delay;
+  a.minDoppler = min_doppler;
+  a.cap = cap;
+  int rc;
+  if ((rc = tic(h, BLAH2HIP_K_CFAR, st))) return rc;
+  hipLaunchKernelGGL(cfar1d_kernel, dim3(a.nD, n_cpi), dim3(256), (size_t)a.nDelay * sizeof(double), st, a);
+  HIPCHK(hipGetLastError());
+  if ((rc = toc(h, BLAH2HIP_K_CFAR, st))) return rc;
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_cfar1d_process(blah2hip_amb_t h, uint32_t cpi, double pfa, int32_t n_guard,
+                            int32_t n_train, int32_t min_delay, double min_doppler, double *delay,
+                            double *doppler, double *snr, uint32_t cap, uint32_t *count)
+{
+  if (!h || !count) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (cpi >= h->dims.max_batch) return fail(BLAH2HIP_ERR_INVALID, "cpi index out of range");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t cells = (size_t)h->dims.n_doppler_bins * h->dims.n_delay_bins;
+  // worst case every cell fires; size the device list for that once
+  if (h->hitCap < cells) {
+    if (h->d_hits) HIPCHK(hipFree(h->d_hits));
+    h->d_hits = nullptr;
+    HIPCHK(hipMalloc(&h->d_hits, cells * sizeof(blah2hip_hit_t)));
+    h->hitCap = (uint32_t)cells;
+  }
+  // run on a one-CPI view of the internal buffers
+  const cf *m = h->d_map + cells * cpi;
+  const double *met = h->d_metrics + 2 * cpi;
+  int rc = blah2hip_cfar1d_dev(h, m, met, 1, pfa, n_guard, n_train, min_delay, min_doppler, h->d_hits,
+                               h->hitCap, h->d_count, h->stream);
+  if (rc) return rc;
+  uint32_t n = 0;
+  HIPCHK(hipMemcpyAsync(&n, h->d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  n = std::min(n, h->hitCap);
+  std::vector<blah2hip_hit_t> hits(n);
+  if (n) HIPCHK(hipMemcpy(hits.data(), h->d_hits, n * sizeof(blah2hip_hit_t), hipMemcpyDeviceToHost));
+  // the reference emits row by row, then by delay (CfarDetector1D.cpp:36-92)
+  std::sort(hits.begin(), hits.end(), [](const blah2hip_hit_t &a, const blah2hip_hit_t &b) {
+    return a.row != b.row ? a.row < b.row : a.col < b.col;
+  });
+  *count = n;
+  if (n > cap) return fail(BLAH2HIP_ERR_CAPACITY, "detection capacity too small");
+  for (uint32_t i = 0; i < n; i++) {
+    if (delay) delay[i] = (double)(hits[i].col + h->delayAxis[0]); // :88  j + x->delay[0]
+    if (doppler) doppler[i] = h->dopplerAxis[hits[i].row];         // :89
+    if (snr) snr[i] = hits[i].snr;                                 // :90
+  }
+  return BLAH2HIP_OK;
+}
+
+// ----------------------------------------------------------------- timing --
+int blah2hip_amb_set_timing(blah2hip_amb_t h, int enable)
+{
+  if (!h) return fail(BLAH2HIP_ERR_INVALID, "NULL handle");
+  h->timing = enable != 0;
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_amb_get_timing(blah2hip_amb_t h, double *ms_total, uint32_t *launches)
+{
+  if (!h || !ms_total || !launches) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  for (int k = 0; k < BLAH2HIP_K_COUNT; k++) {
+    double tot = 0.0;
+    for (auto &p : h->ev[k]) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
+      tot += ms;
+      h->evPool.push_back(p);
+    }
+    ms_total[k] = tot;
+    launches[k] = (uint32_t)h->ev[k].size();
+    h->ev[k].clear();
+  }
+  return BLAH2HIP_OK;
+}
+
+// ---------------------------------------------------------------- clutter --
+// (implemented in clutter.hip)
+
+} // extern "C"

@@ -1,0 +1,91 @@
+// Per-thread pieces of the range (Hot loop A) kernel that are independent of
+// the launch machinery, shared by the HIP kernel (ambiguity_kernels.hip) and
+// the host emulation test (tests/host/emulate_fft.cpp).
+//
+// What it computes -- /root/reference/src/process/ambiguity/Ambiguity.cpp:106-149:
+// for pulse i and lag d in [delayMin, delayMax]
+//     R[i][d] = sum_{n=0}^{nCorr-1} y[i*nCorr + n + d] * conj(x[i*nCorr + n])
+// with y taken as zero outside the pulse (the reference zero-pads each pulse to
+// nfft >= 2*nCorr-1, :114-118, so neighbouring pulses never contribute).
+//
+// How: the reference does one nfft-point circular correlation per pulse and
+// keeps nDelayBins of the nfft lags.  Only those lags are wanted, so the pulse is
+// cut into nSeg segments of segLen samples; for segment s
+//     x'[m] = x[s*segLen + m]              m in [0, segLen)      , 0 elsewhere
+//     y'[m] = y[s*segLen + delayMin + m]   (0 outside the pulse)
+// and with F >= segLen + nDelayBins - 1 the F-point circular correlation
+//     c_s[k] = sum_n y'[(n+k) mod F] conj(x'[n]),  k in [0, nDelayBins)
+// never wraps, so R[i][delayMin + k] = sum_s c_s[k].  The sum over segments is
+// taken in the frequency domain (registers), followed by ONE inverse transform
+// per pulse.  The result is the same linear correlation the reference computes,
+// i.e. mathematically identical, not an approximation.
+#pragma once
+
+#include "fft_wg.hpp"
+
+#include <stdint.h>
+
+namespace blah2 {
+
+struct RangePlan {
+  int32_t nCorr;     // samples per pulse (Ambiguity.cpp:39)
+  int32_t nDoppler;  // pulses per CPI   (Ambiguity.cpp:37)
+  int32_t nDelay;    // lags kept        (Ambiguity.cpp:22)
+  int32_t delayMin;  // first lag
+  int32_t nSeg;      // segments per pulse
+  int32_t segLen;    // samples of x per segment
+  float scale;       // 1/F (the reference divides by nfft before its backward FFT, :126)
+};
+
+// complex fp32 planes: x = reference channel, y = surveillance channel
+struct InC32 {
+  const cf *x;
+  const cf *y;
+  B2_HD cf lx(int64_t i) const { return x[i]; }
+  B2_HD cf ly(int64_t i) const { return y[i]; }
+};
+
+// .rspduo wire layout: int16 I1 Q1 I2 Q2 per sample pair
+// (/root/reference/src/capture/rspduo/RspDuo.cpp:512-526); tuner 1 = reference.
+struct InI16 {
+  const int16_t *iq;
+  B2_HD cf lx(int64_t i) const { return cmake((float)iq[4 * i], (float)iq[4 * i + 1]); }
+  B2_HD cf ly(int64_t i) const { return cmake((float)iq[4 * i + 2], (float)iq[4 * i + 3]); }
+};
+
+template <int R3, class In>
+B2_HD void load_seg_x(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, cf *v)
+{
+  constexpr int T = 16 * R3;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int m = t + T * k;
+    const int idx = s * p.segLen + m;
+    v[k] = (m < p.segLen && idx < p.nCorr) ? in.lx(pulseBase + idx) : cmake(0.f, 0.f);
+  }
+}
+
+template <int R3, class In>
+B2_HD void load_seg_y(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, cf *v)
+{
+  constexpr int T = 16 * R3;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int m = t + T * k;
+    const int idx = s * p.segLen + p.delayMin + m;
+    v[k] = (idx >= 0 && idx < p.nCorr) ? in.ly(pulseBase + idx) : cmake(0.f, 0.f);
+  }
+}
+
+template <int R3>
+B2_HD void store_lags(cf *out, const RangePlan &p, int64_t pulse, int t, const cf *v)
+{
+  constexpr int T = 16 * R3;
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const int j = t + T * c;
+    if (j < p.nDelay) out[pulse * p.nDelay + j] = cmake(v[c].x * p.scale, v[c].y * p.scale);
+  }
+}
+
+} // namespace blah2

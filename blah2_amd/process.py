@@ -1,0 +1,214 @@
+"""Python mirror of the reference's hot-path classes, on top of the C ABI.
+
+Same names, constructor arguments, getters and call order as
+/root/reference/src/process/ambiguity/Ambiguity.h:34-58,
+src/data/Map.h:19-112, src/data/Detection.h:13-70 and
+src/process/detection/CfarDetector1D.h:46-55, so the parity tests read like
+test/unit/process/ambiguity/TestAmbiguity.cpp.  All numerics run in the HIP
+library; this file only marshals buffers.  (The C++ mirror that drops into
+blah2.cpp lives in blah2_amd/host/.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import AmbDims, Blah2HipError, check
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class Map:
+    """src/data/Map.h: rows = Doppler, cols = delay.  ``data`` is complex64."""
+
+    def __init__(self, owner, data, delay, doppler, noise_power, max_power, cpi_index=0):
+        self._owner = owner
+        self._cpi_index = cpi_index
+        self.data = data
+        self.delay = delay
+        self.doppler = doppler
+        self.noisePower = noise_power
+        self.maxPower = max_power
+
+    def get_nRows(self):
+        return self.data.shape[0]
+
+    def get_nCols(self):
+        return self.data.shape[1]
+
+    def set_metrics(self):
+        """Map::set_metrics (Map.cpp:187-206).  The reduction is fused into the
+        Doppler kernel, so the values are already there; kept so that callers
+        can follow blah2.cpp:278-279 verbatim."""
+        return None
+
+
+class Detection:
+    """src/data/Detection.h:13-70."""
+
+    def __init__(self, delay, doppler, snr):
+        self.delay = np.asarray(delay, dtype=np.float64)
+        self.doppler = np.asarray(doppler, dtype=np.float64)
+        self.snr = np.asarray(snr, dtype=np.float64)
+
+    def get_delay(self):
+        return self.delay.copy()
+
+    def get_doppler(self):
+        return self.doppler.copy()
+
+    def get_snr(self):
+        return self.snr.copy()
+
+    def get_nDetections(self):
+        return int(self.delay.size)
+
+
+class Ambiguity:
+    """src/process/ambiguity/Ambiguity.h:34-58."""
+
+    def __init__(self, delayMin, delayMax, dopplerMin, dopplerMax, fs, n, roundHamming=False,
+                 device=0, max_batch=1):
+        L = _lib.load()
+        h = C.c_void_p()
+        check(L.blah2hip_amb_create(delayMin, delayMax, dopplerMin, dopplerMax, fs, n,
+                                    1 if roundHamming else 0, device, max_batch, C.byref(h)))
+        self._h = h
+        self._L = L
+        self.dims = AmbDims()
+        check(L.blah2hip_amb_get_dims(h, C.byref(self.dims)))
+        self.delay = np.zeros(self.dims.n_delay_bins, dtype=np.int32)
+        self.doppler = np.zeros(self.dims.n_doppler_bins, dtype=np.float64)
+        check(L.blah2hip_amb_get_axes(h, _ptr(self.delay), _ptr(self.doppler)))
+        self._n_samples = n
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.blah2hip_amb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- getters (Ambiguity.cpp:174-199) --------------------------------------
+    def get_doppler_middle(self):
+        return self.dims.doppler_middle
+
+    def get_n_delay_bins(self):
+        return self.dims.n_delay_bins
+
+    def get_n_doppler_bins(self):
+        return self.dims.n_doppler_bins
+
+    def get_n_corr(self):
+        return self.dims.n_corr
+
+    def get_cpi(self):
+        return self.dims.cpi
+
+    def get_nfft(self):
+        return self.dims.nfft
+
+    def get_n_samples(self):
+        return self._n_samples
+
+    # -- process --------------------------------------------------------------
+    def _result(self, out, met, cpi_index=0):
+        return Map(self, out, self.delay.copy(), self.doppler.copy(), float(met[0]), float(met[1]), cpi_index)
+
+    def process(self, x, y):
+        """Ambiguity::process (+ Map::set_metrics) on host arrays of complex
+        samples (x = reference, y = surveillance).  Like the reference it
+        consumes n_corr*n_doppler_bins samples and raises on underflow
+        (IqData::pop_front, IqData.cpp:57-59)."""
+        x = np.ascontiguousarray(x)
+        y = np.ascontiguousarray(y)
+        nD, nC = self.dims.n_doppler_bins, self.dims.n_delay_bins
+        out = np.empty((nD, nC), dtype=np.complex64)
+        met = np.zeros(2, dtype=np.float64)
+        if x.dtype == np.complex64 and y.dtype == np.complex64:
+            fn = self._L.blah2hip_amb_process_c32
+        else:
+            x = x.astype(np.complex128, copy=False)
+            y = y.astype(np.complex128, copy=False)
+            fn = self._L.blah2hip_amb_process_c64
+        n = min(x.shape[0], y.shape[0])
+        rc = fn(self._h, _ptr(x), _ptr(y), n, _ptr(out), _ptr(met))
+        if rc == _lib.ERR_UNDERFLOW:
+            raise RuntimeError("Attempting to pop from an empty deque")
+        check(rc)
+        self._n_samples = self.dims.n_used  # Ambiguity.cpp:105
+        return self._result(out, met)
+
+    def process_i16(self, iq):
+        """Same, on the .rspduo wire layout: int16 array [n, 4] = I1 Q1 I2 Q2."""
+        iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1, 4)
+        nD, nC = self.dims.n_doppler_bins, self.dims.n_delay_bins
+        out = np.empty((nD, nC), dtype=np.complex64)
+        met = np.zeros(2, dtype=np.float64)
+        rc = self._L.blah2hip_amb_process_i16(self._h, _ptr(iq), iq.shape[0], _ptr(out), _ptr(met))
+        if rc == _lib.ERR_UNDERFLOW:
+            raise RuntimeError("Attempting to pop from an empty deque")
+        check(rc)
+        self._n_samples = self.dims.n_used
+        return self._result(out, met)
+
+    def process_dev(self, fmt, d_x, d_y, n_cpi, cpi_stride, d_map=None, d_metrics=None, stream=0):
+        """Enqueue the device-resident chain on ``stream`` (raw pointers/ints)."""
+        check(self._L.blah2hip_amb_process_dev(self._h, fmt, d_x, d_y, n_cpi, cpi_stride, d_map,
+                                               d_metrics, stream))
+
+    def read_last(self, cpi=0):
+        nD, nC = self.dims.n_doppler_bins, self.dims.n_delay_bins
+        out = np.empty((nD, nC), dtype=np.complex64)
+        met = np.zeros(2, dtype=np.float64)
+        check(self._L.blah2hip_amb_read_last(self._h, cpi, _ptr(out), _ptr(met)))
+        return self._result(out, met, cpi)
+
+    # -- per-kernel timing -----------------------------------------------------
+    def set_timing(self, enable=True):
+        check(self._L.blah2hip_amb_set_timing(self._h, 1 if enable else 0))
+
+    def get_timing(self):
+        ms = np.zeros(_lib.K_COUNT, dtype=np.float64)
+        cnt = np.zeros(_lib.K_COUNT, dtype=np.uint32)
+        check(self._L.blah2hip_amb_get_timing(self._h, _ptr(ms), _ptr(cnt)))
+        return {name: (float(ms[k]), int(cnt[k])) for k, name in _lib.KERNEL_NAMES.items()}
+
+
+class CfarDetector1D:
+    """src/process/detection/CfarDetector1D.h:46-55."""
+
+    def __init__(self, pfa, nGuard, nTrain, minDelay, minDoppler):
+        for name, v in (("nGuard", nGuard), ("nTrain", nTrain), ("minDelay", minDelay)):
+            if not -128 <= int(v) <= 127:  # int8_t in the reference
+                raise ValueError(f"{name} outside int8 range")
+        self.pfa, self.nGuard, self.nTrain = float(pfa), int(nGuard), int(nTrain)
+        self.minDelay, self.minDoppler = int(minDelay), float(minDoppler)
+
+    def process(self, x: Map) -> Detection:
+        amb = x._owner
+        cells = x.data.size
+        cap = cells
+        d = np.zeros(cap)
+        f = np.zeros(cap)
+        s = np.zeros(cap)
+        n = C.c_uint32(0)
+        check(amb._L.blah2hip_cfar1d_process(amb._h, x._cpi_index, self.pfa, self.nGuard, self.nTrain,
+                                             self.minDelay, self.minDoppler, _ptr(d), _ptr(f), _ptr(s),
+                                             cap, C.byref(n)))
+        k = n.value
+        return Detection(d[:k].copy(), f[:k].copy(), s[:k].copy())
+
+
+def next_hamming(v: int) -> int:
+    """src/process/meta/HammingNumber.cpp:38-48."""
+    return int(_lib.load().blah2hip_next_hamming(v))

@@ -1,0 +1,173 @@
+/* blah2hip.h -- C ABI of the MI355X (gfx950) cross-ambiguity engine for blah2.
+ *
+ * The reference (30hours/blah2) has no plugin/FFI layer: the boundary of its
+ * hot path is the C++ class surface that src/blah2.cpp constructs and calls
+ * once per CPI on its processing thread (blah2.cpp:154-177, 263-289):
+ *
+ *   Ambiguity(delayMin,delayMax,dopplerMin,dopplerMax,fs,n,roundHamming)
+ *       src/process/ambiguity/Ambiguity.h:34   ctor   Ambiguity.cpp:11-82
+ *   Map<complex<double>>* Ambiguity::process(IqData* x, IqData* y)
+ *       src/process/ambiguity/Ambiguity.h:44          Ambiguity.cpp:92-172
+ *   void Map::set_metrics()                            src/data/Map.cpp:187-206
+ *   CfarDetector1D(pfa,nGuard,nTrain,minDelay,minDoppler)::process(Map*)
+ *       src/process/detection/CfarDetector1D.h:46,55   CfarDetector1D.cpp:23-100
+ *   WienerHopf(delayMin,delayMax,nSamples)::process(IqData* x, IqData* y) -> bool
+ *       src/process/clutter/WienerHopf.h:68,78         WienerHopf.cpp:58-163
+ *
+ * This header is what a binding for that path binds: opaque handles, plain
+ * pointers and sizes, int status returns, no exceptions, no C++ or torch types.
+ * blah2_amd/host/ holds source-compatible C++ classes (same names, arguments
+ * and error behaviour as the reference's) implemented on top of it, and
+ * INTEGRATION.md shows how they replace the FFTW path in blah2.cpp.
+ *
+ * Conventions
+ *   - every function returns BLAH2HIP_OK (0) or a negative error code;
+ *     blah2hip_last_error() returns a thread-local description of the last one.
+ *   - "host" entry points take caller-owned host buffers, run on the handle's
+ *     own stream and return when the results are in the output buffers.
+ *   - "dev" entry points take device pointers that are already resident in HBM
+ *     and a hipStream_t (as void*); they only enqueue work and never
+ *     synchronise.  This is the chain the benchmark times.
+ *   - a handle is not re-entrant: one thread at a time, like the reference's
+ *     objects (all three process() calls run on blah2.cpp's single t2 thread).
+ *   - maps are complex fp32, interleaved (re,im), row-major [doppler][delay],
+ *     the layout of Map<T>::data (src/data/Map.h:27).
+ */
+#ifndef BLAH2HIP_H
+#define BLAH2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLAH2HIP_OK 0
+#define BLAH2HIP_ERR_INVALID (-1)     /* bad argument */
+#define BLAH2HIP_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define BLAH2HIP_ERR_UNSUPPORTED (-3) /* configuration outside what the kernels cover */
+#define BLAH2HIP_ERR_UNDERFLOW (-4)   /* fewer samples than one CPI (IqData::pop_front throws, IqData.cpp:57-59) */
+#define BLAH2HIP_ERR_NO_DEVICE (-5)   /* no gfx950 device visible */
+#define BLAH2HIP_ERR_CAPACITY (-6)    /* output capacity too small */
+
+/* input sample formats of the dev entry points */
+#define BLAH2HIP_FMT_C32 0 /* two planes of complex fp32: x = reference, y = surveillance */
+#define BLAH2HIP_FMT_I16 1 /* one buffer, int16 I1 Q1 I2 Q2 per sample (.rspduo, RspDuo.cpp:512-526) */
+
+typedef struct blah2hip_amb_s *blah2hip_amb_t;
+typedef struct blah2hip_clutter_s *blah2hip_clutter_t;
+
+/* Derived sizes: the first block reproduces the reference constructor
+ * (Ambiguity.cpp:22-65) and is what its getters return; the second block is
+ * this engine's execution plan for the range stage. */
+typedef struct blah2hip_amb_dims {
+  uint32_t n_doppler_bins; /* Ambiguity::get_n_doppler_bins */
+  uint32_t n_delay_bins;   /* Ambiguity::get_n_delay_bins   */
+  uint32_t n_corr;         /* Ambiguity::get_n_corr         */
+  uint32_t nfft;           /* Ambiguity::get_nfft (value the reference would plan; reported, not used) */
+  uint32_t n_samples;      /* constructor argument n        */
+  uint32_t n_used;         /* n_corr * n_doppler_bins = samples process() consumes */
+  double cpi;              /* Ambiguity::get_cpi            */
+  double doppler_middle;   /* Ambiguity::get_doppler_middle */
+  uint32_t fft_len;        /* F: on-chip transform length of the range kernel */
+  uint32_t n_seg;          /* segments per pulse */
+  uint32_t seg_len;        /* reference samples per segment */
+  uint32_t max_batch;      /* CPIs one dev call may carry */
+} blah2hip_amb_dims_t;
+
+/* One CFAR hit as the device writes it; the host API converts to the
+ * reference's Detection triplets. */
+typedef struct blah2hip_hit {
+  int32_t row; /* Doppler bin index */
+  int32_t col; /* delay bin index   */
+  double snr;  /* 10*log10|z| - noisePower (CfarDetector1D.cpp:48) */
+} blah2hip_hit_t;
+
+const char *blah2hip_last_error(void);
+const char *blah2hip_version(void);
+int blah2hip_device_count(int *count);
+/* smallest 5-smooth integer strictly greater than v (HammingNumber.cpp:38-48) */
+uint32_t blah2hip_next_hamming(uint32_t v);
+
+/* ---- Ambiguity (Ambiguity.h:34-58) ------------------------------------- */
+int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_min,
+                        int32_t doppler_max, uint32_t fs, uint32_t n, int round_hamming,
+                        int device, uint32_t max_batch, blah2hip_amb_t *out);
+int blah2hip_amb_destroy(blah2hip_amb_t h);
+int blah2hip_amb_get_dims(blah2hip_amb_t h, blah2hip_amb_dims_t *dims);
+/* Map::delay (bins, length n_delay_bins) and Map::doppler (Hz, length n_doppler_bins) */
+int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
+
+/* Ambiguity::process + Map::set_metrics on host buffers (blah2.cpp:278-279).
+ * x = reference, y = surveillance, n complex samples each (n >= n_used, only
+ * the first n_used are consumed, like the reference's pops).  map_out may be
+ * NULL; metrics[0] = noisePower, metrics[1] = maxPower. */
+int blah2hip_amb_process_c64(blah2hip_amb_t h, const double *x, const double *y, uint32_t n,
+                             float *map_out, double *metrics);
+int blah2hip_amb_process_c32(blah2hip_amb_t h, const float *x, const float *y, uint32_t n,
+                             float *map_out, double *metrics);
+int blah2hip_amb_process_i16(blah2hip_amb_t h, const int16_t *iq, uint32_t n, float *map_out,
+                             double *metrics);
+
+/* Device-resident chain: range kernel -> Doppler kernel (+ fused metrics).
+ * d_x/d_y: device pointers (fmt C32: two planes; fmt I16: d_x = interleaved
+ * buffer, d_y ignored).  CPI c starts at sample c*cpi_stride.  d_map:
+ * [n_cpi][n_doppler][n_delay] complex fp32; d_metrics: [n_cpi][2] doubles.
+ * Either output may be NULL (then the handle's internal buffer is used and
+ * can be read with blah2hip_amb_read_last). */
+int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const void *d_y,
+                             uint32_t n_cpi, uint64_t cpi_stride, void *d_map, double *d_metrics,
+                             void *stream);
+/* copies CPI `cpi` of the handle's internal map/metrics to the host (synchronises) */
+int blah2hip_amb_read_last(blah2hip_amb_t h, uint32_t cpi, float *map_out, double *metrics);
+
+/* ---- CfarDetector1D (CfarDetector1D.h:46-55) ---------------------------- */
+/* dev: d_map/d_metrics as written by blah2hip_amb_process_dev (NULL = the
+ * handle's internal buffers).  d_hits: [n_cpi][cap]; d_count: [n_cpi], zeroed
+ * by the call.  Hits are appended in arbitrary order; count may exceed cap
+ * (then only cap were stored). */
+int blah2hip_cfar1d_dev(blah2hip_amb_t h, const void *d_map, const double *d_metrics,
+                        uint32_t n_cpi, double pfa, int32_t n_guard, int32_t n_train,
+                        int32_t min_delay, double min_doppler, blah2hip_hit_t *d_hits,
+                        uint32_t cap, uint32_t *d_count, void *stream);
+/* host: runs the detector on CPI `cpi` of the handle's internal map and
+ * returns Detection's three vectors (delay bins, Doppler Hz, snr) in the
+ * reference's emission order (row-major, CfarDetector1D.cpp:36-92). */
+int blah2hip_cfar1d_process(blah2hip_amb_t h, uint32_t cpi, double pfa, int32_t n_guard,
+                            int32_t n_train, int32_t min_delay, double min_doppler, double *delay,
+                            double *doppler, double *snr, uint32_t cap, uint32_t *count);
+
+/* ---- WienerHopf clutter filter (WienerHopf.h:68-78) --------------------- */
+int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_samples, int device,
+                            uint32_t max_batch, blah2hip_clutter_t *out);
+int blah2hip_clutter_destroy(blah2hip_clutter_t h);
+/* host: y_out = y - w*x (WienerHopf.cpp:156-160); *ok = 0 when the normal
+ * equations are not positive definite (the reference returns false and the CPI
+ * is skipped, blah2.cpp:270-273), in which case y_out is not written. */
+int blah2hip_clutter_process_c64(blah2hip_clutter_t h, const double *x, const double *y, uint32_t n,
+                                 double *y_out, int *ok);
+int blah2hip_clutter_process_c32(blah2hip_clutter_t h, const float *x, const float *y, uint32_t n,
+                                 float *y_out, int *ok);
+/* dev: complex fp32 planes resident in HBM; d_y_out may alias d_y.
+ * d_ok: [n_cpi] int32 flags.  Enqueues only. */
+int blah2hip_clutter_process_dev(blah2hip_clutter_t h, const void *d_x, const void *d_y,
+                                 uint32_t n_cpi, uint64_t cpi_stride, void *d_y_out, int32_t *d_ok,
+                                 void *stream);
+
+/* ---- per-kernel timing (HIP events on the launch stream) ---------------- */
+#define BLAH2HIP_K_RANGE 0
+#define BLAH2HIP_K_DOPPLER 1
+#define BLAH2HIP_K_METRICS 2
+#define BLAH2HIP_K_CFAR 3
+#define BLAH2HIP_K_COUNT 8
+/* enable != 0: every dev call brackets each kernel with hipEvents */
+int blah2hip_amb_set_timing(blah2hip_amb_t h, int enable);
+/* synchronises the recorded events; ms_total[k] = summed duration of kernel k
+ * over launches[k] launches since the last reset; then resets */
+int blah2hip_amb_get_timing(blah2hip_amb_t h, double *ms_total, uint32_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLAH2HIP_H */

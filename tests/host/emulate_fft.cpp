@@ -1,0 +1,174 @@
+// Host emulation of the workgroup FFT and of the segmented range correlation.
+// Compiles blah2_amd/csrc/fft_wg.hpp + range_core.hpp for the CPU and runs the
+// threads of one workgroup one after another between barriers, so the index
+// algebra, twiddle placement, LDS layouts and segment masks can be checked
+// without a GPU.  Used by tests/test_host_emulation.py (not gpu).
+//
+//   emulate_fft fft                       -> prints max rel errors of fwd/inv for R3=4,8,16
+//   emulate_fft range R3 nCorr nD dMin dMax nSeg segLen seed
+//                                          -> prints max rel error vs the direct definition
+#include "../../blah2_amd/csrc/range_core.hpp"
+
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+using namespace blah2;
+using cd = std::complex<double>;
+
+template <int R3> std::vector<cf> make_table()
+{
+  constexpr int F = 256 * R3;
+  std::vector<cf> tw(F);
+  for (int k = 0; k < F; k++) {
+    double a = -2.0 * M_PI * k / F;
+    tw[k] = cmake((float)std::cos(a), (float)std::sin(a));
+  }
+  return tw;
+}
+
+template <int R3> struct Wg {
+  using W = WgFft<R3>;
+  static constexpr int T = W::T;
+  std::vector<cf> A, B, tw;
+  std::vector<cf> tw1, tw3; // per thread
+  Wg() : A(W::A_ELEMS), B(W::B_ELEMS), tw(make_table<R3>()), tw1(T * 15), tw3(T * 16)
+  {
+    for (int t = 0; t < T; t++) W::load_twiddles(t, tw.data(), &tw1[t * 15], &tw3[t * 16]);
+  }
+  // v: T x 16 registers
+  void forward(std::vector<cf> &v)
+  {
+    for (int t = 0; t < T; t++) W::fwd_s1(t, &v[t * 16], &tw1[t * 15], A.data());
+    for (int t = 0; t < T; t++) W::fwd_s2(t, &v[t * 16], A.data(), B.data());
+    for (int t = 0; t < T; t++) W::fwd_s3(t, &v[t * 16], &tw3[t * 16], B.data());
+  }
+  void inverse(std::vector<cf> &v)
+  {
+    for (int t = 0; t < T; t++) W::inv_s1(t, &v[t * 16], &tw3[t * 16], B.data());
+    for (int t = 0; t < T; t++) W::inv_s2(t, &v[t * 16], B.data(), A.data());
+    for (int t = 0; t < T; t++) W::inv_s3(t, &v[t * 16], &tw1[t * 15], A.data());
+  }
+};
+
+template <int R3> int test_fft()
+{
+  using W = WgFft<R3>;
+  constexpr int T = W::T, F = W::F;
+  std::mt19937 gen(1234 + R3);
+  std::uniform_real_distribution<float> dist(-1.f, 1.f);
+  std::vector<cf> in(F);
+  for (auto &c : in) c = cmake(dist(gen), dist(gen));
+  std::vector<cf> v(T * 16);
+  for (int t = 0; t < T; t++)
+    for (int k = 0; k < 16; k++) v[t * 16 + k] = in[t + T * k];
+  Wg<R3> wg;
+  wg.forward(v);
+  // direct DFT in double
+  std::vector<cd> X(F);
+  for (int m = 0; m < F; m++) {
+    cd acc = 0;
+    for (int n = 0; n < F; n++) {
+      double a = -2.0 * M_PI * (double)(((long)m * n) % F) / F;
+      acc += cd(in[n].x, in[n].y) * cd(std::cos(a), std::sin(a));
+    }
+    X[m] = acc;
+  }
+  double peak = 0, err = 0;
+  for (auto &c : X) peak = std::max(peak, std::abs(c));
+  for (int t = 0; t < T; t++)
+    for (int j = 0; j < W::NP; j++)
+      for (int s = 0; s < R3; s++) {
+        const int p = t + T * j, q = p / 16, r = p % 16;
+        const int m = q + 16 * r + 256 * s;
+        const cf g = v[t * 16 + j * R3 + s];
+        err = std::max(err, std::abs(cd(g.x, g.y) - X[m]));
+      }
+  wg.inverse(v);
+  double ierr = 0;
+  for (int t = 0; t < T; t++)
+    for (int c = 0; c < 16; c++) {
+      const cf g = v[t * 16 + c];
+      const cf e = in[t + T * c];
+      ierr = std::max(ierr, (double)std::abs(cd(g.x / F - e.x, g.y / F - e.y)));
+    }
+  std::printf("R3=%d F=%d fwd_rel_err=%.3e inv_abs_err=%.3e\n", R3, F, err / peak, ierr);
+  return (err / peak < 2e-6 && ierr < 2e-6) ? 0 : 1;
+}
+
+template <int R3>
+int test_range(int nCorr, int nD, int dMin, int dMax, int nSeg, int segLen, unsigned seed)
+{
+  using W = WgFft<R3>;
+  constexpr int T = W::T, F = W::F;
+  RangePlan p;
+  p.nCorr = nCorr; p.nDoppler = nD; p.nDelay = dMax - dMin + 1; p.delayMin = dMin;
+  p.nSeg = nSeg; p.segLen = segLen; p.scale = 1.0f / F;
+  if (segLen + p.nDelay - 1 > F || nSeg * segLen < nCorr) { std::printf("bad plan\n"); return 2; }
+  const long n = (long)nCorr * nD;
+  std::mt19937 gen(seed);
+  std::normal_distribution<float> dist(0.f, 300.f);
+  std::vector<cf> x(n), y(n);
+  for (long i = 0; i < n; i++) { x[i] = cmake(std::round(dist(gen)), std::round(dist(gen))); }
+  for (long i = 0; i < n; i++) {
+    y[i] = cmake(std::round(0.5f * x[i].x + dist(gen) * 0.1f), std::round(0.5f * x[i].y + dist(gen) * 0.1f));
+  }
+  InC32 in{x.data(), y.data()};
+  std::vector<cf> out((size_t)nD * p.nDelay);
+  Wg<R3> wg;
+  std::vector<cf> v(T * 16), xs(T * 16), acc(T * 16);
+  for (int pulse = 0; pulse < nD; pulse++) {
+    const int64_t base = (int64_t)pulse * nCorr;
+    std::fill(acc.begin(), acc.end(), cmake(0, 0));
+    for (int s = 0; s < nSeg; s++) {
+      for (int t = 0; t < T; t++) load_seg_x<R3>(in, p, base, s, t, &v[t * 16]);
+      wg.forward(v);
+      xs = v;
+      for (int t = 0; t < T; t++) load_seg_y<R3>(in, p, base, s, t, &v[t * 16]);
+      wg.forward(v);
+      for (int i = 0; i < T * 16; i++) acc[i] = cmacc(acc[i], v[i], xs[i]);
+    }
+    v = acc;
+    wg.inverse(v);
+    for (int t = 0; t < T; t++) store_lags<R3>(out.data(), p, pulse, t, &v[t * 16]);
+  }
+  // direct definition in double
+  double peak = 0, err = 0;
+  for (int pulse = 0; pulse < nD; pulse++)
+    for (int j = 0; j < p.nDelay; j++) {
+      const int d = dMin + j;
+      cd accd = 0;
+      for (int k = 0; k < nCorr; k++) {
+        const int ky = k + d;
+        if (ky < 0 || ky >= nCorr) continue;
+        const cf a = y[(long)pulse * nCorr + ky], b = x[(long)pulse * nCorr + k];
+        accd += cd(a.x, a.y) * std::conj(cd(b.x, b.y));
+      }
+      const cf g = out[(size_t)pulse * p.nDelay + j];
+      peak = std::max(peak, std::abs(accd));
+      err = std::max(err, std::abs(cd(g.x, g.y) - accd));
+    }
+  std::printf("range R3=%d nCorr=%d nD=%d lags=[%d,%d] nSeg=%d segLen=%d rel_err=%.3e\n", R3, nCorr,
+              nD, dMin, dMax, nSeg, segLen, err / peak);
+  return err / peak < 1e-5 ? 0 : 1;
+}
+
+int main(int argc, char **argv)
+{
+  if (argc >= 2 && !std::strcmp(argv[1], "fft"))
+    return test_fft<4>() | test_fft<8>() | test_fft<16>();
+  if (argc >= 10 && !std::strcmp(argv[1], "range")) {
+    const int R3 = std::atoi(argv[2]);
+    const int a[7] = {std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]),
+                      std::atoi(argv[7]), std::atoi(argv[8]), std::atoi(argv[9])};
+    if (R3 == 4) return test_range<4>(a[0], a[1], a[2], a[3], a[4], a[5], a[6]);
+    if (R3 == 8) return test_range<8>(a[0], a[1], a[2], a[3], a[4], a[5], a[6]);
+    if (R3 == 16) return test_range<16>(a[0], a[1], a[2], a[3], a[4], a[5], a[6]);
+  }
+  std::fprintf(stderr, "usage: emulate_fft fft | range R3 nCorr nD dMin dMax nSeg segLen seed\n");
+  return 2;
+}

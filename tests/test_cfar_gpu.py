@@ -1,0 +1,90 @@
+"""GPU parity tests for CfarDetector1D through the C ABI.
+
+The detector compares |z|^2 against alpha*mean; the GPU map is fp32, so a cell
+whose margin |sq/threshold - 1| is below fp32 resolution may legitimately flip.
+Parity rule: every reference detection with margin > 1e-3 must be reported,
+every reported detection must be a reference detection or borderline; delay and
+Doppler of common detections are identical, snr within 1e-3 dB.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+from oracle import blah2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def b2(built_lib):
+    import blah2_amd
+    assert blah2_amd.device_count() > 0
+    return blah2_amd
+
+
+def margins(m, pfa, ng, nt):
+    """|z|^2 / threshold per cell (fp64), restating CfarDetector1D.cpp:55-83."""
+    sq = np.abs(m * m)
+    nD, nC = sq.shape
+    out = np.full(sq.shape, np.nan)
+    for j in range(nC):
+        idx = [k for k in range(j - ng - nt, j - ng) if 0 < k < nC]
+        idx += [k for k in range(j + ng + 1, j + ng + nt + 1) if 0 <= k < nC]
+        if not idx:
+            continue
+        alpha = len(idx) * (pfa ** (-1.0 / len(idx)) - 1)
+        out[:, j] = sq[:, j] / (alpha * sq[:, idx].mean(axis=1))
+    return out
+
+
+def check_detections(amb, det, m_ref, noise, pfa, ng, nt, md, mdop):
+    dl, dp, sn = O.cfar1d_fast(m_ref, amb.delay, amb.doppler, noise, pfa, ng, nt, md, mdop)
+    ref = {(a, b): s for a, b, s in zip(dl, dp, sn)}
+    got = {(a, b): s for a, b, s in zip(det.get_delay(), det.get_doppler(), det.get_snr())}
+    mg = margins(np.asarray(m_ref, dtype=np.complex128), pfa, ng, nt)
+    row = {f: i for i, f in enumerate(amb.doppler)}
+    for key in set(ref) ^ set(got):
+        i, j = row[key[1]], int(key[0] - amb.delay[0])
+        assert abs(mg[i, j] - 1) < 1e-3, f"non-borderline mismatch at {key}: margin {mg[i, j]}"
+    for key in set(ref) & set(got):
+        assert abs(ref[key] - got[key]) < 1e-3
+    # emission order is row-major like the reference's loops
+    order = [(row[f], d) for d, f in zip(det.get_delay(), det.get_doppler())]
+    assert order == sorted(order)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_cfar_golden(b2, name):
+    g = load_golden(name)
+    fs, n, dmin, dmax, fmin, fmax, rh = (int(v) for v in g["params"])
+    pfa, ng, nt, md, mdop = g["det_params"][:5]
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, bool(rh))
+    m = amb.process(g["x"], g["y"])
+    m.set_metrics()
+    det = b2.CfarDetector1D(pfa, int(ng), int(nt), int(md), mdop).process(m)
+    check_detections(amb, det, g["map"], g["metrics"][0], pfa, int(ng), int(nt), int(md), mdop)
+    # the fixture's targets are far from the threshold: exact agreement expected
+    assert np.array_equal(det.get_delay(), g["cfar"][0])
+    assert np.array_equal(det.get_doppler(), g["cfar"][1])
+    assert np.allclose(det.get_snr(), g["cfar"][2], rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize("params", [
+    (1e-5, 2, 6, 5, 15.0),    # config/config.yml:36-40 defaults
+    (1e-2, 0, 1, -10, 0.0),   # dense detections, windows clipped at both map edges
+    (1e-3, 3, 20, 0, 0.0),    # windows wider than the distance to the edge (k > 0 quirk)
+])
+def test_cfar_dense_vs_oracle(b2, params):
+    pfa, ng, nt, md, mdop = params
+    g = load_golden("medium")
+    fs, n, dmin, dmax, fmin, fmax, rh = (int(v) for v in g["params"])
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, bool(rh))
+    m = amb.process(g["x"], g["y"])
+    det = b2.CfarDetector1D(pfa, ng, nt, md, mdop).process(m)
+    assert det.get_nDetections() > 0
+    check_detections(amb, det, g["map"], g["metrics"][0], pfa, ng, nt, md, mdop)
+
+
+def test_cfar_parameters_are_int8_like_the_reference(b2):
+    with pytest.raises(ValueError):
+        b2.CfarDetector1D(1e-5, 200, 6, 5, 15.0)
