@@ -75,6 +75,16 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m blah2_amd.build` "
             "(there is no CPU fallback for the HIP path)")
+    # The PyTorch-ROCm wheel bundles its own libamdhip64/libhsa-runtime64.  Two HIP
+    # runtimes in one process cannot both own the device, so when torch is installed
+    # it is imported FIRST: libblah2hip.so's libamdhip64.so.7 dependency then binds
+    # to the runtime torch already loaded (torch is only used by the Python harness
+    # for device buffers/streams; C++ callers link /opt/rocm's runtime directly).
+    if os.environ.get("BLAH2HIP_NO_TORCH_PRELOAD", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError when the library does not export a declared symbol

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -76,7 +77,14 @@ struct blah2hip_amb_s {
   blah2hip_hit_t *d_hits = nullptr;
   uint32_t *d_count = nullptr;
   uint32_t hitCap = 0;
-  int dopTilesX = 0, dopTilesY = 0;
+  int dopTilesX = 0, dopTilesY = 0; // direct-DFT fallback grid
+  int dopR3 = 0;                    // 0 = direct fallback, else Bluestein on WgFft<dopR3>
+  int dopGridX = 0;
+  int nParts = 0;                   // metrics partials per CPI
+  int nTiles = 0;                   // 16-column tiles of the range map
+  cf *d_dtw = nullptr;              // exp(-2 pi i k/M)
+  cf *d_chirp = nullptr;            // exp(-i pi n^2/nD)
+  cf *d_bf = nullptr;               // chirp-kernel spectrum / M in register layout
 
   bool timing = false;
   std::vector<EventPair> ev[BLAH2HIP_K_COUNT];
@@ -157,6 +165,75 @@ bool choose_plan(blah2hip_amb_s *h)
   h->dims.n_seg = h->plan.nSeg;
   h->dims.seg_len = h->plan.segLen;
   return true;
+}
+
+
+// fp64 radix-2 FFT on the host, used once per handle for the chirp-kernel spectrum
+void host_fft(std::vector<std::complex<double>> &a)
+{
+  const size_t n = a.size();
+  for (size_t i = 1, j = 0; i < n; i++) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) std::swap(a[i], a[j]);
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    for (size_t i = 0; i < n; i += len)
+      for (size_t k = 0; k < len / 2; k++) {
+        const double ang = -2.0 * M_PI * (double)k / (double)len;
+        const std::complex<double> w(std::cos(ang), std::sin(ang));
+        const std::complex<double> u = a[i + k], v = a[i + k + len / 2] * w;
+        a[i + k] = u + v;
+        a[i + k + len / 2] = u - v;
+      }
+  }
+}
+
+// Bluestein tables for the Doppler DFT of length nD on an M = 256*r3 point FFT
+void doppler_tables(int nD, int r3, std::vector<cf> &tw, std::vector<cf> &chirp, std::vector<cf> &bf)
+{
+  const int M = 256 * r3, T = 16 * r3;
+  tw.resize(M);
+  for (int k = 0; k < M; k++) tw[k] = root_of_unity(k, M);
+  std::vector<std::complex<double>> c(nD);
+  chirp.resize(nD);
+  for (int64_t n = 0; n < nD; n++) {
+    const int64_t q = (n * n) % (2 * (int64_t)nD); // exp(-i pi n^2/nD) = exp(-2 pi i q/(2 nD))
+    const double ang = -M_PI * (double)q / (double)nD;
+    c[n] = {std::cos(ang), std::sin(ang)};
+    chirp[n] = cmake((float)c[n].real(), (float)c[n].imag());
+  }
+  std::vector<std::complex<double>> b(M, {0.0, 0.0});
+  b[0] = std::conj(c[0]);
+  for (int m = 1; m < nD; m++) b[m] = b[M - m] = std::conj(c[m]);
+  host_fft(b);
+  bf.resize(M);
+  for (int t = 0; t < T; t++)
+    for (int j = 0; j < 16 / r3; j++)
+      for (int sidx = 0; sidx < r3; sidx++) {
+        const int p = t + T * j, q = p / 16, r = p % 16;
+        const int m = q + 16 * r + 256 * sidx;
+        const int e = j * r3 + sidx;
+        const std::complex<double> v = b[m] / (double)M;
+        bf[(size_t)e * T + t] = cmake((float)v.real(), (float)v.imag());
+      }
+}
+
+template <int R3> int launch_doppler_t(blah2hip_amb_s *h, const DopplerArgs &a, uint32_t n_cpi, hipStream_t st)
+{
+  using W = WgFft<R3>;
+  constexpr int NC = 256 / W::T;
+  const size_t lds = (size_t)NC * (W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
+  auto kern = doppler_fft_kernel<R3>;
+  static thread_local const void *configured = nullptr;
+  if (configured != (const void *)kern) {
+    HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = (const void *)kern;
+  }
+  hipLaunchKernelGGL(kern, dim3(h->dopGridX, n_cpi), dim3(256), lds, st, a);
+  HIPCHK(hipGetLastError());
+  return BLAH2HIP_OK;
 }
 
 template <int R3, class In> int launch_range_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
@@ -312,23 +389,47 @@ int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_mi
   std::vector<cf> dw(nD);
   for (uint32_t k = 0; k < nD; k++) dw[k] = root_of_unity(k, nD);
   const size_t cells = (size_t)nD * nDelay;
+  h->nTiles = (int)((nDelay + 15) / 16);
+  const size_t rcells = (size_t)h->nTiles * nD * 16; // tiled range map, padded to 16 columns
+  // Doppler plan: Bluestein on the smallest on-chip transform with M >= 2*nD-2
+  h->dopR3 = 0;
+  for (int r3 : {4, 8, 16})
+    if (256 * r3 >= 2 * (int)nD - 2) { h->dopR3 = r3; break; }
+  if (const char *e = std::getenv("BLAH2HIP_DOPPLER_DIRECT")) if (std::atoi(e)) h->dopR3 = 0;
   h->dopTilesX = (nDelay + 63) / 64;
   h->dopTilesY = (nD + DOP_KPT - 1) / DOP_KPT;
-  const size_t nTiles = (size_t)h->dopTilesX * h->dopTilesY;
+  if (h->dopR3) {
+    const int gpt = 16 / (256 / (16 * h->dopR3)); // column groups per 16-column tile
+    h->dopGridX = 8 * ((h->nTiles + 7) / 8) * gpt;
+    h->nParts = h->dopGridX;
+  } else {
+    h->nParts = h->dopTilesX * h->dopTilesY;
+  }
 
   HIPCHK(hipMalloc(&h->d_tw, F * sizeof(cf)));
   HIPCHK(hipMalloc(&h->d_dopW, nD * sizeof(cf)));
-  HIPCHK(hipMalloc(&h->d_R, cells * max_batch * sizeof(cf)));
+  HIPCHK(hipMalloc(&h->d_R, rcells * max_batch * sizeof(cf)));
   HIPCHK(hipMalloc(&h->d_map, cells * max_batch * sizeof(cf)));
-  HIPCHK(hipMalloc(&h->d_partSum, nTiles * max_batch * sizeof(double)));
-  HIPCHK(hipMalloc(&h->d_partMax, nTiles * max_batch * sizeof(float)));
+  HIPCHK(hipMalloc(&h->d_partSum, (size_t)h->nParts * max_batch * sizeof(double)));
+  HIPCHK(hipMalloc(&h->d_partMax, (size_t)h->nParts * max_batch * sizeof(float)));
   HIPCHK(hipMalloc(&h->d_metrics, 2 * max_batch * sizeof(double)));
   HIPCHK(hipMalloc(&h->d_doppler, nD * sizeof(double)));
   HIPCHK(hipMalloc(&h->d_alpha, 256 * sizeof(double)));
   HIPCHK(hipMalloc(&h->d_count, max_batch * sizeof(uint32_t)));
+  HIPCHK(hipMemset(h->d_R, 0, rcells * max_batch * sizeof(cf))); // padding columns stay finite
   HIPCHK(hipMemcpy(h->d_tw, tw.data(), F * sizeof(cf), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->d_dopW, dw.data(), nD * sizeof(cf), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->d_doppler, h->dopplerAxis.data(), nD * sizeof(double), hipMemcpyHostToDevice));
+  if (h->dopR3) {
+    std::vector<cf> dtw, chirp, bf;
+    doppler_tables((int)nD, h->dopR3, dtw, chirp, bf);
+    HIPCHK(hipMalloc(&h->d_dtw, dtw.size() * sizeof(cf)));
+    HIPCHK(hipMalloc(&h->d_chirp, chirp.size() * sizeof(cf)));
+    HIPCHK(hipMalloc(&h->d_bf, bf.size() * sizeof(cf)));
+    HIPCHK(hipMemcpy(h->d_dtw, dtw.data(), dtw.size() * sizeof(cf), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_chirp, chirp.data(), chirp.size() * sizeof(cf), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_bf, bf.data(), bf.size() * sizeof(cf), hipMemcpyHostToDevice));
+  }
   *out = h;
   return BLAH2HIP_OK;
 }
@@ -341,7 +442,8 @@ int blah2hip_amb_destroy(blah2hip_amb_t h)
   for (void *p : {(void *)h->d_tw, (void *)h->d_dopW, (void *)h->d_R, (void *)h->d_map,
                   (void *)h->d_partSum, (void *)h->d_partMax, (void *)h->d_metrics,
                   (void *)h->d_doppler, (void *)h->d_alpha, h->d_in, (void *)h->d_rot,
-                  (void *)h->d_hits, (void *)h->d_count})
+                  (void *)h->d_hits, (void *)h->d_count, (void *)h->d_dtw, (void *)h->d_chirp,
+                  (void *)h->d_bf})
     if (p) hipFree(p);
   for (auto &v : h->ev)
     for (auto &p : v) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -431,18 +533,29 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   da.R = h->d_R;
   da.map = map;
   da.W = h->d_dopW;
+  da.tw = h->d_dtw;
+  da.chirp = h->d_chirp;
+  da.bf = h->d_bf;
   da.partSum = h->d_partSum;
   da.partMax = h->d_partMax;
   da.nD = (int32_t)nD;
   da.nDelay = (int32_t)nDelay;
+  da.nTiles = h->nTiles;
+  da.nGroups = h->dopR3 ? h->nTiles * (16 / (256 / (16 * h->dopR3))) : 0;
   if ((rc = tic(h, BLAH2HIP_K_DOPPLER, st))) return rc;
-  hipLaunchKernelGGL(doppler_dft_kernel, dim3(h->dopTilesX, h->dopTilesY, n_cpi), dim3(64 * DOP_WAVES), 0, st, da);
-  HIPCHK(hipGetLastError());
+  if (h->dopR3 == 4) rc = launch_doppler_t<4>(h, da, n_cpi, st);
+  else if (h->dopR3 == 8) rc = launch_doppler_t<8>(h, da, n_cpi, st);
+  else if (h->dopR3 == 16) rc = launch_doppler_t<16>(h, da, n_cpi, st);
+  else {
+    hipLaunchKernelGGL(doppler_dft_kernel, dim3(h->dopTilesX, h->dopTilesY, n_cpi), dim3(64 * DOP_WAVES), 0, st, da);
+    HIPCHK(hipGetLastError());
+  }
+  if (rc) return rc;
   if ((rc = toc(h, BLAH2HIP_K_DOPPLER, st))) return rc;
 
   if ((rc = tic(h, BLAH2HIP_K_METRICS, st))) return rc;
   hipLaunchKernelGGL(metrics_kernel, dim3(n_cpi), dim3(256), 0, st, h->d_partSum, h->d_partMax,
-                     h->dopTilesX * h->dopTilesY, (double)nD * (double)nDelay, met);
+                     h->nParts, (double)nD * (double)nDelay, met);
   HIPCHK(hipGetLastError());
   if ((rc = toc(h, BLAH2HIP_K_METRICS, st))) return rc;
   return BLAH2HIP_OK;

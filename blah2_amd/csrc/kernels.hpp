@@ -30,7 +30,7 @@ namespace blah2 {
 struct RangeArgs {
   RangePlan plan;
   const cf *tw;        // exp(-2 pi i k / F), k in [0, F)
-  cf *out;             // [nCpi*nDoppler][nDelay]
+  cf *out;             // tiled range map, see rmap_index()
   int64_t cpiStride;   // samples between consecutive CPIs of the batch
   int32_t nPulses;     // nCpi * nDoppler
 };
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
     W::inv_s2(t, acc, B, A);
     __syncthreads();
     W::inv_s3(t, acc, tw1, A);
-    store_lags<R3>(a.out, p, pulse, t, acc);
+    store_lags<R3>(a.out, p, cpi, i, t, acc);
     __syncthreads(); // A is rewritten by the next pulse's fwd_s1
   }
 }
@@ -114,41 +114,152 @@ __global__ void rotate_kernel(In in, cf *xo, cf *yo, int64_t cpiStride, int64_t 
 }
 
 // --------------------------------------------------------------------------
-// Doppler kernel v0: direct DFT down the pulse axis (works for any nDoppler,
-// which is always odd in the reference, Ambiguity.cpp:26-36).
-//   D[k][j] = sum_i R[i][j] * exp(-2 pi i * i*k / nD)
-//   M[o][j] = D[(o + nD/2 + 1) % nD][j]                          (Ambiguity.cpp:165)
-// lane <-> delay column j (coalesced), each thread accumulates KPT output rows,
-// the 4 waves of a workgroup split the pulse axis and reduce through LDS.
-// The roots come from an exact table W[k] = exp(-2 pi i k/nD) (fp64 -> fp32),
-// indexed by (i*k mod nD), which is wave-uniform -> scalar loads.
-// Epilogue: writes the map tile and one (sum of 10 log10|z|, max) partial per
-// workgroup for Map::set_metrics.
+// Doppler kernel (Hot loop B, Ambiguity.cpp:152-169): for every delay column
+//   D[k] = sum_i R[i] * exp(-2 pi i * i*k / nD)        forward DFT over the pulses
+//   M[o] = D[(o + nD/2 + 1) % nD]                      (Ambiguity.cpp:165)
+// nD is always odd and rarely smooth (127, 301, 513 = 27*19, 1025, 2049 = 3*683),
+// so the DFT is evaluated as a chirp-z (Bluestein) convolution on the power-of-
+// two workgroup FFT:   D[k] = c[k] * sum_n (R[n] c[n]) * conj(c[k-n]),
+// c[n] = exp(-i pi n^2 / nD).  M = 16*T >= 2*nD - 2 suffices because c is even:
+// the only lags that alias, +(nD-1) and -(nD-1), carry the same kernel value.
+// The spectrum of the kernel (times 1/M) is precomputed in fp64 on the host, in
+// the register layout the forward transform leaves its output in.
+//
+// Accuracy: the zero-delay columns hold the direct-path peak in every pulse, a
+// DC term ~1e2..1e4 times larger than what the other Doppler bins of that
+// column contain.  DFT(R - r0)[k] = DFT(R)[k] for k != 0 for ANY constant r0,
+// so the first pulse's value is subtracted before the transform (an exact
+// fp32 subtraction by Sterbenz for the dominant part) and nD*r0 is added back
+// to bin 0.  This removes the fp32 cancellation error of the DC term.
+//
+// One column per T threads, 256/T columns per workgroup; columns come out of
+// the tiled range map with 128-byte-stride gathers (the 16 columns of a tile
+// are handled by workgroups that the block->tile map keeps on one XCD, so the
+// lines are fetched from HBM once and the partial row writes of the final map
+// merge in that XCD's L2).  Epilogue: Map::set_metrics partials.
+struct DopplerArgs {
+  const cf *R;      // tiled range map
+  cf *map;          // [nCpi][nD][nDelay]
+  const cf *W;      // direct kernel: exp(-2 pi i k/nD), [nD]
+  const cf *tw;     // fft kernel: exp(-2 pi i k/M), [M]
+  const cf *chirp;  // fft kernel: exp(-i pi n^2/nD), [nD]
+  const cf *bf;     // fft kernel: kernel spectrum / M, [16][T]
+  double *partSum;  // [nCpi][partsPerCpi]
+  float *partMax;   // [nCpi][partsPerCpi]
+  int32_t nD, nDelay, nTiles, nGroups;
+};
+
+// 10*log10|z| = 5*log10(re^2+im^2) = 5*log10(2) * log2(re^2+im^2)
+__device__ __forceinline__ float db_of(cf z) { return 1.50514997831990597607f * log2f(z.x * z.x + z.y * z.y); }
+
+// sum / max over the 256 threads of a workgroup -> one partial per workgroup
+__device__ __forceinline__ void block_metrics_partial(double lsum, float lmax, double *dst_sum, float *dst_max)
+{
+  __shared__ double wsum[4];
+  __shared__ float wmax[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lsum += __shfl_xor(lsum, off);
+    lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { wsum[wave] = lsum; wmax[wave] = lmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    float m = 0.f; // Map.cpp:193: the running max starts at 0
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) { s += wsum[w]; m = fmaxf(m, wmax[w]); }
+    *dst_sum = s;
+    *dst_max = m;
+  }
+}
+
+template <int R3>
+__global__ __launch_bounds__(256) void doppler_fft_kernel(DopplerArgs a)
+{
+  using W = WgFft<R3>;
+  constexpr int T = W::T;
+  constexpr int NC = 256 / T; // columns per workgroup
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int sub = threadIdx.x / T;
+  const int t = threadIdx.x % T;
+  cf *A = reinterpret_cast<cf *>(smem) + sub * (W::A_ELEMS + W::B_ELEMS);
+  cf *B = A + W::A_ELEMS;
+  const int nD = a.nD;
+  const int cpi = blockIdx.y;
+  // block -> column group: the 16/NC groups of one 16-column tile get block ids
+  // that are congruent mod 8 (same XCD) and adjacent in dispatch order
+  constexpr int GPT = 16 / NC; // groups per tile
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tileIdx = (slot / GPT) * 8 + xcd;
+  const int group = tileIdx * GPT + (slot % GPT);
+  const int col = group * NC + sub;
+  const bool colok = group < a.nGroups && col < a.nDelay;
+
+  cf tw1[15], tw3[16];
+  W::load_twiddles(t, a.tw, tw1, tw3);
+
+  const cf *Rc = a.R + rmap_index(nD, a.nTiles, cpi, 0, colok ? col : 0);
+  const cf r0 = Rc[0];
+  cf v[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int i = t + T * k;
+    v[k] = (i < nD) ? cmul(csub(Rc[(size_t)i * 16], r0), a.chirp[i]) : cmake(0.f, 0.f);
+  }
+  W::fwd_s1(t, v, tw1, A);
+  __syncthreads();
+  W::fwd_s2(t, v, A, B);
+  __syncthreads();
+  W::fwd_s3(t, v, tw3, B);
+#pragma unroll
+  for (int e = 0; e < 16; e++) v[e] = cmul(v[e], a.bf[e * T + t]);
+  __syncthreads();
+  W::inv_s1(t, v, tw3, B);
+  __syncthreads();
+  W::inv_s2(t, v, B, A);
+  __syncthreads();
+  W::inv_s3(t, v, tw1, A);
+
+  double lsum = 0.0;
+  float lmax = 0.f;
+  cf *mapc = a.map + (size_t)cpi * nD * a.nDelay + col;
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const int k = t + T * c;
+    if (colok && k < nD) {
+      cf d = cmul(v[c], a.chirp[k]);
+      if (k == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
+      int o = k - (nD / 2 + 1);
+      if (o < 0) o += nD;
+      mapc[(size_t)o * a.nDelay] = d;
+      const float db = db_of(d);
+      lsum += (double)db;
+      lmax = fmaxf(lmax, db);
+    }
+  }
+  const size_t part = (size_t)cpi * gridDim.x + blockIdx.x;
+  block_metrics_partial(lsum, lmax, a.partSum + part, a.partMax + part);
+}
+
+// Fallback for nD > 2049 (transform longer than the on-chip FFT covers):
+// direct DFT, lane <-> delay column, KPT output rows per thread, the 4 waves
+// split the pulse axis and reduce through LDS.  Same DC handling as above.
 constexpr int DOP_KPT = 8;
 constexpr int DOP_WAVES = 4;
-
-struct DopplerArgs {
-  const cf *R;      // [nCpi][nD][nDelay]
-  cf *map;          // [nCpi][nD][nDelay]
-  const cf *W;      // [nD]
-  double *partSum;  // [nCpi][nTilesPerCpi]
-  float *partMax;   // [nCpi][nTilesPerCpi]
-  int32_t nD, nDelay;
-};
 
 __global__ __launch_bounds__(64 * DOP_WAVES) void doppler_dft_kernel(DopplerArgs a)
 {
   __shared__ cf red[DOP_WAVES][DOP_KPT][64];
-  __shared__ double wsum[DOP_WAVES];
-  __shared__ float wmax[DOP_WAVES];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nD = a.nD, nDelay = a.nDelay;
   const int j = blockIdx.x * 64 + lane;
   const int o0 = blockIdx.y * DOP_KPT;
   const int cpi = blockIdx.z;
-  const cf *R = a.R + (size_t)cpi * nD * nDelay;
   const bool jok = j < nDelay;
+  const cf *Rc = a.R + rmap_index(nD, a.nTiles, cpi, 0, jok ? j : 0);
+  const cf r0 = Rc[0];
   const int chunk = (nD + DOP_WAVES - 1) / DOP_WAVES;
   const int i0 = wave * chunk;
   const int i1 = min(nD, i0 + chunk);
@@ -164,7 +275,7 @@ __global__ __launch_bounds__(64 * DOP_WAVES) void doppler_dft_kernel(DopplerArgs
     acc[kk] = cmake(0.f, 0.f);
   }
   for (int i = i0; i < i1; i++) {
-    const cf r = jok ? R[(size_t)i * nDelay + j] : cmake(0.f, 0.f);
+    const cf r = csub(Rc[(size_t)i * 16], r0);
 #pragma unroll
     for (int kk = 0; kk < DOP_KPT; kk++) {
       const cf w = a.W[idx[kk]];
@@ -177,9 +288,8 @@ __global__ __launch_bounds__(64 * DOP_WAVES) void doppler_dft_kernel(DopplerArgs
 #pragma unroll
   for (int kk = 0; kk < DOP_KPT; kk++) red[wave][kk][lane] = acc[kk];
   __syncthreads();
-  // wave w finalises output rows kk = 2w, 2w+1
   double lsum = 0.0;
-  float lmax = 0.f; // Map.cpp:193: the running max starts at 0
+  float lmax = 0.f;
 #pragma unroll
   for (int h = 0; h < DOP_KPT / DOP_WAVES; h++) {
     const int kk = wave * (DOP_KPT / DOP_WAVES) + h;
@@ -188,29 +298,15 @@ __global__ __launch_bounds__(64 * DOP_WAVES) void doppler_dft_kernel(DopplerArgs
     for (int w = 1; w < DOP_WAVES; w++) s = cadd(s, red[w][kk][lane]);
     const int o = o0 + kk;
     if (jok && o < nD) {
+      if ((o + nD / 2 + 1) % nD == 0) s = cmake(s.x + (float)nD * r0.x, s.y + (float)nD * r0.y);
       a.map[(size_t)cpi * nD * nDelay + (size_t)o * nDelay + j] = s;
-      // 10*log10|z| = 5*log10(re^2+im^2)
-      const float v = 1.50514997831990597607f * log2f(s.x * s.x + s.y * s.y);
-      lsum += (double)v;
-      lmax = fmaxf(lmax, v);
+      const float db = db_of(s);
+      lsum += (double)db;
+      lmax = fmaxf(lmax, db);
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    lsum += __shfl_xor(lsum, off);
-    lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-  }
-  if (lane == 0) { wsum[wave] = lsum; wmax[wave] = lmax; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    float m = 0.f;
-    for (int w = 0; w < DOP_WAVES; w++) { s += wsum[w]; m = fmaxf(m, wmax[w]); }
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-    const int nTiles = gridDim.x * gridDim.y;
-    a.partSum[(size_t)cpi * nTiles + tile] = s;
-    a.partMax[(size_t)cpi * nTiles + tile] = m;
-  }
+  const size_t part = (size_t)cpi * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x;
+  block_metrics_partial(lsum, lmax, a.partSum + part, a.partMax + part);
 }
 
 // Map::set_metrics (Map.cpp:187-206): noisePower = mean(10 log10|z|),

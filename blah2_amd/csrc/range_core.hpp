@@ -77,14 +77,25 @@ B2_HD void load_seg_y(const In &in, const RangePlan &p, int64_t pulseBase, int s
   }
 }
 
+// Range map layout in HBM ("tiled"): [cpi][colTile][pulse][16] complex fp32,
+// colTile = lag/16.  The range kernel writes 128-byte runs (16 lags of one
+// pulse), and the Doppler kernel, which needs whole columns, finds the 16
+// columns of a tile for all pulses in one contiguous nDoppler*128-byte block.
+B2_HD int64_t rmap_index(int nDoppler, int nTiles, int cpi, int pulse, int lag)
+{
+  return (((int64_t)cpi * nTiles + (lag >> 4)) * nDoppler + pulse) * 16 + (lag & 15);
+}
+
 template <int R3>
-B2_HD void store_lags(cf *out, const RangePlan &p, int64_t pulse, int t, const cf *v)
+B2_HD void store_lags(cf *out, const RangePlan &p, int cpi, int pulse, int t, const cf *v)
 {
   constexpr int T = 16 * R3;
+  const int nTiles = (p.nDelay + 15) >> 4;
 #pragma unroll
   for (int c = 0; c < 16; c++) {
     const int j = t + T * c;
-    if (j < p.nDelay) out[pulse * p.nDelay + j] = cmake(v[c].x * p.scale, v[c].y * p.scale);
+    if (j < p.nDelay)
+      out[rmap_index(p.nDoppler, nTiles, cpi, pulse, j)] = cmake(v[c].x * p.scale, v[c].y * p.scale);
   }
 }
 

@@ -118,7 +118,8 @@ int test_range(int nCorr, int nD, int dMin, int dMax, int nSeg, int segLen, unsi
     y[i] = cmake(std::round(0.5f * x[i].x + dist(gen) * 0.1f), std::round(0.5f * x[i].y + dist(gen) * 0.1f));
   }
   InC32 in{x.data(), y.data()};
-  std::vector<cf> out((size_t)nD * p.nDelay);
+  const int nTiles = (p.nDelay + 15) / 16;
+  std::vector<cf> out((size_t)nTiles * nD * 16);
   Wg<R3> wg;
   std::vector<cf> v(T * 16), xs(T * 16), acc(T * 16);
   for (int pulse = 0; pulse < nD; pulse++) {
@@ -134,7 +135,7 @@ int test_range(int nCorr, int nD, int dMin, int dMax, int nSeg, int segLen, unsi
     }
     v = acc;
     wg.inverse(v);
-    for (int t = 0; t < T; t++) store_lags<R3>(out.data(), p, pulse, t, &v[t * 16]);
+    for (int t = 0; t < T; t++) store_lags<R3>(out.data(), p, 0, pulse, t, &v[t * 16]);
   }
   // direct definition in double
   double peak = 0, err = 0;
@@ -148,7 +149,7 @@ int test_range(int nCorr, int nD, int dMin, int dMax, int nSeg, int segLen, unsi
         const cf a = y[(long)pulse * nCorr + ky], b = x[(long)pulse * nCorr + k];
         accd += cd(a.x, a.y) * std::conj(cd(b.x, b.y));
       }
-      const cf g = out[(size_t)pulse * p.nDelay + j];
+      const cf g = out[rmap_index(nD, nTiles, 0, pulse, j)];
       peak = std::max(peak, std::abs(accd));
       err = std::max(err, std::abs(cd(g.x, g.y) - accd));
     }

@@ -123,6 +123,17 @@ def test_every_transform_length(b2, fft_len, monkeypatch):
     assert_map_close(m.data, g["map"])
 
 
+def test_direct_doppler_fallback(b2, monkeypatch):
+    # nDoppler > 2049 falls back to a direct DFT kernel; force it on a small case
+    monkeypatch.setenv("BLAH2HIP_DOPPLER_DIRECT", "1")
+    g = load_golden("medium")
+    fs, n, dmin, dmax, fmin, fmax, rh = (int(v) for v in g["params"])
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, bool(rh))
+    m = amb.process(g["x"], g["y"])
+    assert_map_close(m.data, g["map"])
+    assert abs(m.noisePower - g["metrics"][0]) <= DB_TOL
+
+
 def cfg2():
     return dict(delayMin=-10, delayMax=400, dopplerMin=-256, dopplerMax=256, fs=2_000_000, n=2_000_000)
 
