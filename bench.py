@@ -175,6 +175,22 @@ def main():
     achieved = algo_bytes / avg_range_s / 1e9 if avg_range_s > 0 else 0.0
     chain_s = sum(v[0] for v in kt.values()) * 1e-3 / max(range_n, 1)
 
+    # HBM bytes per launch of the range kernel from the committed rocprofv3 PMC
+    # passes of this same command (tools/summarize_prof.py -> profiles/*_traffic.json)
+    traffic, traffic_src = None, None
+    import glob
+    for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(pth))
+            bc = tj.get("bench_config", {})
+            if bc and (bc.get("config"), bc.get("batch"), bc.get("fmt")) != (a.config, B, a.fmt):
+                continue
+            traffic = tj["kernels"]["range_kernel"]["hbm_bytes"]
+            traffic_src = os.path.relpath(pth, ROOT)
+            break
+        except Exception:
+            continue
+
     # sanity: the timed outputs are real (metrics of the last batch are finite, target visible)
     mt = met.cpu().numpy()
     ok = bool((mt == mt).all() and (mt[:, 1] > 0).all())
@@ -196,7 +212,7 @@ def main():
             "us_per_cpi": elapsed / (B * a.steps) * 1e6,
             "outputs_valid": ok,
             "roofline": {"bound": "hbm", "kernel": "range_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "avg_launch_us": avg_range_s * 1e6, "launches_timed": range_n,
                          "kernel_us_per_step": {k: v[0] / max(v[1], 1) * 1e3 for k, v in kt.items() if v[1]},

@@ -240,7 +240,8 @@ template <int R3, class In> int launch_range_t(blah2hip_amb_s *h, const RangeArg
 {
   using W = WgFft<R3>;
   const size_t lds = (size_t)(W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
-  auto kern = range_kernel<R3, In>;
+  static const bool ilv = [] { const char *e = std::getenv("BLAH2HIP_RANGE_ILV"); return e && std::atoi(e) != 0; }();
+  auto kern = ilv ? range_kernel<R3, In, true> : range_kernel<R3, In, false>;
   static thread_local const void *configured = nullptr;
   if (configured != (const void *)kern) {
     HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

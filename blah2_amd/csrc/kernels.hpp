@@ -35,13 +35,13 @@ struct RangeArgs {
   int32_t nPulses;     // nCpi * nDoppler
 };
 
-template <int R3, class In>
+template <int R3, class In, bool ILV>
 __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
 {
   using W = WgFft<R3>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  cf *A = reinterpret_cast<cf *>(smem);
-  cf *B = A + W::A_ELEMS;
+  cf *P = reinterpret_cast<cf *>(smem);
+  cf *Q = P + W::A_ELEMS;
   const int t = threadIdx.x;
 
   cf tw1[15], tw3[16];
@@ -53,39 +53,60 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
     const int i = pulse - cpi * p.nDoppler;
     const int64_t base = (int64_t)cpi * a.cpiStride + (int64_t)i * p.nCorr;
 
-    cf v[16], xs[16], acc[16];
+    cf v[16], yv[16], acc[16];
     for (int s = 0; s < p.nSeg; s++) {
+      // both channels' loads go out first: 32 requests in flight per thread
       load_seg_x<R3>(in, p, base, s, t, v);
-      W::fwd_s1(t, v, tw1, A);
-      __syncthreads();
-      W::fwd_s2(t, v, A, B);
-      __syncthreads();
-      W::fwd_s3(t, v, tw3, B);
-#pragma unroll
-      for (int e = 0; e < 16; e++) xs[e] = v[e];
-
-      load_seg_y<R3>(in, p, base, s, t, v);
-      W::fwd_s1(t, v, tw1, A);
-      __syncthreads();
-      W::fwd_s2(t, v, A, B);
-      __syncthreads();
-      W::fwd_s3(t, v, tw3, B);
+      load_seg_y<R3>(in, p, base, s, t, yv);
+      mask_seg_x<R3>(p, s, t, v);
+      mask_seg_y<R3>(p, s, t, yv);
+      // The x and y transforms advance together, each through its own exchange
+      // buffer (P for x, Q for y, used first in the A layout and then in the B
+      // layout): every barrier interval holds two independent instruction
+      // streams, so LDS latency of one overlaps butterflies of the other.
+      if (ILV) {
+        W::fwd_s1(t, v, tw1, P);
+        W::fwd_s1(t, yv, tw1, Q);
+        __syncthreads();
+        W::fwd_s2_load(t, v, P);
+        W::fwd_s2_load(t, yv, Q);
+        dft16<-1>(v);
+        dft16<-1>(yv);
+        __syncthreads(); // every thread has read its A-layout values
+        W::fwd_s2_store(t, v, P);
+        W::fwd_s2_store(t, yv, Q);
+        __syncthreads();
+        W::fwd_s3(t, v, tw3, P);  // v  = X spectrum
+        W::fwd_s3(t, yv, tw3, Q); // yv = Y spectrum
+      } else {
+        // one transform at a time, P in the A layout and Q in the B layout
+        W::fwd_s1(t, v, tw1, P);
+        __syncthreads();
+        W::fwd_s2(t, v, P, Q);
+        __syncthreads();
+        W::fwd_s3(t, v, tw3, Q);
+        W::fwd_s1(t, yv, tw1, P);
+        __syncthreads();
+        W::fwd_s2(t, yv, P, Q);
+        __syncthreads();
+        W::fwd_s3(t, yv, tw3, Q);
+      }
       if (s == 0) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[e] = cmulc(v[e], xs[e]);
+        for (int e = 0; e < 16; e++) acc[e] = cmulc(yv[e], v[e]);
       } else {
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[e] = cmacc(acc[e], v[e], xs[e]);
+        for (int e = 0; e < 16; e++) acc[e] = cmacc(acc[e], yv[e], v[e]);
       }
+      __syncthreads(); // P/Q are rewritten by the next segment (or the inverse)
     }
-    __syncthreads(); // B is still being read by fwd_s3 of slower waves
-    W::inv_s1(t, acc, tw3, B);
+    W::inv_s1(t, acc, tw3, P);
     __syncthreads();
-    W::inv_s2(t, acc, B, A);
+    W::inv_s2(t, acc, P, Q);
     __syncthreads();
-    W::inv_s3(t, acc, tw1, A);
+    W::inv_s3(t, acc, tw1, Q);
     store_lags<R3>(a.out, p, cpi, i, t, acc);
-    __syncthreads(); // A is rewritten by the next pulse's fwd_s1
+    __syncthreads(); // Q is rewritten by the next pulse
   }
 }
 

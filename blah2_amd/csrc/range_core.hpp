@@ -53,15 +53,32 @@ struct InI16 {
   B2_HD cf ly(int64_t i) const { return cmake((float)iq[4 * i + 2], (float)iq[4 * i + 3]); }
 };
 
+// Loads are branch-free: the index is clamped into the pulse, all 16 loads of a
+// thread issue back to back (so their HBM latencies overlap), and the segment /
+// pulse masks are applied afterwards with selects (mask_seg_*).  Clamped lanes
+// re-read the last sample of the pulse, an L1 hit.
 template <int R3, class In>
 B2_HD void load_seg_x(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, cf *v)
 {
   constexpr int T = 16 * R3;
+  const int s0 = s * p.segLen + t;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int idx = s0 + T * k;
+    v[k] = in.lx(pulseBase + (idx < p.nCorr ? idx : p.nCorr - 1));
+  }
+}
+
+template <int R3>
+B2_HD void mask_seg_x(const RangePlan &p, int s, int t, cf *v)
+{
+  constexpr int T = 16 * R3;
+  const int s0 = s * p.segLen;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     const int m = t + T * k;
-    const int idx = s * p.segLen + m;
-    v[k] = (m < p.segLen && idx < p.nCorr) ? in.lx(pulseBase + idx) : cmake(0.f, 0.f);
+    const bool ok = (m < p.segLen) && (s0 + m < p.nCorr);
+    v[k] = ok ? v[k] : cmake(0.f, 0.f);
   }
 }
 
@@ -69,11 +86,24 @@ template <int R3, class In>
 B2_HD void load_seg_y(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, cf *v)
 {
   constexpr int T = 16 * R3;
+  const int s0 = s * p.segLen + p.delayMin + t;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    const int m = t + T * k;
-    const int idx = s * p.segLen + p.delayMin + m;
-    v[k] = (idx >= 0 && idx < p.nCorr) ? in.ly(pulseBase + idx) : cmake(0.f, 0.f);
+    const int idx = s0 + T * k;
+    const int cl = idx < 0 ? 0 : (idx < p.nCorr ? idx : p.nCorr - 1);
+    v[k] = in.ly(pulseBase + cl);
+  }
+}
+
+template <int R3>
+B2_HD void mask_seg_y(const RangePlan &p, int s, int t, cf *v)
+{
+  constexpr int T = 16 * R3;
+  const int s0 = s * p.segLen + p.delayMin + t;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int idx = s0 + T * k;
+    v[k] = (idx >= 0 && idx < p.nCorr) ? v[k] : cmake(0.f, 0.f);
   }
 }
 

@@ -121,17 +121,36 @@ int test_range(int nCorr, int nD, int dMin, int dMax, int nSeg, int segLen, unsi
   const int nTiles = (p.nDelay + 15) / 16;
   std::vector<cf> out((size_t)nTiles * nD * 16);
   Wg<R3> wg;
-  std::vector<cf> v(T * 16), xs(T * 16), acc(T * 16);
+  std::vector<cf> v(T * 16), yv(T * 16), acc(T * 16);
   for (int pulse = 0; pulse < nD; pulse++) {
     const int64_t base = (int64_t)pulse * nCorr;
     std::fill(acc.begin(), acc.end(), cmake(0, 0));
     for (int s = 0; s < nSeg; s++) {
-      for (int t = 0; t < T; t++) load_seg_x<R3>(in, p, base, s, t, &v[t * 16]);
-      wg.forward(v);
-      xs = v;
-      for (int t = 0; t < T; t++) load_seg_y<R3>(in, p, base, s, t, &v[t * 16]);
-      wg.forward(v);
-      for (int i = 0; i < T * 16; i++) acc[i] = cmacc(acc[i], v[i], xs[i]);
+      // same barrier structure as range_kernel: x through P, y through Q
+      std::vector<cf> &P = wg.A, &Q = wg.B;
+      for (int t = 0; t < T; t++) {
+        load_seg_x<R3>(in, p, base, s, t, &v[t * 16]);
+        load_seg_y<R3>(in, p, base, s, t, &yv[t * 16]);
+        mask_seg_x<R3>(p, s, t, &v[t * 16]);
+        mask_seg_y<R3>(p, s, t, &yv[t * 16]);
+        W::fwd_s1(t, &v[t * 16], &wg.tw1[t * 15], P.data());
+        W::fwd_s1(t, &yv[t * 16], &wg.tw1[t * 15], Q.data());
+      }
+      for (int t = 0; t < T; t++) {
+        W::fwd_s2_load(t, &v[t * 16], P.data());
+        W::fwd_s2_load(t, &yv[t * 16], Q.data());
+        dft16<-1>(&v[t * 16]);
+        dft16<-1>(&yv[t * 16]);
+      }
+      for (int t = 0; t < T; t++) {
+        W::fwd_s2_store(t, &v[t * 16], P.data());
+        W::fwd_s2_store(t, &yv[t * 16], Q.data());
+      }
+      for (int t = 0; t < T; t++) {
+        W::fwd_s3(t, &v[t * 16], &wg.tw3[t * 16], P.data());
+        W::fwd_s3(t, &yv[t * 16], &wg.tw3[t * 16], Q.data());
+        for (int e = 0; e < 16; e++) acc[t * 16 + e] = cmacc(acc[t * 16 + e], yv[t * 16 + e], v[t * 16 + e]);
+      }
     }
     v = acc;
     wg.inverse(v);

@@ -42,7 +42,7 @@ def timing():
     dmin, dmax, fmin, fmax, fs, n = CFG2
     dev = torch.device("cuda", 0)
     for fft_len in (1024, 2048, 4096):
-        for B in (1, 8, 16):
+        for B in [int(b) for b in os.environ.get("DIAG_B", "1,8,16").split(",")]:
             os.environ["BLAH2HIP_FFT_LEN"] = str(fft_len)
             amb = blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, max_batch=B)
             ring = max(2, int(600e6 // (16 * n * B)) + 1)
