@@ -725,6 +725,8 @@ int blah2hip_amb_get_timing(blah2hip_amb_t h, double *ms_total, uint32_t *launch
 }
 
 // ---------------------------------------------------------------- clutter --
-// (implemented in clutter.hip)
+// implemented in clutter.hip; it reports errors through this internal hook so
+// that blah2hip_last_error() covers both translation units
+void blah2hip_set_error_(const char *msg) { g_err = msg ? msg : ""; }
 
 } // extern "C"

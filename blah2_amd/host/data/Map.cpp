@@ -1,0 +1,147 @@
+#include "data/Map.h"
+
+#include "data/meta/Constants.h"
+#include "util/JsonOut.h"
+
+#include <cmath>
+#include <cstdio>
+#include <iostream>
+
+// every cell starts at 1 like the reference (Map.cpp:18), so 10*log10|z| is 0
+template <class T>
+Map<T>::Map(uint32_t rows, uint32_t cols)
+    : nRows(rows), nCols(cols), data(rows, std::vector<T>(cols, T(1))), noisePower(0.0), maxPower(0.0) {}
+
+template <class T> void Map<T>::set_row(uint32_t i, std::vector<T> row)
+{
+  for (uint32_t j = 0; j < nCols; j++) data[i][j] = row[j];
+}
+
+template <class T> void Map<T>::set_col(uint32_t i, std::vector<T> col)
+{
+  for (uint32_t j = 0; j < nRows; j++) data[j][i] = col[j];
+}
+
+template <class T> uint32_t Map<T>::get_nRows() { return nRows; }
+template <class T> uint32_t Map<T>::get_nCols() { return nCols; }
+template <class T> std::vector<T> Map<T>::get_row(uint32_t row) { return data[row]; }
+
+template <class T> std::vector<T> Map<T>::get_col(uint32_t col)
+{
+  std::vector<T> out(nRows);
+  for (uint32_t i = 0; i < nRows; i++) out[i] = data[i][col];
+  return out;
+}
+
+template <class T> Map<double> *Map<T>::get_map_db()
+{
+  Map<double> *db = new Map<double>(nRows, nCols);
+  for (uint32_t i = 0; i < nRows; i++)
+    for (uint32_t j = 0; j < nCols; j++) db->data[i][j] = 10.0 * std::log10(std::abs(data[i][j]));
+  return db;
+}
+
+template <class T> void Map<T>::print()
+{
+  for (const auto &row : data) {
+    for (const auto &v : row) std::cout << v << " ";
+    std::cout << std::endl;
+  }
+}
+
+// exact-equality search that returns 0 on a miss (reference Map.cpp:102-113)
+template <class T> uint32_t Map<T>::doppler_hz_to_bin(double hz)
+{
+  for (size_t i = 0; i < doppler.size(); i++)
+    if (doppler[i] == hz) return (uint32_t)i;
+  return 0;
+}
+
+// Map::set_metrics (reference Map.cpp:187-206): noisePower = mean(10 log10|z|),
+// maxPower = max(0, max 10 log10|z|) - noisePower.  For a map that came out of
+// the GPU engine the reduction was fused into the Doppler kernel and the
+// values are adopted from there; any other map is reduced here in fp64.
+template <class T> void Map<T>::set_metrics()
+{
+  if (engineMetricsValid) {
+    noisePower = engineNoise;
+    maxPower = engineMax;
+    return;
+  }
+  double sum = 0.0, peak = 0.0;
+  for (uint32_t i = 0; i < nRows; i++)
+    for (uint32_t j = 0; j < nCols; j++) {
+      const double v = 10.0 * std::log10(std::abs(data[i][j]));
+      sum += v;
+      if (peak < v) peak = v;
+    }
+  noisePower = sum / ((double)nRows * nCols);
+  maxPower = peak - noisePower;
+}
+
+// Field order of the reference document (Map.cpp:148-155):
+// timestamp,nRows,nCols,noisePower,maxPower,delay[],doppler[],data[][]
+template <class T> std::string Map<T>::to_json(uint64_t timestamp)
+{
+  blah2json::Writer w(2);
+  w.begin_object();
+  w.key("timestamp"); w.value(timestamp);
+  w.key("nRows"); w.value(nRows);
+  w.key("nCols"); w.value(nCols);
+  w.key("noisePower"); w.value(noisePower);
+  w.key("maxPower"); w.value(maxPower);
+  w.key("delay"); w.begin_array();
+  for (int d : delay) w.value(d);
+  w.end_array();
+  w.key("doppler"); w.begin_array();
+  for (uint32_t i = 0; i < nRows; i++) w.value(doppler[i]);
+  w.end_array();
+  w.key("data"); w.begin_array();
+  for (const auto &row : data) {
+    w.begin_array();
+    for (const auto &v : row) w.value(10.0 * std::log10(std::abs(v)) - noisePower);
+    w.end_array();
+  }
+  w.end_array();
+  w.end_object();
+  return w.str();
+}
+
+// The reference re-parses the document and rewrites "delay" in km
+// (Map.cpp:165-185): delay*c/fs/1000 with 2 decimals.
+template <class T> std::string Map<T>::delay_bin_to_km(std::string json, uint32_t fs)
+{
+  std::string arr = "[";
+  for (size_t i = 0; i < delay.size(); i++) {
+    if (i) arr.push_back(',');
+    blah2json::write_double(arr, 1.0 * delay[i] * (Constants::c / (double)fs) / 1000, 2);
+  }
+  arr.push_back(']');
+  return blah2json::replace_array(json, "delay", arr);
+}
+
+// append one JSON object to a file that holds a JSON array (Map.cpp:208-262)
+template <class T> bool Map<T>::save(std::string json, std::string path)
+{
+  FILE *fp = std::fopen(path.c_str(), "rb+");
+  if (!fp) {
+    fp = std::fopen(path.c_str(), "wb+");
+    if (!fp) return false;
+    std::fputs("[]", fp);
+    std::fflush(fp);
+  }
+  std::fseek(fp, 0, SEEK_SET);
+  if (std::fgetc(fp) != '[') { std::fclose(fp); return false; }
+  const bool empty = std::fgetc(fp) == ']';
+  std::fseek(fp, -1, SEEK_END);
+  if (std::fgetc(fp) != ']') { std::fclose(fp); return false; }
+  std::fseek(fp, -1, SEEK_END);
+  if (!empty) std::fputc(',', fp);
+  std::fwrite(json.data(), 1, json.size(), fp);
+  std::fputc(']', fp);
+  std::fclose(fp);
+  return true;
+}
+
+template class Map<std::complex<double>>;
+template class Map<double>;

@@ -209,6 +209,51 @@ class CfarDetector1D:
         return Detection(d[:k].copy(), f[:k].copy(), s[:k].copy())
 
 
+class WienerHopf:
+    """src/process/clutter/WienerHopf.h:68-78: least-squares clutter canceller.
+
+    ``process(x, y)`` returns ``(ok, y_filtered)``; the reference returns the
+    bool and replaces the contents of the y FIFO (WienerHopf.cpp:156-160).  When
+    the normal equations are not positive definite ``ok`` is False and y is
+    returned unchanged (blah2.cpp:270-273 then skips the CPI)."""
+
+    def __init__(self, delayMin, delayMax, nSamples, device=0, max_batch=1):
+        L = _lib.load()
+        h = C.c_void_p()
+        check(L.blah2hip_clutter_create(delayMin, delayMax, nSamples, device, max_batch, C.byref(h)))
+        self._h, self._L = h, L
+        self.nSamples = nSamples
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.blah2hip_clutter_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process(self, x, y):
+        x = np.ascontiguousarray(x)
+        y = np.ascontiguousarray(y)
+        ok = C.c_int(0)
+        if x.dtype == np.complex64 and y.dtype == np.complex64:
+            out = np.empty(self.nSamples, dtype=np.complex64)
+            check(self._L.blah2hip_clutter_process_c32(self._h, _ptr(x), _ptr(y), x.shape[0], _ptr(out), C.byref(ok)))
+        else:
+            x = x.astype(np.complex128, copy=False)
+            y = y.astype(np.complex128, copy=False)
+            out = np.empty(self.nSamples, dtype=np.complex128)
+            check(self._L.blah2hip_clutter_process_c64(self._h, _ptr(x), _ptr(y), x.shape[0], _ptr(out), C.byref(ok)))
+        return (True, out) if ok.value else (False, y.copy())
+
+    def process_dev(self, d_x, d_y, n_cpi, cpi_stride, d_y_out, d_ok=None, stream=0):
+        """Enqueue on ``stream``: device complex64 planes, output may alias d_y."""
+        check(self._L.blah2hip_clutter_process_dev(self._h, d_x, d_y, n_cpi, cpi_stride, d_y_out, d_ok, stream))
+
+
 def next_hamming(v: int) -> int:
     """src/process/meta/HammingNumber.cpp:38-48."""
     return int(_lib.load().blah2hip_next_hamming(v))
