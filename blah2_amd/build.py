@@ -75,11 +75,32 @@ def build_host(force=False, verbose=True):
     return HOSTLIB
 
 
+HOSTTEST = os.path.join(HOST, "test", "test_ambiguity")
+
+
+def build_host_test(force=False, verbose=True):
+    """C++ test program for the drop-in classes (mirrors the reference's TestAmbiguity.cpp)."""
+    src = os.path.join(HOST, "test", "test_ambiguity.cpp")
+    if not os.path.exists(src) or not os.path.exists(HOSTLIB):
+        return None
+    if not force and not _newer(HOSTTEST, [src, HOSTLIB, LIB]):
+        return HOSTTEST
+    cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", HOST, src, "-o", HOSTTEST,
+           "-L", PKG, "-lblah2host", "-lblah2hip", "-Wl,-rpath,$ORIGIN/../.."]
+    if verbose:
+        print("[blah2_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HOSTTEST
+
+
 def build_all(force=False, verbose=True):
     out = [build_hip(force, verbose)]
     h = build_host(force, verbose)
     if h:
         out.append(h)
+        t = build_host_test(force, verbose)
+        if t:
+            out.append(t)
     return out
 
 

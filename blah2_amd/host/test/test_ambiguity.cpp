@@ -1,0 +1,107 @@
+// C++ test of the host classes, modelled on the reference's
+// test/unit/process/ambiguity/TestAmbiguity.cpp (Catch2 is not available in
+// this image, so plain checks).  Exercises the exact call sequence of
+// blah2.cpp:268-287 through the drop-in classes.  Run on a GPU box:
+//     test_ambiguity [golden.bin]
+// Exit code 0 = all checks passed.
+#include "data/IqData.h"
+#include "data/Map.h"
+#include "process/ambiguity/Ambiguity.h"
+#include "process/clutter/WienerHopf.h"
+#include "process/detection/CfarDetector1D.h"
+#include "process/meta/HammingNumber.h"
+
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <stdexcept>
+
+static int failures = 0;
+#define CHECK(cond)                                                     \
+  do {                                                                  \
+    if (!(cond)) { std::printf("CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); failures++; } \
+  } while (0)
+
+static void random_iq(IqData &iq, unsigned seed)
+{
+  std::mt19937 gen(seed);
+  std::uniform_real_distribution<> dist(-100.0, 100.0);
+  for (uint32_t i = 0; i < iq.get_n(); ++i) iq.push_back({dist(gen), dist(gen)});
+}
+
+int main()
+{
+  // TestHammingNumber.cpp:15-17
+  CHECK(next_hamming(104) == 108);
+  CHECK(next_hamming(3322) == 3375);
+  CHECK(next_hamming(19043) == 19200);
+
+  const int32_t delayMin = -10, delayMax = 300, dopplerMin = -300, dopplerMax = 300;
+  const uint32_t fs = 2000000;
+  const float tCpi = 0.5;
+  const uint32_t nSamples = tCpi * fs;
+
+  for (int rh = 0; rh < 2; rh++) {
+    // TestAmbiguity.cpp "Constructor" / "Constructor_Round"
+    Ambiguity ambiguity(delayMin, delayMax, dopplerMin, dopplerMax, fs, nSamples, rh != 0);
+    CHECK(std::fabs(ambiguity.get_cpi() - tCpi) <= 0.02);
+    CHECK(ambiguity.get_doppler_middle() == 0);
+    CHECK(ambiguity.get_n_corr() == 3322);
+    CHECK(ambiguity.get_n_delay_bins() == delayMax + std::abs(delayMin) + 1);
+    CHECK(ambiguity.get_n_doppler_bins() == 301);
+    CHECK(ambiguity.get_nfft() == (rh ? 6750u : 6643u));
+
+    // "Process_Simple"
+    IqData x{nSamples}, y{nSamples};
+    random_iq(x, 1);
+    random_iq(y, 2);
+    auto map = ambiguity.process(&x, &y);
+    map->set_metrics();
+    CHECK(map->maxPower > 0.0);
+    CHECK(map->noisePower > 0.0);
+    CHECK(x.get_length() == nSamples - 3322u * 301u); // process() consumes by pop_front
+    CHECK(ambiguity.get_n_samples() == 3322u * 301u);
+
+    // underflow behaves like IqData::pop_front
+    bool threw = false;
+    try { ambiguity.process(&x, &y); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+  }
+
+  // the t2 loop of blah2.cpp:268-287 with an injected target
+  {
+    const uint32_t n = 200000, fsl = 1000000;
+    IqData x{n}, y{n};
+    std::mt19937 gen(7);
+    std::normal_distribution<> g(0.0, 300.0);
+    std::vector<std::complex<double>> xs(n);
+    for (auto &v : xs) v = {std::round(g(gen)), std::round(g(gen))};
+    for (uint32_t i = 0; i < n; i++) {
+      std::complex<double> t = 0.8 * xs[i];
+      if (i >= 37) t += 0.05 * xs[i - 37] * std::exp(std::complex<double>(0, 2 * M_PI * (-63.0) * i / fsl));
+      t += std::complex<double>(0.1 * g(gen), 0.1 * g(gen));
+      x.push_back(xs[i]);
+      y.push_back({std::round(t.real()), std::round(t.imag())});
+    }
+    WienerHopf filter(-10, 100, n);
+    Ambiguity ambiguity(-10, 100, -100, 100, fsl, n, true);
+    CfarDetector1D cfar(1e-5, 2, 6, 5, 15.0);
+    CHECK(filter.process(&x, &y));
+    auto map = ambiguity.process(&x, &y);
+    map->set_metrics();
+    auto det = cfar.process(map);
+    bool found = false;
+    auto dl = det->get_delay();
+    auto dp = det->get_doppler();
+    for (size_t i = 0; i < dl.size(); i++)
+      if (dl[i] == 37 && std::fabs(dp[i] + 63.0) < 5.1) found = true;
+    CHECK(found);
+    const std::string js = map->delay_bin_to_km(map->to_json(1234567890123ull), fsl);
+    CHECK(js.find("{\"timestamp\":1234567890123,\"nRows\":41,\"nCols\":111,\"noisePower\":") == 0);
+    CHECK(js.find("\"delay\":[-2.99,-2.69") != std::string::npos); // -10*c/fs/1000 = -2.9979 -> truncated
+    std::printf("chain: %zu detections, noisePower %.3f maxPower %.3f, json %zu bytes\n", dl.size(),
+                map->noisePower, map->maxPower, js.size());
+  }
+  std::printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
+  return failures ? 1 : 0;
+}
