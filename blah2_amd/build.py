@@ -51,7 +51,7 @@ def build_hip(force=False, verbose=True):
     if not force and not _newer(LIB, deps):
         return LIB
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-I", CSRC, *srcs, "-o", LIB]
+           "-Wno-unused-value", "-fno-slp-vectorize", "-I", os.path.join(ROOT, "include"), "-I", CSRC, *srcs, "-o", LIB]
     if verbose:
         print("[blah2_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -146,7 +146,9 @@ bool choose_plan(blah2hip_amb_s *h)
     if (lmax < 16) continue;
     const int nSeg = (nCorr + lmax - 1) / lmax;
     const int segLen = (nCorr + nSeg - 1) / nSeg;
-    const double cost = (2.0 * nSeg + 1.0) * F * std::log2((double)F);
+    // measured on MI355X (tools/gpu_diag.py): at equal butterfly count the one-wave
+    // F = 1024 transform is ~8 % slower per point than the multi-wave ones
+    const double cost = (2.0 * nSeg + 1.0) * F * std::log2((double)F) * (r3 == 4 ? 1.08 : 1.0);
     if (cost < best) {
       best = cost;
       found = true;
@@ -241,7 +243,21 @@ template <int R3, class In> int launch_range_t(blah2hip_amb_s *h, const RangeArg
   using W = WgFft<R3>;
   const size_t lds = (size_t)(W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
   static const bool ilv = [] { const char *e = std::getenv("BLAH2HIP_RANGE_ILV"); return e && std::atoi(e) != 0; }();
-  auto kern = ilv ? range_kernel<R3, In, true> : range_kernel<R3, In, false>;
+  // profiling ablations (results are wrong by construction): bit0 arithmetic, bit1 LDS, bit2 loads
+  static const int abl = [] { const char *e = std::getenv("BLAH2HIP_RANGE_ABLATE"); return e ? std::atoi(e) : 7; }();
+  void (*kern)(RangeArgs, In) = ilv ? range_kernel<R3, In, true> : range_kernel<R3, In, false>;
+  if (abl != 7 && R3 <= 8) {
+    switch (abl) {
+    case 0: kern = range_kernel<R3, In, false, 0, false>; break;
+    case 1: kern = range_kernel<R3, In, false, 1, false>; break;
+    case 2: kern = range_kernel<R3, In, false, 2, false>; break;
+    case 3: kern = range_kernel<R3, In, false, 3, false>; break;
+    case 4: kern = range_kernel<R3, In, false, 0, true>; break;
+    case 5: kern = range_kernel<R3, In, false, 1, true>; break;
+    case 6: kern = range_kernel<R3, In, false, 2, true>; break;
+    default: break;
+    }
+  }
   static thread_local const void *configured = nullptr;
   if (configured != (const void *)kern) {
     HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

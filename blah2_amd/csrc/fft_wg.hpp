@@ -43,6 +43,12 @@
 
 namespace blah2 {
 
+// Complex fp32 as a plain {re, im} pair with scalar arithmetic.  The library is
+// built with -fno-slp-vectorize: v_pk_*_f32 has the same lanes-per-cycle rate as
+// the scalar v_*_f32 forms on gfx950 (157 TF either way), and letting the SLP
+// vectoriser (or a float2 ext-vector type, which was tried) form packed ops
+// costs one v_mov per repacked operand (17-30 % of the VALU stream) and 64-bit
+// register-tuple constraints that pushed the range kernel into scratch spills.
 struct alignas(8) cf {
   float x, y;
 };
@@ -170,12 +176,19 @@ template <int R3> struct WgFft {
 
   // ---- forward -----------------------------------------------------------
   // v[k1] = in[t + T*k1] on entry
-  B2_HD static void fwd_s1(int t, cf *v, const cf *tw1, cf *A)
+  // M is an ablation mask for profiling builds: bit 0 = do the arithmetic,
+  // bit 1 = do the LDS traffic.  Production code uses the default (3).
+  template <int M = 3> B2_HD static void fwd_s1(int t, cf *v, const cf *tw1, cf *A)
   {
-    dft16<-1>(v);
-    A[t] = v[0];
+    if (M & 1) {
+      dft16<-1>(v);
 #pragma unroll
-    for (int q = 1; q < 16; q++) A[q * PA + t] = cmul(v[q], tw1[q - 1]);
+      for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw1[q - 1]);
+    }
+    if (M & 2) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) A[q * PA + t] = v[q];
+    }
   }
   B2_HD static void fwd_s2_load(int t, cf *v, const cf *A)
   {
@@ -189,39 +202,49 @@ template <int R3> struct WgFft {
 #pragma unroll
     for (int r = 0; r < 16; r++) B[q * PB + u * SU + r] = v[r];
   }
-  B2_HD static void fwd_s2(int t, cf *v, const cf *A, cf *B)
+  template <int M = 3> B2_HD static void fwd_s2(int t, cf *v, const cf *A, cf *B)
   {
-    fwd_s2_load(t, v, A);
-    dft16<-1>(v);
-    fwd_s2_store(t, v, B);
+    if (M & 2) fwd_s2_load(t, v, A);
+    if (M & 1) dft16<-1>(v);
+    if (M & 2) fwd_s2_store(t, v, B);
   }
   // leaves X[q + 16*r + 256*s] in v[j*R3 + s], (16*q + r) = t + T*j
-  B2_HD static void fwd_s3(int t, cf *v, const cf *tw3, const cf *B)
+  template <int M = 3> B2_HD static void fwd_s3(int t, cf *v, const cf *tw3, const cf *B)
   {
     const int r = t & 15;
 #pragma unroll
     for (int j = 0; j < NP; j++) {
       const int q = (t >> 4) + R3 * j;
       cf *w = v + j * R3;
-      w[0] = B[q * PB + r];
+      if (M & 2) {
 #pragma unroll
-      for (int u = 1; u < R3; u++) w[u] = cmul(B[q * PB + u * SU + r], tw3[u - 1]);
-      dftR<R3, -1>(w);
+        for (int u = 0; u < R3; u++) w[u] = B[q * PB + u * SU + r];
+      }
+      if (M & 1) {
+#pragma unroll
+        for (int u = 1; u < R3; u++) w[u] = cmul(w[u], tw3[u - 1]);
+        dftR<R3, -1>(w);
+      }
     }
   }
 
   // ---- inverse (unnormalised: returns F * ifft) ----------------------------
-  B2_HD static void inv_s1(int t, cf *v, const cf *tw3, cf *B)
+  template <int M = 3> B2_HD static void inv_s1(int t, cf *v, const cf *tw3, cf *B)
   {
     const int r = t & 15;
 #pragma unroll
     for (int j = 0; j < NP; j++) {
       const int q = (t >> 4) + R3 * j;
       cf *w = v + j * R3;
-      dftR<R3, +1>(w);
-      B[q * PB + r] = w[0];
+      if (M & 1) {
+        dftR<R3, +1>(w);
 #pragma unroll
-      for (int a = 1; a < R3; a++) B[q * PB + a * SU + r] = cmulc(w[a], tw3[a - 1]);
+        for (int a = 1; a < R3; a++) w[a] = cmulc(w[a], tw3[a - 1]);
+      }
+      if (M & 2) {
+#pragma unroll
+        for (int a = 0; a < R3; a++) B[q * PB + a * SU + r] = w[a];
+      }
     }
   }
   B2_HD static void inv_s2_load(int t, cf *v, const cf *B)
@@ -236,19 +259,24 @@ template <int R3> struct WgFft {
 #pragma unroll
     for (int b = 0; b < 16; b++) A[q * PA + a + R3 * b] = v[b];
   }
-  B2_HD static void inv_s2(int t, cf *v, const cf *B, cf *A)
+  template <int M = 3> B2_HD static void inv_s2(int t, cf *v, const cf *B, cf *A)
   {
-    inv_s2_load(t, v, B);
-    dft16<+1>(v);
-    inv_s2_store(t, v, A);
+    if (M & 2) inv_s2_load(t, v, B);
+    if (M & 1) dft16<+1>(v);
+    if (M & 2) inv_s2_store(t, v, A);
   }
   // leaves z[t + T*c] in v[c]
-  B2_HD static void inv_s3(int t, cf *v, const cf *tw1, const cf *A)
+  template <int M = 3> B2_HD static void inv_s3(int t, cf *v, const cf *tw1, const cf *A)
   {
-    v[0] = A[t];
+    if (M & 2) {
 #pragma unroll
-    for (int q = 1; q < 16; q++) v[q] = cmulc(A[q * PA + t], tw1[q - 1]);
-    dft16<+1>(v);
+      for (int q = 0; q < 16; q++) v[q] = A[q * PA + t];
+    }
+    if (M & 1) {
+#pragma unroll
+      for (int q = 1; q < 16; q++) v[q] = cmulc(v[q], tw1[q - 1]);
+      dft16<+1>(v);
+    }
   }
 };
 

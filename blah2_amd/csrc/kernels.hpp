@@ -35,7 +35,9 @@ struct RangeArgs {
   int32_t nPulses;     // nCpi * nDoppler
 };
 
-template <int R3, class In, bool ILV>
+// M / LD are profiling ablations (tools/gpu_ablate.py): M bit 0 = arithmetic, bit 1 = LDS
+// traffic, LD = global loads.  Production launches use <.., 3, true>.
+template <int R3, class In, bool ILV, int M = 3, bool LD = true>
 __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
 {
   using W = WgFft<R3>;
@@ -56,8 +58,13 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
     cf v[16], yv[16], acc[16];
     for (int s = 0; s < p.nSeg; s++) {
       // both channels' loads go out first: 32 requests in flight per thread
-      load_seg_x<R3>(in, p, base, s, t, v);
-      load_seg_y<R3>(in, p, base, s, t, yv);
+      if (LD) {
+        load_seg_x<R3>(in, p, base, s, t, v);
+        load_seg_y<R3>(in, p, base, s, t, yv);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) { v[k] = cmake((float)(t + k), (float)s); yv[k] = cmake((float)k, (float)(t - s)); }
+      }
       mask_seg_x<R3>(p, s, t, v);
       mask_seg_y<R3>(p, s, t, yv);
       // The x and y transforms advance together, each through its own exchange
@@ -80,16 +87,16 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
         W::fwd_s3(t, yv, tw3, Q); // yv = Y spectrum
       } else {
         // one transform at a time, P in the A layout and Q in the B layout
-        W::fwd_s1(t, v, tw1, P);
+        W::template fwd_s1<M>(t, v, tw1, P);
         __syncthreads();
-        W::fwd_s2(t, v, P, Q);
+        W::template fwd_s2<M>(t, v, P, Q);
         __syncthreads();
-        W::fwd_s3(t, v, tw3, Q);
-        W::fwd_s1(t, yv, tw1, P);
+        W::template fwd_s3<M>(t, v, tw3, Q);
+        W::template fwd_s1<M>(t, yv, tw1, P);
         __syncthreads();
-        W::fwd_s2(t, yv, P, Q);
+        W::template fwd_s2<M>(t, yv, P, Q);
         __syncthreads();
-        W::fwd_s3(t, yv, tw3, Q);
+        W::template fwd_s3<M>(t, yv, tw3, Q);
       }
       if (s == 0) {
 #pragma unroll
@@ -100,11 +107,11 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
       }
       __syncthreads(); // P/Q are rewritten by the next segment (or the inverse)
     }
-    W::inv_s1(t, acc, tw3, P);
+    W::template inv_s1<M>(t, acc, tw3, P);
     __syncthreads();
-    W::inv_s2(t, acc, P, Q);
+    W::template inv_s2<M>(t, acc, P, Q);
     __syncthreads();
-    W::inv_s3(t, acc, tw1, Q);
+    W::template inv_s3<M>(t, acc, tw1, Q);
     store_lags<R3>(a.out, p, cpi, i, t, acc);
     __syncthreads(); // Q is rewritten by the next pulse
   }
