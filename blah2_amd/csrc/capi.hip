@@ -85,6 +85,7 @@ struct blah2hip_amb_s {
   cf *d_dtw = nullptr;              // exp(-2 pi i k/M)
   cf *d_chirp = nullptr;            // exp(-i pi n^2/nD)
   cf *d_bf = nullptr;               // chirp-kernel spectrum / M in register layout
+  uint32_t *d_dopCnt = nullptr;     // per-CPI arrival tickets of the Doppler kernel (zero between launches)
 
   bool timing = false;
   std::vector<EventPair> ev[BLAH2HIP_K_COUNT];
@@ -225,15 +226,14 @@ void doppler_tables(int nD, int r3, std::vector<cf> &tw, std::vector<cf> &chirp,
 template <int R3> int launch_doppler_t(blah2hip_amb_s *h, const DopplerArgs &a, uint32_t n_cpi, hipStream_t st)
 {
   using W = WgFft<R3>;
-  constexpr int NC = 256 / W::T;
-  const size_t lds = (size_t)NC * (W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
+  const size_t lds = (size_t)(R3 == 4 ? W::A_ELEMS : W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
   auto kern = doppler_fft_kernel<R3>;
   static thread_local const void *configured = nullptr;
   if (configured != (const void *)kern) {
     HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = (const void *)kern;
   }
-  hipLaunchKernelGGL(kern, dim3(h->dopGridX, n_cpi), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(h->dopGridX, n_cpi), dim3(W::T), lds, st, a);
   HIPCHK(hipGetLastError());
   return BLAH2HIP_OK;
 }
@@ -242,7 +242,8 @@ template <int R3, class In> int launch_range_t(blah2hip_amb_s *h, const RangeArg
 {
   using W = WgFft<R3>;
   const size_t lds = (size_t)(W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
-  static const bool ilv = [] { const char *e = std::getenv("BLAH2HIP_RANGE_ILV"); return e && std::atoi(e) != 0; }();
+  // x/y transforms interleaved between barriers: +3..6 % for F <= 2048 (measured), neutral at 4096
+  static const bool ilv = [] { const char *e = std::getenv("BLAH2HIP_RANGE_ILV"); return e ? std::atoi(e) != 0 : (R3 <= 8); }();
   // profiling ablations (results are wrong by construction): bit0 arithmetic, bit1 LDS, bit2 loads
   static const int abl = [] { const char *e = std::getenv("BLAH2HIP_RANGE_ABLATE"); return e ? std::atoi(e) : 7; }();
   void (*kern)(RangeArgs, In) = ilv ? range_kernel<R3, In, true> : range_kernel<R3, In, false>;
@@ -416,8 +417,7 @@ int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_mi
   h->dopTilesX = (nDelay + 63) / 64;
   h->dopTilesY = (nD + DOP_KPT - 1) / DOP_KPT;
   if (h->dopR3) {
-    const int gpt = 16 / (256 / (16 * h->dopR3)); // column groups per 16-column tile
-    h->dopGridX = 8 * ((h->nTiles + 7) / 8) * gpt;
+    h->dopGridX = 8 * ((h->nTiles + 7) / 8) * 16; // one workgroup per column, tiles padded to a multiple of 8
     h->nParts = h->dopGridX;
   } else {
     h->nParts = h->dopTilesX * h->dopTilesY;
@@ -433,6 +433,8 @@ int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_mi
   HIPCHK(hipMalloc(&h->d_doppler, nD * sizeof(double)));
   HIPCHK(hipMalloc(&h->d_alpha, 256 * sizeof(double)));
   HIPCHK(hipMalloc(&h->d_count, max_batch * sizeof(uint32_t)));
+  HIPCHK(hipMalloc(&h->d_dopCnt, max_batch * sizeof(uint32_t)));
+  HIPCHK(hipMemset(h->d_dopCnt, 0, max_batch * sizeof(uint32_t)));
   HIPCHK(hipMemset(h->d_R, 0, rcells * max_batch * sizeof(cf))); // padding columns stay finite
   HIPCHK(hipMemcpy(h->d_tw, tw.data(), F * sizeof(cf), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->d_dopW, dw.data(), nD * sizeof(cf), hipMemcpyHostToDevice));
@@ -459,7 +461,7 @@ int blah2hip_amb_destroy(blah2hip_amb_t h)
   for (void *p : {(void *)h->d_tw, (void *)h->d_dopW, (void *)h->d_R, (void *)h->d_map,
                   (void *)h->d_partSum, (void *)h->d_partMax, (void *)h->d_metrics,
                   (void *)h->d_doppler, (void *)h->d_alpha, h->d_in, (void *)h->d_rot,
-                  (void *)h->d_hits, (void *)h->d_count, (void *)h->d_dtw, (void *)h->d_chirp,
+                  (void *)h->d_hits, (void *)h->d_count, (void *)h->d_dopCnt, (void *)h->d_dtw, (void *)h->d_chirp,
                   (void *)h->d_bf})
     if (p) hipFree(p);
   for (auto &v : h->ev)
@@ -558,7 +560,10 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   da.nD = (int32_t)nD;
   da.nDelay = (int32_t)nDelay;
   da.nTiles = h->nTiles;
-  da.nGroups = h->dopR3 ? h->nTiles * (16 / (256 / (16 * h->dopR3))) : 0;
+  da.nGroups = 0;
+  da.counter = h->d_dopCnt;
+  da.metrics = met;
+  da.cells = (double)nD * (double)nDelay;
   if ((rc = tic(h, BLAH2HIP_K_DOPPLER, st))) return rc;
   if (h->dopR3 == 4) rc = launch_doppler_t<4>(h, da, n_cpi, st);
   else if (h->dopR3 == 8) rc = launch_doppler_t<8>(h, da, n_cpi, st);
@@ -570,11 +575,13 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   if (rc) return rc;
   if ((rc = toc(h, BLAH2HIP_K_DOPPLER, st))) return rc;
 
-  if ((rc = tic(h, BLAH2HIP_K_METRICS, st))) return rc;
-  hipLaunchKernelGGL(metrics_kernel, dim3(n_cpi), dim3(256), 0, st, h->d_partSum, h->d_partMax,
-                     h->nParts, (double)nD * (double)nDelay, met);
-  HIPCHK(hipGetLastError());
-  if ((rc = toc(h, BLAH2HIP_K_METRICS, st))) return rc;
+  {
+    if ((rc = tic(h, BLAH2HIP_K_METRICS, st))) return rc;
+    hipLaunchKernelGGL(metrics_kernel, dim3(n_cpi), dim3(256), 0, st, h->d_partSum, h->d_partMax,
+                       h->nParts, (double)nD * (double)nDelay, met);
+    HIPCHK(hipGetLastError());
+    if ((rc = toc(h, BLAH2HIP_K_METRICS, st))) return rc;
+  }
   return BLAH2HIP_OK;
 }
 

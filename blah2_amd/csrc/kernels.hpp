@@ -175,6 +175,9 @@ struct DopplerArgs {
   double *partSum;  // [nCpi][partsPerCpi]
   float *partMax;   // [nCpi][partsPerCpi]
   int32_t nD, nDelay, nTiles, nGroups;
+  uint32_t *counter; // [nCpi] arrival tickets, zero between launches
+  double *metrics;   // [nCpi][2]
+  double cells;      // nD * nDelay
 };
 
 // 10*log10|z| = 5*log10(re^2+im^2) = 5*log10(2) * log2(re^2+im^2)
@@ -202,27 +205,26 @@ __device__ __forceinline__ void block_metrics_partial(double lsum, float lmax, d
   }
 }
 
+// One column per workgroup of T = 16*R3 threads (for nD <= 513 that is a single
+// wave: its barriers cost nothing and the two exchange buffers can alias).
+// Epilogue: per-workgroup (sum, max) partial of Map::set_metrics.
 template <int R3>
-__global__ __launch_bounds__(256) void doppler_fft_kernel(DopplerArgs a)
+__global__ __launch_bounds__(16 * R3) void doppler_fft_kernel(DopplerArgs a)
 {
   using W = WgFft<R3>;
   constexpr int T = W::T;
-  constexpr int NC = 256 / T; // columns per workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int sub = threadIdx.x / T;
-  const int t = threadIdx.x % T;
-  cf *A = reinterpret_cast<cf *>(smem) + sub * (W::A_ELEMS + W::B_ELEMS);
-  cf *B = A + W::A_ELEMS;
+  const int t = threadIdx.x;
+  cf *A = reinterpret_cast<cf *>(smem);
+  cf *B = (R3 == 4) ? A : A + W::A_ELEMS; // single wave: in-order LDS, no cross-wave hazard
   const int nD = a.nD;
   const int cpi = blockIdx.y;
-  // block -> column group: the 16/NC groups of one 16-column tile get block ids
-  // that are congruent mod 8 (same XCD) and adjacent in dispatch order
-  constexpr int GPT = 16 / NC; // groups per tile
+  // block -> column: the 16 columns of one tile get block ids that are congruent
+  // mod 8 (same XCD) and adjacent in dispatch order
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int tileIdx = (slot / GPT) * 8 + xcd;
-  const int group = tileIdx * GPT + (slot % GPT);
-  const int col = group * NC + sub;
-  const bool colok = group < a.nGroups && col < a.nDelay;
+  const int tileIdx = (slot >> 4) * 8 + xcd;
+  const int col = tileIdx * 16 + (slot & 15);
+  const bool colok = tileIdx < a.nTiles && col < a.nDelay;
 
   cf tw1[15], tw3[16];
   W::load_twiddles(t, a.tw, tw1, tw3);
@@ -233,7 +235,9 @@ __global__ __launch_bounds__(256) void doppler_fft_kernel(DopplerArgs a)
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     const int i = t + T * k;
-    v[k] = (i < nD) ? cmul(csub(Rc[(size_t)i * 16], r0), a.chirp[i]) : cmake(0.f, 0.f);
+    const cf rv = Rc[(size_t)(i < nD ? i : 0) * 16];
+    const cf ch = a.chirp[i < nD ? i : 0];
+    v[k] = (i < nD) ? cmul(csub(rv, r0), ch) : cmake(0.f, 0.f);
   }
   W::fwd_s1(t, v, tw1, A);
   __syncthreads();
@@ -266,8 +270,14 @@ __global__ __launch_bounds__(256) void doppler_fft_kernel(DopplerArgs a)
       lmax = fmaxf(lmax, db);
     }
   }
-  const size_t part = (size_t)cpi * gridDim.x + blockIdx.x;
-  block_metrics_partial(lsum, lmax, a.partSum + part, a.partMax + part);
+  const int nParts = gridDim.x;
+  double *pS = a.partSum + (size_t)cpi * nParts;
+  float *pM = a.partMax + (size_t)cpi * nParts;
+
+  // one (sum, max) partial per workgroup; metrics_kernel folds them in index order.
+  // (A last-arriver reduction inside this kernel was tried: one ticket atomic per
+  // workgroup on a per-CPI counter serialises at ~12 ns each, 5 us per CPI.)
+  block_metrics_partial(lsum, lmax, pS + blockIdx.x, pM + blockIdx.x);
 }
 
 // Fallback for nD > 2049 (transform longer than the on-chip FFT covers):
