@@ -1,0 +1,73 @@
+"""GPU parity at the full sizes of BASELINE.json configs[2..4] against the fp64
+NumPy oracle (seconds on the host), plus size-independent properties."""
+import numpy as np
+import pytest
+
+from oracle import blah2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def b2(built_lib):
+    import blah2_amd
+    assert blah2_amd.device_count() > 0
+    return blah2_amd
+
+
+def check(b2, cfg, expect_dims, targets, seed, elem_tol=2e-4):
+    dmin, dmax, fmin, fmax, fs, n = cfg
+    x, y = O.synth_iq(n, seed=seed, fs=fs, targets=targets)
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True)
+    assert (amb.get_n_doppler_bins(), amb.get_n_delay_bins(), amb.get_n_corr(), amb.get_nfft()) == expect_dims
+    m = amb.process(x.astype(np.complex64), y.astype(np.complex64))
+    d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
+    ref = O.ambiguity_process(d, x, y)
+    got = m.data.astype(np.complex128)
+    peak = np.max(np.abs(ref))
+    err = np.abs(got - ref)
+    assert err.max() / peak <= 1e-5
+    strong = np.abs(ref) > np.mean(np.abs(ref))
+    assert np.max(err[strong] / np.abs(ref[strong])) <= elem_tol
+    noise, mx = O.map_metrics(ref)
+    assert abs(m.noisePower - noise) <= 1e-3 and abs(m.maxPower - mx) <= 1e-3
+    # every injected target is the local maximum of the map around its cell
+    db = 10 * np.log10(np.abs(got))
+    for dly, f, _ in targets:
+        j = dly - dmin
+        i = int(np.argmin(np.abs(amb.doppler - f)))
+        win = db[max(0, i - 2):i + 3, max(0, j - 2):j + 3]
+        assert db[i, j] == win.max(), (dly, f)
+        assert db[i, j] - m.noisePower > 10.0
+    return amb, m
+
+
+def test_cfg3_10Msps_1025x2048(b2):
+    """configs[2]: 10 MS/s, 1 s CPI, 1025 Doppler x 2048 range (F = 4096, Bluestein M = 2048)."""
+    cfg = (-24, 2023, -512, 512, 10_000_000, 10_000_000)
+    amb, m = check(b2, cfg, (1025, 2048, 9756, 19683), ((37, -63.0, 0.05), (1500, 300.0, 0.05), (700, -400.0, 0.04)), 5)
+    assert amb.dims.fft_len == 4096
+    # 1-D CFAR on the big map agrees with the vectorised oracle (borderline cells excepted)
+    det = b2.CfarDetector1D(1e-6, 2, 6, 5, 15.0).process(m)
+    d = O.ambiguity_dims(*cfg, True)
+    dl, dp, _ = O.cfar1d_fast(m.data.astype(np.complex128), d.delay, d.doppler, m.noisePower, 1e-6, 2, 6, 5, 15.0)
+    assert set(zip(det.get_delay(), det.get_doppler())) == set(zip(dl, dp))
+    assert (1500.0 in det.get_delay()) and (700.0 in det.get_delay())
+
+
+def test_cfg5_20Msps_2049_doppler(b2):
+    """configs[4] geometry: 20 MS/s, 2 s CPI, 2049 Doppler bins (Bluestein M = 4096, nCorr = 19521)."""
+    cfg = (-10, 400, -512, 512, 20_000_000, 40_000_000)
+    check(b2, cfg, (2049, 411, 19521, 39366), ((37, -63.0, 0.05), (300, 250.25, 0.05)), 6)
+
+
+def test_config_yml_defaults(b2):
+    """config/config.yml:21,26-29: 2 MS/s, 0.75 s, +-200 Hz, -10..400 -> 301 x 411."""
+    cfg = (-10, 400, -200, 200, 2_000_000, 1_500_000)
+    check(b2, cfg, (301, 411, 4983, 10000), ((37, -63.0, 0.05),), 7)
+
+
+def test_cfg1_127_doppler_prime(b2):
+    """configs[0] geometry: 0.5 s CPI, +-126 Hz -> 127 (prime) Doppler bins."""
+    cfg = (-10, 400, -126, 126, 2_000_000, 1_000_000)
+    check(b2, cfg, (127, 411, 7874, 16000), ((37, -63.0, 0.05),), 8)
