@@ -747,6 +747,89 @@ int blah2hip_amb_get_timing(blah2hip_amb_t h, double *ms_total, uint32_t *launch
   return BLAH2HIP_OK;
 }
 
+// ------------------------------------------------- centroid / interpolate --
+// Host arithmetic on a handful of detections (O(n^2) over tens of items).
+int blah2hip_centroid(const double *delay, const double *doppler, const double *snr, uint32_t count,
+                      uint16_t n_delay, uint16_t n_doppler, double resolution_doppler,
+                      double *delay_out, double *doppler_out, double *snr_out, uint32_t *count_out)
+{
+  if (!count_out || (count && (!delay || !doppler || !snr || !delay_out || !doppler_out || !snr_out)))
+    return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  uint32_t kept = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    // Centroid.cpp:36-39: uint16_t limits -> (int)delay - n_delay wraps when negative
+    const uint16_t lo = (uint16_t)((int)delay[i] - (int)n_delay);
+    const uint16_t hi = (uint16_t)((int)delay[i] + (int)n_delay);
+    const double flo = doppler[i] - (n_doppler * resolution_doppler);
+    const double fhi = doppler[i] + (n_doppler * resolution_doppler);
+    bool keep = true;
+    for (uint32_t j = 0; j < count && keep; j++) {
+      if (j == i) continue;
+      if (delay[j] > lo && delay[j] < hi && doppler[j] > flo && doppler[j] < fhi && snr[i] < snr[j]) keep = false;
+    }
+    if (keep) {
+      delay_out[kept] = delay[i];
+      doppler_out[kept] = doppler[i];
+      snr_out[kept] = snr[i];
+      kept++;
+    }
+  }
+  *count_out = kept;
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_interpolate(const double *delay, const double *doppler, const double *snr, uint32_t count,
+                         const float *map, uint32_t n_doppler, uint32_t n_delay, const int32_t *delay_axis,
+                         const double *doppler_axis, double noise_power, int do_delay, int do_doppler,
+                         double *delay_out, double *doppler_out, double *snr_out, uint32_t *count_out)
+{
+  if (!count_out || !map || !delay_axis || !doppler_axis) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (count && (!delay || !doppler || !snr || !delay_out || !doppler_out || !snr_out))
+    return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  // 10*log10|z| - noisePower of one map cell (Interpolate.cpp:50-52)
+  auto cell = [&](int64_t row, int64_t col) -> double {
+    if (row < 0 || row >= (int64_t)n_doppler || col < 0 || col >= (int64_t)n_delay)
+      return std::nan(""); // the reference would index out of bounds here
+    const float *z = map + 2 * ((size_t)row * n_delay + (size_t)col);
+    return 10.0 * std::log10(std::hypot((double)z[0], (double)z[1])) - noise_power;
+  };
+  // Map::doppler_hz_to_bin: exact match, 0 on a miss (Map.cpp:102-113)
+  auto row_of = [&](double hz) -> int64_t {
+    for (uint32_t r = 0; r < n_doppler; r++)
+      if (doppler_axis[r] == hz) return r;
+    return 0;
+  };
+  uint32_t kept = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    double intDelay = delay[i], intDoppler = doppler[i], intSnrDelay = snr[i];
+    const double intSnrDoppler = snr[i]; // never updated in the reference (:80 writes intSnrDelay)
+    const int64_t row = row_of(doppler[i]);
+    const int64_t col = (int64_t)(delay[i] - delay_axis[0]);
+    if (do_delay) {
+      if (delay[i] == delay_axis[0] || delay[i] == delay_axis[n_delay - 1]) continue; // :46-49
+      const double s0 = cell(row, col - 1), s1 = cell(row, col), s2 = cell(row, col + 1);
+      if (s1 < s0 || s1 < s2) continue; // :54-58 dropped (peak lower than a neighbour)
+      double off = (s0 - s2) / (2 * (s0 - (2 * s1) + s2));
+      intSnrDelay = s1 - (((s0 - s2) * off) / 4);
+      intDelay = delay[i] + off;
+    }
+    if (do_doppler) {
+      if (doppler[i] == doppler_axis[0] || doppler[i] == doppler_axis[n_doppler - 1]) continue; // :67-70
+      const double s0 = cell(row - 1, col), s1 = cell(row, col), s2 = cell(row + 1, col);
+      if (s1 < s0 || s1 < s2) continue;
+      double off = (s0 - s2) / (2 * (s0 - (2 * s1) + s2));
+      intSnrDelay = s1 - (((s0 - s2) * off) / 4); // sic, :80
+      intDoppler = doppler[i] + ((doppler_axis[1] - doppler_axis[0]) * off);
+    }
+    delay_out[kept] = intDelay;
+    doppler_out[kept] = intDoppler;
+    snr_out[kept] = std::max(std::max(intSnrDelay, intSnrDoppler), snr[i]); // :88
+    kept++;
+  }
+  *count_out = kept;
+  return BLAH2HIP_OK;
+}
+
 // ---------------------------------------------------------------- clutter --
 // implemented in clutter.hip; it reports errors through this internal hook so
 // that blah2hip_last_error() covers both translation units

@@ -209,6 +209,44 @@ class CfarDetector1D:
         return Detection(d[:k].copy(), f[:k].copy(), s[:k].copy())
 
 
+class Centroid:
+    """src/process/detection/Centroid.h: non-maximum suppression of the CFAR list."""
+
+    def __init__(self, nDelay, nDoppler, resolutionDoppler):
+        self.nDelay, self.nDoppler, self.resolutionDoppler = int(nDelay), int(nDoppler), float(resolutionDoppler)
+
+    def process(self, x: Detection) -> Detection:
+        L = _lib.load()
+        n = x.get_nDetections()
+        d, f, s = (np.ascontiguousarray(v, dtype=np.float64) for v in (x.delay, x.doppler, x.snr))
+        od, of, os_ = np.zeros(n), np.zeros(n), np.zeros(n)
+        k = C.c_uint32(0)
+        check(L.blah2hip_centroid(_ptr(d), _ptr(f), _ptr(s), n, self.nDelay, self.nDoppler, self.resolutionDoppler,
+                                  _ptr(od), _ptr(of), _ptr(os_), C.byref(k)))
+        return Detection(od[:k.value], of[:k.value], os_[:k.value])
+
+
+class Interpolate:
+    """src/process/detection/Interpolate.h: quadratic peak interpolation."""
+
+    def __init__(self, doDelay, doDoppler):
+        self.doDelay, self.doDoppler = bool(doDelay), bool(doDoppler)
+
+    def process(self, x: Detection, y: Map) -> Detection:
+        L = _lib.load()
+        n = x.get_nDetections()
+        d, f, s = (np.ascontiguousarray(v, dtype=np.float64) for v in (x.delay, x.doppler, x.snr))
+        m = np.ascontiguousarray(y.data, dtype=np.complex64)
+        dax = np.ascontiguousarray(y.delay, dtype=np.int32)
+        fax = np.ascontiguousarray(y.doppler, dtype=np.float64)
+        od, of, os_ = np.zeros(n), np.zeros(n), np.zeros(n)
+        k = C.c_uint32(0)
+        check(L.blah2hip_interpolate(_ptr(d), _ptr(f), _ptr(s), n, _ptr(m), m.shape[0], m.shape[1], _ptr(dax),
+                                     _ptr(fax), float(y.noisePower), int(self.doDelay), int(self.doDoppler),
+                                     _ptr(od), _ptr(of), _ptr(os_), C.byref(k)))
+        return Detection(od[:k.value], of[:k.value], os_[:k.value])
+
+
 class WienerHopf:
     """src/process/clutter/WienerHopf.h:68-78: least-squares clutter canceller.
 

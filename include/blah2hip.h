@@ -138,6 +138,25 @@ int blah2hip_cfar1d_process(blah2hip_amb_t h, uint32_t cpi, double pfa, int32_t 
                             int32_t n_train, int32_t min_delay, double min_doppler, double *delay,
                             double *doppler, double *snr, uint32_t cap, uint32_t *count);
 
+/* ---- Centroid / Interpolate (host-side, tens of detections) -------------- */
+/* Centroid::process (src/process/detection/Centroid.cpp:19-73): keeps a
+ * detection unless a stronger one lies strictly inside its
+ * (+-n_delay bins, +-n_doppler*resolution Hz) box.  The box's delay limits are
+ * uint16_t in the reference (they wrap for delay - n_delay < 0); reproduced.
+ * In/out arrays may not alias.  *count_out <= count. */
+int blah2hip_centroid(const double *delay, const double *doppler, const double *snr, uint32_t count,
+                      uint16_t n_delay, uint16_t n_doppler, double resolution_doppler,
+                      double *delay_out, double *doppler_out, double *snr_out, uint32_t *count_out);
+/* Interpolate::process (src/process/detection/Interpolate.cpp:20-91): 3-point
+ * quadratic peak interpolation in delay and/or Doppler on the map cells
+ * (complex fp32, [n_doppler][n_delay]); drops detections on the map edge or
+ * whose neighbours are stronger.  The Doppler branch stores its SNR estimate
+ * into the delay variable like the reference does (:80). */
+int blah2hip_interpolate(const double *delay, const double *doppler, const double *snr, uint32_t count,
+                         const float *map, uint32_t n_doppler, uint32_t n_delay, const int32_t *delay_axis,
+                         const double *doppler_axis, double noise_power, int do_delay, int do_doppler,
+                         double *delay_out, double *doppler_out, double *snr_out, uint32_t *count_out);
+
 /* ---- WienerHopf clutter filter (WienerHopf.h:68-78) --------------------- */
 int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_samples, int device,
                             uint32_t max_batch, blah2hip_clutter_t *out);
