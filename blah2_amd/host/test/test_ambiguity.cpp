@@ -8,7 +8,9 @@
 #include "data/Map.h"
 #include "process/ambiguity/Ambiguity.h"
 #include "process/clutter/WienerHopf.h"
+#include "process/detection/Centroid.h"
 #include "process/detection/CfarDetector1D.h"
+#include "process/detection/Interpolate.h"
 #include "process/meta/HammingNumber.h"
 
 #include <cmath>
@@ -89,12 +91,17 @@ int main()
     CHECK(filter.process(&x, &y));
     auto map = ambiguity.process(&x, &y);
     map->set_metrics();
-    auto det = cfar.process(map);
+    auto det1 = cfar.process(map);
+    Centroid centroid(6, 6, 1.0 / 0.2);
+    Interpolate interpolate(true, true);
+    auto det2 = centroid.process(det1.get());        // blah2.cpp:286
+    auto det = interpolate.process(det2.get(), map); // blah2.cpp:287
+    CHECK(det2->get_nDetections() <= det1->get_nDetections());
     bool found = false;
     auto dl = det->get_delay();
     auto dp = det->get_doppler();
     for (size_t i = 0; i < dl.size(); i++)
-      if (dl[i] == 37 && std::fabs(dp[i] + 63.0) < 5.1) found = true;
+      if (std::fabs(dl[i] - 37) < 1.0 && std::fabs(dp[i] + 63.0) < 5.1) found = true;
     CHECK(found);
     const std::string js = map->delay_bin_to_km(map->to_json(1234567890123ull), fsl);
     CHECK(js.find("{\"timestamp\":1234567890123,\"nRows\":41,\"nCols\":111,\"noisePower\":") == 0);
