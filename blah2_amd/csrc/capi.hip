@@ -85,6 +85,9 @@ struct blah2hip_amb_s {
   cf *d_dtw = nullptr;              // exp(-2 pi i k/M)
   cf *d_chirp = nullptr;            // exp(-i pi n^2/nD)
   cf *d_bf = nullptr;               // chirp-kernel spectrum / M in register layout
+  double *d_sat = nullptr;          // 2-D CFAR summed-area table [max_batch][nD+1][nDelay+1]
+  double *d_alpha2 = nullptr;       // 2-D CFAR alpha table
+  size_t alpha2Cap = 0;
   uint32_t *d_dopCnt = nullptr;     // per-CPI arrival tickets of the Doppler kernel (zero between launches)
 
   bool timing = false;
@@ -461,7 +464,7 @@ int blah2hip_amb_destroy(blah2hip_amb_t h)
   for (void *p : {(void *)h->d_tw, (void *)h->d_dopW, (void *)h->d_R, (void *)h->d_map,
                   (void *)h->d_partSum, (void *)h->d_partMax, (void *)h->d_metrics,
                   (void *)h->d_doppler, (void *)h->d_alpha, h->d_in, (void *)h->d_rot,
-                  (void *)h->d_hits, (void *)h->d_count, (void *)h->d_dopCnt, (void *)h->d_dtw, (void *)h->d_chirp,
+                  (void *)h->d_hits, (void *)h->d_count, (void *)h->d_sat, (void *)h->d_alpha2, (void *)h->d_dopCnt, (void *)h->d_dtw, (void *)h->d_chirp,
                   (void *)h->d_bf})
     if (p) hipFree(p);
   for (auto &v : h->ev)
@@ -715,6 +718,96 @@ int blah2hip_cfar1d_process(blah2hip_amb_t h, uint32_t cpi, double pfa, int32_t 
     if (delay) delay[i] = (double)(hits[i].col + h->delayAxis[0]); // :88  j + x->delay[0]
     if (doppler) doppler[i] = h->dopplerAxis[hits[i].row];         // :89
     if (snr) snr[i] = hits[i].snr;                                 // :90
+  }
+  return BLAH2HIP_OK;
+}
+
+// ---------------------------------------------------------------- 2-D CFAR --
+int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_metrics, uint32_t n_cpi,
+                        double pfa, int32_t ngd, int32_t ntd, int32_t ngf, int32_t ntf, int32_t min_delay,
+                        double min_doppler, blah2hip_hit_t *d_hits, uint32_t cap, uint32_t *d_count,
+                        void *stream)
+{
+  if (!h || !d_hits || !d_count) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (n_cpi == 0 || n_cpi > h->dims.max_batch) return fail(BLAH2HIP_ERR_INVALID, "n_cpi outside [1, max_batch]");
+  for (int32_t v : {ngd, ntd, ngf, ntf})
+    if (v < 0 || v > 127) return fail(BLAH2HIP_ERR_INVALID, "guard/train sizes outside [0, 127]");
+  if (min_delay < -128 || min_delay > 127) return fail(BLAH2HIP_ERR_INVALID, "minDelay outside int8 range");
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int nD = (int)h->dims.n_doppler_bins, nC = (int)h->dims.n_delay_bins;
+  const size_t satElems = (size_t)(nD + 1) * (nC + 1);
+  if (!h->d_sat) {
+    HIPCHK(hipMalloc(&h->d_sat, satElems * h->dims.max_batch * sizeof(double)));
+    HIPCHK(hipMemset(h->d_sat, 0, satElems * h->dims.max_batch * sizeof(double))); // zero borders
+  }
+  const size_t maxN = (size_t)(2 * (ngd + ntd) + 1) * (2 * (ngf + ntf) + 1);
+  if (h->alpha2Cap < maxN + 1) {
+    if (h->d_alpha2) HIPCHK(hipFree(h->d_alpha2));
+    h->d_alpha2 = nullptr;
+    HIPCHK(hipMalloc(&h->d_alpha2, (maxN + 1) * sizeof(double)));
+    h->alpha2Cap = maxN + 1;
+  }
+  std::vector<double> alpha(maxN + 1);
+  alpha[0] = std::nan("");
+  for (size_t n = 1; n <= maxN; n++) alpha[n] = (double)n * (pow(pfa, -1.0 / (double)n) - 1);
+  HIPCHK(hipMemcpyAsync(h->d_alpha2, alpha.data(), (maxN + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st)); // alpha[] is a stack-lifetime host buffer
+  HIPCHK(hipMemsetAsync(d_count, 0, n_cpi * sizeof(uint32_t), st));
+  Cfar2dArgs a;
+  a.map = d_map ? (const cf *)d_map : h->d_map;
+  a.metrics = d_metrics ? d_metrics : h->d_metrics;
+  a.doppler = h->d_doppler;
+  a.alpha = h->d_alpha2;
+  a.sat = h->d_sat;
+  a.hits = d_hits;
+  a.count = d_count;
+  a.nD = nD; a.nDelay = nC; a.delayMin = h->delayMin;
+  a.ngD = ngd; a.ntD = ntd; a.ngF = ngf; a.ntF = ntf; a.minDelay = min_delay;
+  a.minDoppler = min_doppler;
+  a.cap = cap;
+  int rc;
+  if ((rc = tic(h, BLAH2HIP_K_CFAR, st))) return rc;
+  hipLaunchKernelGGL(sat_rows_kernel, dim3(nD, n_cpi), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(sat_cols_kernel, dim3((nC + 255) / 256, n_cpi), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cfar2d_kernel, dim3((nC + 255) / 256, nD, n_cpi), dim3(256), 0, st, a);
+  HIPCHK(hipGetLastError());
+  if ((rc = toc(h, BLAH2HIP_K_CFAR, st))) return rc;
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_cfar2d_process(blah2hip_amb_t h, uint32_t cpi, double pfa, int32_t ngd, int32_t ntd,
+                            int32_t ngf, int32_t ntf, int32_t min_delay, double min_doppler, double *delay,
+                            double *doppler, double *snr, uint32_t cap, uint32_t *count)
+{
+  if (!h || !count) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (cpi >= h->dims.max_batch) return fail(BLAH2HIP_ERR_INVALID, "cpi index out of range");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t cells = (size_t)h->dims.n_doppler_bins * h->dims.n_delay_bins;
+  if (h->hitCap < cells) {
+    if (h->d_hits) HIPCHK(hipFree(h->d_hits));
+    h->d_hits = nullptr;
+    HIPCHK(hipMalloc(&h->d_hits, cells * sizeof(blah2hip_hit_t)));
+    h->hitCap = (uint32_t)cells;
+  }
+  int rc = blah2hip_cfar2d_dev(h, h->d_map + cells * cpi, h->d_metrics + 2 * cpi, 1, pfa, ngd, ntd, ngf, ntf,
+                               min_delay, min_doppler, h->d_hits, h->hitCap, h->d_count, h->stream);
+  if (rc) return rc;
+  uint32_t n = 0;
+  HIPCHK(hipMemcpyAsync(&n, h->d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  n = std::min(n, h->hitCap);
+  std::vector<blah2hip_hit_t> hits(n);
+  if (n) HIPCHK(hipMemcpy(hits.data(), h->d_hits, n * sizeof(blah2hip_hit_t), hipMemcpyDeviceToHost));
+  std::sort(hits.begin(), hits.end(), [](const blah2hip_hit_t &a, const blah2hip_hit_t &b) {
+    return a.row != b.row ? a.row < b.row : a.col < b.col;
+  });
+  *count = n;
+  if (n > cap) return fail(BLAH2HIP_ERR_CAPACITY, "detection capacity too small");
+  for (uint32_t i = 0; i < n; i++) {
+    if (delay) delay[i] = (double)(hits[i].col + h->delayAxis[0]);
+    if (doppler) doppler[i] = h->dopplerAxis[hits[i].row];
+    if (snr) snr[i] = hits[i].snr;
   }
   return BLAH2HIP_OK;
 }

@@ -436,4 +436,98 @@ __global__ void cfar1d_kernel(CfarArgs a)
   }
 }
 
+// --------------------------------------------------------------------------
+// 2-D cell-averaging CFAR (BASELINE.json configs[2]; the reference only has the
+// 1-D detector).  Definition: SURVEY.md section 8g / oracle cfar2d(): training
+// cells = the (2(nGd+nTd)+1) x (2(nGf+nTf)+1) rectangle minus the guard box,
+// in-bounds only, delay column 0 never trains (CfarDetector1D.cpp:61), statistic
+// |z|^2, alpha = N (pfa^(-1/N) - 1).  With nGf = nTf = 0 it is the 1-D detector.
+// Window sums come from an fp64 summed-area table built by two scan kernels.
+struct Cfar2dArgs {
+  const cf *map;         // [nCpi][nD][nDelay]
+  const double *metrics; // [nCpi][2]
+  const double *doppler; // [nD]
+  const double *alpha;   // [maxN + 1]
+  double *sat;           // [nCpi][nD + 1][nDelay + 1], row 0 and column 0 stay zero
+  blah2hip_hit_t *hits;
+  uint32_t *count;
+  int32_t nD, nDelay, delayMin;
+  int32_t ngD, ntD, ngF, ntF, minDelay;
+  double minDoppler;
+  uint32_t cap;
+};
+
+// row-wise inclusive prefix of |z|^2 (column 0 zeroed) into sat[i+1][1..]
+__global__ __launch_bounds__(256) void sat_rows_kernel(Cfar2dArgs a)
+{
+  __shared__ double tot[256];
+  const int row = blockIdx.x, cpi = blockIdx.y, t = threadIdx.x;
+  const cf *z = a.map + ((size_t)cpi * a.nD + row) * a.nDelay;
+  double *out = a.sat + ((size_t)cpi * (a.nD + 1) + row + 1) * (a.nDelay + 1) + 1;
+  const int per = (a.nDelay + 255) / 256;
+  const int j0 = t * per, j1 = min(a.nDelay, j0 + per);
+  double run = 0.0;
+  for (int j = j0; j < j1; j++) {
+    const cf c = z[j];
+    run += (j == 0) ? 0.0 : (double)c.x * (double)c.x + (double)c.y * (double)c.y;
+  }
+  tot[t] = run;
+  __syncthreads();
+  double off = 0.0;
+  for (int i = 0; i < t; i++) off += tot[i]; // 256-entry serial prefix per thread: tiny
+  run = off;
+  for (int j = j0; j < j1; j++) {
+    const cf c = z[j];
+    run += (j == 0) ? 0.0 : (double)c.x * (double)c.x + (double)c.y * (double)c.y;
+    out[j] = run;
+  }
+}
+
+// column-wise running sum of the row prefixes -> summed-area table
+__global__ __launch_bounds__(256) void sat_cols_kernel(Cfar2dArgs a)
+{
+  const int j = blockIdx.x * 256 + threadIdx.x, cpi = blockIdx.y;
+  if (j >= a.nDelay) return;
+  double *col = a.sat + (size_t)cpi * (a.nD + 1) * (a.nDelay + 1) + (j + 1);
+  double run = 0.0;
+  for (int i = 1; i <= a.nD; i++) {
+    run += col[(size_t)i * (a.nDelay + 1)];
+    col[(size_t)i * (a.nDelay + 1)] = run;
+  }
+}
+
+__global__ __launch_bounds__(256) void cfar2d_kernel(Cfar2dArgs a)
+{
+  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, cpi = blockIdx.z;
+  if (j >= a.nDelay) return;
+  if (fabs(a.doppler[i]) < a.minDoppler) return;
+  if (j + a.delayMin < a.minDelay) return;
+  const int nD = a.nD, nC = a.nDelay, W = nC + 1;
+  const double *S = a.sat + (size_t)cpi * (nD + 1) * W;
+  auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+  const int R0 = clampi(i - a.ngF - a.ntF, 0, nD), R1 = clampi(i + a.ngF + a.ntF + 1, 0, nD);
+  const int G0 = clampi(i - a.ngF, 0, nD), G1 = clampi(i + a.ngF + 1, 0, nD);
+  const int C0 = clampi(j - a.ngD - a.ntD, 0, nC), C1 = clampi(j + a.ngD + a.ntD + 1, 0, nC);
+  const int H0 = clampi(j - a.ngD, 0, nC), H1 = clampi(j + a.ngD + 1, 0, nC);
+  auto box = [&](int r0, int r1, int c0, int c1) {
+    return S[(size_t)r1 * W + c1] - S[(size_t)r0 * W + c1] - S[(size_t)r1 * W + c0] + S[(size_t)r0 * W + c0];
+  };
+  auto cols = [](int c0, int c1) { return max(c1, 1) - max(c0, 1); }; // column 0 never trains
+  const double tot = box(R0, R1, C0, C1) - box(G0, G1, H0, H1);
+  const int n = (R1 - R0) * cols(C0, C1) - (G1 - G0) * cols(H0, H1);
+  if (n <= 0) return;
+  const cf c = a.map[((size_t)cpi * nD + i) * nC + j];
+  const double sq = (double)c.x * (double)c.x + (double)c.y * (double)c.y;
+  if (sq > a.alpha[n] * (tot / n)) {
+    const uint32_t slot = atomicAdd(&a.count[cpi], 1u);
+    if (slot < a.cap) {
+      blah2hip_hit_t h;
+      h.row = i;
+      h.col = j;
+      h.snr = 5.0 * log10(sq) - a.metrics[2 * cpi];
+      a.hits[(size_t)cpi * a.cap + slot] = h;
+    }
+  }
+}
+
 } // namespace blah2

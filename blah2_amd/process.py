@@ -209,6 +209,28 @@ class CfarDetector1D:
         return Detection(d[:k].copy(), f[:k].copy(), s[:k].copy())
 
 
+class CfarDetector2D:
+    """2-D cell-averaging CFAR (BASELINE.json configs[2]).  Not a reference class:
+    the reference only has the 1-D detector; this is its extension as defined in
+    SURVEY.md section 8g, and with nGuardDoppler = nTrainDoppler = 0 it returns
+    exactly what :class:`CfarDetector1D` returns."""
+
+    def __init__(self, pfa, nGuardDelay, nTrainDelay, nGuardDoppler, nTrainDoppler, minDelay, minDoppler):
+        self.pfa = float(pfa)
+        self.p = [int(nGuardDelay), int(nTrainDelay), int(nGuardDoppler), int(nTrainDoppler)]
+        self.minDelay, self.minDoppler = int(minDelay), float(minDoppler)
+
+    def process(self, x: Map) -> Detection:
+        amb = x._owner
+        cap = x.data.size
+        d, f, s = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+        n = C.c_uint32(0)
+        check(amb._L.blah2hip_cfar2d_process(amb._h, x._cpi_index, self.pfa, *self.p, self.minDelay,
+                                             self.minDoppler, _ptr(d), _ptr(f), _ptr(s), cap, C.byref(n)))
+        k = n.value
+        return Detection(d[:k].copy(), f[:k].copy(), s[:k].copy())
+
+
 class Centroid:
     """src/process/detection/Centroid.h: non-maximum suppression of the CFAR list."""
 

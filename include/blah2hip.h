@@ -138,6 +138,22 @@ int blah2hip_cfar1d_process(blah2hip_amb_t h, uint32_t cpi, double pfa, int32_t 
                             int32_t n_train, int32_t min_delay, double min_doppler, double *delay,
                             double *doppler, double *snr, uint32_t cap, uint32_t *count);
 
+/* 2-D cell-averaging CFAR (BASELINE.json configs[2]; NOT in the reference, which
+ * only has the 1-D detector).  Extension defined in SURVEY.md section 8g: training
+ * rectangle (2(ngd+ntd)+1) x (2(ngf+ntf)+1) minus the guard box, in-bounds cells
+ * only, delay column 0 never trains, |z|^2 statistic, alpha = N(pfa^(-1/N)-1);
+ * with n_guard_doppler = n_train_doppler = 0 it is exactly blah2hip_cfar1d_*.
+ * Same output conventions as the 1-D entry points. */
+int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_metrics, uint32_t n_cpi,
+                        double pfa, int32_t n_guard_delay, int32_t n_train_delay,
+                        int32_t n_guard_doppler, int32_t n_train_doppler, int32_t min_delay,
+                        double min_doppler, blah2hip_hit_t *d_hits, uint32_t cap, uint32_t *d_count,
+                        void *stream);
+int blah2hip_cfar2d_process(blah2hip_amb_t h, uint32_t cpi, double pfa, int32_t n_guard_delay,
+                            int32_t n_train_delay, int32_t n_guard_doppler, int32_t n_train_doppler,
+                            int32_t min_delay, double min_doppler, double *delay, double *doppler,
+                            double *snr, uint32_t cap, uint32_t *count);
+
 /* ---- Centroid / Interpolate (host-side, tens of detections) -------------- */
 /* Centroid::process (src/process/detection/Centroid.cpp:19-73): keeps a
  * detection unless a stronger one lies strictly inside its

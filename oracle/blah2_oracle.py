@@ -233,6 +233,82 @@ def cfar1d_fast(m, delay_axis, doppler_axis, noise_power, pfa, n_guard, n_train,
 
 
 # --------------------------------------------------------------------------
+# 2-D cell-averaging CFAR.  The reference has only the 1-D detector; BASELINE.json
+# configs[2] asks for a 2-D one, defined in SURVEY.md section 8g as the direct
+# extension of CfarDetector1D.cpp:23-100:
+#   * training cells: the (2(nGd+nTd)+1) x (2(nGf+nTf)+1) rectangle centred on the
+#     cell under test minus the (2nGd+1) x (2nGf+1) guard box, in-bounds cells only;
+#   * delay column 0 never trains (the 1-D detector's `k > 0`, :61);
+#   * statistic |z|^2, alpha = N (pfa^(-1/N) - 1) with N the in-bounds training count;
+#   * the same minDelay / minDoppler skips and row-major emission order;
+# so that with nGf = nTf = 0 it is exactly the 1-D detector.
+def cfar2d_bruteforce(m, delay_axis, doppler_axis, noise_power, pfa, ng_d, nt_d, ng_f, nt_f, min_delay, min_doppler):
+    m = np.asarray(m, dtype=np.complex128)
+    nD, nC = m.shape
+    sq = np.abs(m * m)
+    out = []
+    for i in range(nD):
+        if abs(doppler_axis[i]) < min_doppler:
+            continue
+        for j in range(nC):
+            if delay_axis[j] < min_delay:
+                continue
+            tot, n = 0.0, 0
+            for ii in range(max(0, i - ng_f - nt_f), min(nD, i + ng_f + nt_f + 1)):
+                for kk in range(max(1, j - ng_d - nt_d), min(nC, j + ng_d + nt_d + 1)):
+                    if abs(ii - i) <= ng_f and abs(kk - j) <= ng_d:
+                        continue
+                    tot += sq[ii, kk]
+                    n += 1
+            if n == 0:
+                continue
+            alpha = n * (math.pow(pfa, -1.0 / n) - 1)
+            if sq[i, j] > alpha * (tot / n):
+                out.append((float(j + delay_axis[0]), float(doppler_axis[i]),
+                            float(10.0 * np.log10(np.abs(m[i, j])) - noise_power)))
+    a = np.array(out).reshape(-1, 3)
+    return a[:, 0], a[:, 1], a[:, 2]
+
+
+def cfar2d(m, delay_axis, doppler_axis, noise_power, pfa, ng_d, nt_d, ng_f, nt_f, min_delay, min_doppler,
+           return_margin=False):
+    """Summed-area-table form of :func:`cfar2d_bruteforce` (fp64)."""
+    m = np.asarray(m, dtype=np.complex128)
+    nD, nC = m.shape
+    sq = np.abs(m * m)
+    z = sq.copy()
+    z[:, 0] = 0.0  # column 0 never trains
+    sat = np.zeros((nD + 1, nC + 1))
+    sat[1:, 1:] = np.cumsum(np.cumsum(z, axis=0), axis=1)
+
+    def box(r0, r1, c0, c1):  # half-open [r0,r1) x [c0,c1), already clipped
+        return sat[r1][:, c1] - sat[r0][:, c1] - sat[r1][:, c0] + sat[r0][:, c0]
+
+    i = np.arange(nD)
+    j = np.arange(nC)
+    R0, R1 = np.clip(i - ng_f - nt_f, 0, nD), np.clip(i + ng_f + nt_f + 1, 0, nD)
+    G0, G1 = np.clip(i - ng_f, 0, nD), np.clip(i + ng_f + 1, 0, nD)
+    C0, C1 = np.clip(j - ng_d - nt_d, 0, nC), np.clip(j + ng_d + nt_d + 1, 0, nC)
+    H0, H1 = np.clip(j - ng_d, 0, nC), np.clip(j + ng_d + 1, 0, nC)
+    tot = box(R0, R1, C0, C1) - box(G0, G1, H0, H1)
+    cols = lambda a, b: np.maximum(b, 1) - np.maximum(a, 1)  # columns >= 1 in [a, b)
+    n = np.outer(R1 - R0, cols(C0, C1)) - np.outer(G1 - G0, cols(H0, H1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        alpha = n * (np.power(pfa, -1.0 / n) - 1)
+        thr = alpha * (tot / n)
+    hit = (sq > thr) & (n > 0)
+    hit &= (np.asarray(delay_axis) >= min_delay)[None, :]
+    hit &= (np.abs(np.asarray(doppler_axis)) >= min_doppler)[:, None]
+    ii, jj = np.nonzero(hit)
+    snr = 10.0 * np.log10(np.abs(m[ii, jj])) - noise_power
+    res = ((jj + delay_axis[0]).astype(np.float64), np.asarray(doppler_axis)[ii].astype(np.float64), snr)
+    if return_margin:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return res + (sq / thr,)
+    return res
+
+
+# --------------------------------------------------------------------------
 def wiener_hopf(x, y, delay_min, delay_max):
     """``WienerHopf::process`` (src/process/clutter/WienerHopf.cpp:58-163).
 

@@ -88,3 +88,49 @@ def test_cfar_dense_vs_oracle(b2, params):
 def test_cfar_parameters_are_int8_like_the_reference(b2):
     with pytest.raises(ValueError):
         b2.CfarDetector1D(1e-5, 200, 6, 5, 15.0)
+
+
+# ---- 2-D CA-CFAR (BASELINE configs[2]; defined in SURVEY.md 8g, oracle cfar2d) ----
+def check_2d(b2, amb, m, m_ref, noise, params):
+    pfa, ngd, ntd, ngf, ntf, md, mdop = params
+    det = b2.CfarDetector2D(pfa, ngd, ntd, ngf, ntf, md, mdop).process(m)
+    dl, dp, sn, margin = O.cfar2d(m_ref, amb.delay, amb.doppler, noise, pfa, ngd, ntd, ngf, ntf, md, mdop,
+                                  return_margin=True)
+    ref = {(a, b): s for a, b, s in zip(dl, dp, sn)}
+    got = {(a, b): s for a, b, s in zip(det.get_delay(), det.get_doppler(), det.get_snr())}
+    row = {f: i for i, f in enumerate(amb.doppler)}
+    for key in set(ref) ^ set(got):
+        i, j = row[key[1]], int(key[0] - amb.delay[0])
+        assert abs(margin[i, j] - 1) < 1e-3, f"non-borderline mismatch at {key}: margin {margin[i, j]}"
+    for key in set(ref) & set(got):
+        assert abs(ref[key] - got[key]) < 1e-3
+    order = [(row[f], d) for d, f in zip(det.get_delay(), det.get_doppler())]
+    assert order == sorted(order)
+    return det
+
+
+@pytest.mark.parametrize("params", [
+    (1e-4, 2, 6, 1, 3, 5, 15.0),
+    (1e-2, 1, 3, 1, 2, -10, 0.0),   # dense, windows clipped on all four map edges
+    (1e-3, 0, 1, 0, 1, 0, 0.0),     # smallest possible annulus
+])
+def test_cfar2d_vs_oracle(b2, params):
+    g = load_golden("medium")
+    fs, n, dmin, dmax, fmin, fmax, rh = (int(v) for v in g["params"])
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, bool(rh))
+    m = amb.process(g["x"], g["y"])
+    det = check_2d(b2, amb, m, g["map"], g["metrics"][0], params)
+    assert det.get_nDetections() > 0
+
+
+def test_cfar2d_reduces_to_1d(b2):
+    g = load_golden("medium")
+    fs, n, dmin, dmax, fmin, fmax, rh = (int(v) for v in g["params"])
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, bool(rh))
+    m = amb.process(g["x"], g["y"])
+    for pfa, ng, nt, md, mdop in [(1e-5, 2, 6, 5, 15.0), (1e-2, 0, 1, -10, 0.0), (1e-3, 3, 20, 0, 0.0)]:
+        d1 = b2.CfarDetector1D(pfa, ng, nt, md, mdop).process(m)
+        d2 = b2.CfarDetector2D(pfa, ng, nt, 0, 0, md, mdop).process(m)
+        assert np.array_equal(d1.get_delay(), d2.get_delay())
+        assert np.array_equal(d1.get_doppler(), d2.get_doppler())
+        assert np.allclose(d1.get_snr(), d2.get_snr(), rtol=0, atol=1e-9)
