@@ -79,6 +79,7 @@ struct blah2hip_amb_s {
   uint32_t hitCap = 0;
   int dopTilesX = 0, dopTilesY = 0; // direct-DFT fallback grid
   int dopR3 = 0;                    // 0 = direct fallback, else Bluestein on WgFft<dopR3>
+  int dopTile = 0;                  // nD <= 513: columns per workgroup of the tile kernel (0 = off, 8 or 16)
   int dopGridX = 0;
   int nParts = 0;                   // metrics partials per CPI
   int nTiles = 0;                   // 16-column tiles of the range map
@@ -419,9 +420,14 @@ int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_mi
   if (const char *e = std::getenv("BLAH2HIP_DOPPLER_DIRECT")) if (std::atoi(e)) h->dopR3 = 0;
   h->dopTilesX = (nDelay + 63) / 64;
   h->dopTilesY = (nD + DOP_KPT - 1) / DOP_KPT;
+  h->dopTile = (h->dopR3 == 4) ? 16 : 0;
+  if (const char *e = std::getenv("BLAH2HIP_DOPPLER_TILE")) {
+    const int v = std::atoi(e);
+    h->dopTile = (h->dopR3 == 4 && (v == 8 || v == 16)) ? v : 0;
+  }
   if (h->dopR3) {
-    h->dopGridX = 8 * ((h->nTiles + 7) / 8) * 16; // one workgroup per column, tiles padded to a multiple of 8
-    h->nParts = h->dopGridX;
+    h->dopGridX = 8 * ((h->nTiles + 7) / 8) * 16; // per-column kernel: one workgroup per column, tiles padded to a multiple of 8
+    h->nParts = h->dopGridX;                      // (>= the tile kernel's workgroup count)
   } else {
     h->nParts = h->dopTilesX * h->dopTilesY;
   }
@@ -567,8 +573,24 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   da.counter = h->d_dopCnt;
   da.metrics = met;
   da.cells = (double)nD * (double)nDelay;
+  int nPartsUsed = h->nParts;
   if ((rc = tic(h, BLAH2HIP_K_DOPPLER, st))) return rc;
-  if (h->dopR3 == 4) rc = launch_doppler_t<4>(h, da, n_cpi, st);
+  // The tile kernel (coalesced, one 16-wave workgroup per CU) wins once a launch carries
+  // enough tiles to fill the chip; small launches (single CPI) keep the per-column kernel.
+  const int tileGrid = h->dopTile ? (int)((nDelay + h->dopTile - 1) / h->dopTile) : 0;
+  if (h->dopTile && (int)n_cpi * tileGrid >= h->numCU / 2) {
+    const size_t lds = (size_t)h->dopTile * DOPT_PITCH * sizeof(cf);
+    static thread_local bool configured = false;
+    if (!configured) {
+      HIPCHK(hipFuncSetAttribute((const void *)doppler_tile_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * DOPT_PITCH * (int)sizeof(cf)));
+      HIPCHK(hipFuncSetAttribute((const void *)doppler_tile_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * DOPT_PITCH * (int)sizeof(cf)));
+      configured = true;
+    }
+    if (h->dopTile == 16) hipLaunchKernelGGL(doppler_tile_kernel<16>, dim3(tileGrid, n_cpi), dim3(1024), lds, st, da);
+    else hipLaunchKernelGGL(doppler_tile_kernel<8>, dim3(tileGrid, n_cpi), dim3(512), lds, st, da);
+    nPartsUsed = tileGrid;
+    HIPCHK(hipGetLastError());
+  } else if (h->dopR3 == 4) rc = launch_doppler_t<4>(h, da, n_cpi, st);
   else if (h->dopR3 == 8) rc = launch_doppler_t<8>(h, da, n_cpi, st);
   else if (h->dopR3 == 16) rc = launch_doppler_t<16>(h, da, n_cpi, st);
   else {
@@ -581,7 +603,7 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   {
     if ((rc = tic(h, BLAH2HIP_K_METRICS, st))) return rc;
     hipLaunchKernelGGL(metrics_kernel, dim3(n_cpi), dim3(256), 0, st, h->d_partSum, h->d_partMax,
-                       h->nParts, (double)nD * (double)nDelay, met);
+                       nPartsUsed, (double)nD * (double)nDelay, met);
     HIPCHK(hipGetLastError());
     if ((rc = toc(h, BLAH2HIP_K_METRICS, st))) return rc;
   }

@@ -280,6 +280,135 @@ __global__ __launch_bounds__(16 * R3) void doppler_fft_kernel(DopplerArgs a)
   block_metrics_partial(lsum, lmax, pS + blockIdx.x, pM + blockIdx.x);
 }
 
+// Tile variant for nD <= 513 (M = 1024, one wave per column): a workgroup of 16
+// waves owns one 16-column tile of the range map.  The tile (nD x 128 bytes,
+// contiguous in HBM) is read with fully coalesced loads and transposed through
+// LDS, each wave runs its column's chirp-z transform in its own LDS region (the
+// staging area of a column IS that wave's exchange buffer, so no cross-wave
+// hazard exists after the fill), the results are transposed back through LDS
+// and the final map is written as 128-byte row segments.  This replaces the
+// 128-byte-stride gathers/scatters of doppler_fft_kernel, which spent 57 % of
+// its wave cycles waiting on memory (profiles/r01_pmc.csv).
+constexpr int DOPT_PITCH = WgFft<4>::A_ELEMS + 1; // 1089: odd pitch -> 16 columns hit 16 different bank pairs
+
+// NCOL = 16: whole 128-byte lines per row, 139 KB of LDS, one workgroup per CU;
+// NCOL = 8: half lines (the sibling workgroup takes the other half out of L2),
+// 70 KB, two workgroups per CU so that one's memory phases overlap the other's math.
+template <int NCOL>
+__global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a)
+{
+  using W = WgFft<4>;
+  constexpr int T = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf *lds = reinterpret_cast<cf *>(smem);
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, t = tid & 63; // wave = column of the tile
+  const int nD = a.nD;
+  constexpr int NT = 64 * NCOL;     // threads
+  constexpr int SH = (NCOL == 16) ? 4 : 3;
+  const int sub = blockIdx.x, cpi = blockIdx.y; // sub-tile of NCOL columns
+  const int col0 = sub * NCOL;
+  const int col = col0 + w;
+  const bool colok = col < a.nDelay;
+  cf *region = lds + w * DOPT_PITCH;
+
+  cf tw1[15], tw3[16];
+  W::load_twiddles(t, a.tw, tw1, tw3);
+
+  // phase 1: coalesced tile read, transposed into the per-column regions
+  const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, col0);
+  const int cells = nD * NCOL;
+  for (int idx = tid; idx < cells; idx += NT) {
+    const int c = idx & (NCOL - 1), row = idx >> SH;
+    lds[c * DOPT_PITCH + row] = Rt[row * 16 + c];
+  }
+  __syncthreads();
+
+  // phase 2: this wave's column -> registers (DC removal + chirp), then the transform
+  const cf r0 = region[0];
+  cf ch[16], v[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int i = t + T * k;
+    ch[k] = a.chirp[i < nD ? i : 0];
+    const cf rv = region[i < nD ? i : 0];
+    v[k] = (i < nD) ? cmul(csub(rv, r0), ch[k]) : cmake(0.f, 0.f);
+  }
+  // from here on `region` is this wave's private exchange buffer (A and B alias:
+  // a single wave's LDS operations execute in order)
+  // __builtin_amdgcn_wave_barrier(): no instruction, only stops the compiler from
+  // moving LDS accesses of different lanes' data across the stage boundaries
+  __builtin_amdgcn_wave_barrier();
+  W::fwd_s1(t, v, tw1, region);
+  __builtin_amdgcn_wave_barrier();
+  W::fwd_s2_load(t, v, region);
+  __builtin_amdgcn_wave_barrier();
+  dft16<-1>(v);
+  W::fwd_s2_store(t, v, region);
+  __builtin_amdgcn_wave_barrier();
+  W::fwd_s3(t, v, tw3, region);
+#pragma unroll
+  for (int e = 0; e < 16; e++) v[e] = cmul(v[e], a.bf[e * T + t]);
+  __builtin_amdgcn_wave_barrier();
+  W::inv_s1(t, v, tw3, region);
+  __builtin_amdgcn_wave_barrier();
+  W::inv_s2_load(t, v, region);
+  __builtin_amdgcn_wave_barrier();
+  dft16<+1>(v);
+  W::inv_s2_store(t, v, region);
+  __builtin_amdgcn_wave_barrier();
+  W::inv_s3(t, v, tw1, region);
+  __builtin_amdgcn_wave_barrier();
+
+  // phase 3: rotate rows by nD/2+1 and park the column back in its region
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const int k = t + T * c;
+    if (k < nD) {
+      cf d = cmul(v[c], ch[c]);
+      if (k == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
+      int o = k - (nD / 2 + 1);
+      if (o < 0) o += nD;
+      region[o] = d;
+    }
+  }
+  __syncthreads();
+
+  // phase 4: coalesced row-segment stores + Map::set_metrics partials
+  double lsum = 0.0;
+  float lmax = 0.f;
+  cf *mapb = a.map + (size_t)cpi * nD * a.nDelay + col0;
+  const int ncol = min(NCOL, a.nDelay - col0);
+  for (int idx = tid; idx < cells; idx += NT) {
+    const int c = idx & (NCOL - 1), o = idx >> SH;
+    if (c < ncol) {
+      const cf d = lds[c * DOPT_PITCH + o];
+      mapb[(size_t)o * a.nDelay + c] = d;
+      const float db = db_of(d);
+      lsum += (double)db;
+      lmax = fmaxf(lmax, db);
+    }
+  }
+  (void)colok;
+  const size_t part = (size_t)cpi * gridDim.x + blockIdx.x;
+  __shared__ double wsum[16];
+  __shared__ float wmax[16];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lsum += __shfl_xor(lsum, off);
+    lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+  }
+  if (t == 0) { wsum[w] = lsum; wmax[w] = lmax; }
+  __syncthreads();
+  if (tid == 0) {
+    double sacc = 0.0;
+    float m = 0.f; // Map.cpp:193: the running max starts at 0
+    for (int i = 0; i < NCOL; i++) { sacc += wsum[i]; m = fmaxf(m, wmax[i]); }
+    a.partSum[part] = sacc;
+    a.partMax[part] = m;
+  }
+}
+
 // Fallback for nD > 2049 (transform longer than the on-chip FFT covers):
 // direct DFT, lane <-> delay column, KPT output rows per thread, the 4 waves
 // split the pulse axis and reduce through LDS.  Same DC handling as above.
