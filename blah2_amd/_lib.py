@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(PKG, "libblah2hip.so")
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_UNDERFLOW, ERR_NO_DEVICE, ERR_CAPACITY = -1, -2, -3, -4, -5, -6
-FMT_C32, FMT_I16 = 0, 1
+FMT_C32, FMT_I16, FMT_F16 = 0, 1, 2
 K_RANGE, K_DOPPLER, K_METRICS, K_CFAR, K_COUNT = 0, 1, 2, 3, 8
 KERNEL_NAMES = {K_RANGE: "range", K_DOPPLER: "doppler", K_METRICS: "metrics", K_CFAR: "cfar"}
 

@@ -248,9 +248,11 @@ template <int R3, class In> int launch_range_t(blah2hip_amb_s *h, const RangeArg
   const size_t lds = (size_t)(W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
   // x/y transforms interleaved between barriers: +3..6 % for F <= 2048 (measured), neutral at 4096
   static const bool ilv = [] { const char *e = std::getenv("BLAH2HIP_RANGE_ILV"); return e ? std::atoi(e) != 0 : (R3 <= 8); }();
-  // profiling ablations (results are wrong by construction): bit0 arithmetic, bit1 LDS, bit2 loads
-  static const int abl = [] { const char *e = std::getenv("BLAH2HIP_RANGE_ABLATE"); return e ? std::atoi(e) : 7; }();
   void (*kern)(RangeArgs, In) = ilv ? range_kernel<R3, In, true> : range_kernel<R3, In, false>;
+#ifdef BLAH2HIP_ABLATE
+  // profiling build only (tools/gpu_ablate.py; results are wrong by construction):
+  // bit0 arithmetic, bit1 LDS, bit2 loads
+  static const int abl = [] { const char *e = std::getenv("BLAH2HIP_RANGE_ABLATE"); return e ? std::atoi(e) : 7; }();
   if (abl != 7 && R3 <= 8) {
     switch (abl) {
     case 0: kern = range_kernel<R3, In, false, 0, false>; break;
@@ -263,6 +265,7 @@ template <int R3, class In> int launch_range_t(blah2hip_amb_s *h, const RangeArg
     default: break;
     }
   }
+#endif
   static thread_local const void *configured = nullptr;
   if (configured != (const void *)kern) {
     HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -502,8 +505,9 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
 {
   if (!h) return fail(BLAH2HIP_ERR_INVALID, "NULL handle");
   if (n_cpi == 0 || n_cpi > h->dims.max_batch) return fail(BLAH2HIP_ERR_INVALID, "n_cpi outside [1, max_batch]");
-  if (fmt != BLAH2HIP_FMT_C32 && fmt != BLAH2HIP_FMT_I16) return fail(BLAH2HIP_ERR_INVALID, "unknown sample format");
-  if (!d_x || (fmt == BLAH2HIP_FMT_C32 && !d_y)) return fail(BLAH2HIP_ERR_INVALID, "NULL input pointer");
+  if (fmt != BLAH2HIP_FMT_C32 && fmt != BLAH2HIP_FMT_I16 && fmt != BLAH2HIP_FMT_F16)
+    return fail(BLAH2HIP_ERR_INVALID, "unknown sample format");
+  if (!d_x || (fmt != BLAH2HIP_FMT_I16 && !d_y)) return fail(BLAH2HIP_ERR_INVALID, "NULL input pointer");
   if (n_cpi > 1 && cpi_stride < h->dims.n_used) return fail(BLAH2HIP_ERR_INVALID, "cpi_stride < samples used per CPI");
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
@@ -533,6 +537,10 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
       InC32 in{(const cf *)d_x, (const cf *)d_y};
       hipLaunchKernelGGL(rotate_kernel<InC32>, grid, dim3(256), 0, st, in, xo, yo,
                          (int64_t)cpi_stride, (int64_t)plane, nrot, m2, h->fs);
+    } else if (fmt == BLAH2HIP_FMT_F16) {
+      InF16 in{(const _Float16 *)d_x, (const _Float16 *)d_y};
+      hipLaunchKernelGGL(rotate_kernel<InF16>, grid, dim3(256), 0, st, in, xo, yo,
+                         (int64_t)cpi_stride, (int64_t)plane, nrot, m2, h->fs);
     } else {
       InI16 in{(const int16_t *)d_x};
       hipLaunchKernelGGL(rotate_kernel<InI16>, grid, dim3(256), 0, st, in, xo, yo,
@@ -548,6 +556,9 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     if ((rc = tic(h, BLAH2HIP_K_RANGE, st))) return rc;
     if (fmt == BLAH2HIP_FMT_C32) {
       InC32 in{(const cf *)d_x, (const cf *)d_y};
+      rc = launch_range(h, ra, in, st);
+    } else if (fmt == BLAH2HIP_FMT_F16) {
+      InF16 in{(const _Float16 *)d_x, (const _Float16 *)d_y};
       rc = launch_range(h, ra, in, st);
     } else {
       InI16 in{(const int16_t *)d_x};

@@ -57,6 +57,18 @@ struct InI16 {
 // thread issue back to back (so their HBM latencies overlap), and the segment /
 // pulse masks are applied afterwards with selects (mask_seg_*).  Clamped lanes
 // re-read the last sample of the pulse, an L1 hit.
+#if defined(__clang__)
+// fp16 IQ storage with fp32 accumulate (BASELINE.json configs[4]): two planes of
+// (re, im) half pairs, 4 bytes per sample; every value is widened to fp32 on load
+// and all arithmetic stays fp32.
+struct InF16 {
+  const _Float16 *x;
+  const _Float16 *y;
+  B2_HD cf lx(int64_t i) const { return cmake((float)x[2 * i], (float)x[2 * i + 1]); }
+  B2_HD cf ly(int64_t i) const { return cmake((float)y[2 * i], (float)y[2 * i + 1]); }
+};
+#endif
+
 template <int R3, class In>
 B2_HD void load_seg_x(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, cf *v)
 {

@@ -54,6 +54,7 @@ extern "C" {
 /* input sample formats of the dev entry points */
 #define BLAH2HIP_FMT_C32 0 /* two planes of complex fp32: x = reference, y = surveillance */
 #define BLAH2HIP_FMT_I16 1 /* one buffer, int16 I1 Q1 I2 Q2 per sample (.rspduo, RspDuo.cpp:512-526) */
+#define BLAH2HIP_FMT_F16 2 /* two planes of (re,im) IEEE half pairs; widened to fp32 on load, fp32 accumulate */
 
 typedef struct blah2hip_amb_s *blah2hip_amb_t;
 typedef struct blah2hip_clutter_s *blah2hip_clutter_t;

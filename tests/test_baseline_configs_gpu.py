@@ -71,3 +71,26 @@ def test_cfg1_127_doppler_prime(b2):
     """configs[0] geometry: 0.5 s CPI, +-126 Hz -> 127 (prime) Doppler bins."""
     cfg = (-10, 400, -126, 126, 2_000_000, 1_000_000)
     check(b2, cfg, (127, 411, 7874, 16000), ((37, -63.0, 0.05),), 8)
+
+
+def test_fp16_iq_storage_fp32_accumulate(b2):
+    """configs[4]: IQ stored as fp16, fp32 accumulate.  The oracle is fed the
+    ALREADY-QUANTISED values, so only kernel error is measured."""
+    torch = pytest.importorskip("torch")
+    cfg = (-10, 400, -256, 256, 2_000_000, 2_000_000)
+    dmin, dmax, fmin, fmax, fs, n = cfg
+    x, y = O.synth_iq(n, seed=9, fs=fs, targets=((37, -63.0, 0.05),), quantise=False)
+    xh = np.stack([x.real, x.imag], axis=-1).astype(np.float16)
+    yh = np.stack([y.real, y.imag], axis=-1).astype(np.float16)
+    xq = xh[:, 0].astype(np.float64) + 1j * xh[:, 1].astype(np.float64)
+    yq = yh[:, 0].astype(np.float64) + 1j * yh[:, 1].astype(np.float64)
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True)
+    dx, dy = torch.from_numpy(xh).cuda(), torch.from_numpy(yh).cuda()
+    amb.process_dev(b2.FMT_F16, dx.data_ptr(), dy.data_ptr(), 1, n, None, None, torch.cuda.current_stream().cuda_stream)
+    m = amb.read_last(0)
+    d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
+    ref = O.ambiguity_process(d, xq, yq)
+    err = np.abs(m.data.astype(np.complex128) - ref)
+    assert err.max() / np.abs(ref).max() <= 1e-5
+    strong = np.abs(ref) > np.mean(np.abs(ref))
+    assert np.max(err[strong] / np.abs(ref[strong])) <= 2e-4
