@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--fmt", default="c32", choices=["c32", "i16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chain", default="amb", choices=["amb", "full"],
+                    help="amb: range+Doppler+metrics (BASELINE headline); full: clutter filter + amb + CFAR (configs[2])")
+    ap.add_argument("--cfar", default="2d", choices=["1d", "2d"])
     a = ap.parse_args()
 
     import torch
@@ -128,6 +131,16 @@ def main():
         else:
             iq = torch.stack([x.real, x.imag, y.real, y.imag], dim=-1).to(torch.int16).contiguous()
             iqs.append(iq)
+    wh = None
+    if a.chain == "full":
+        if a.fmt != "c32":
+            raise SystemExit("--chain full needs --fmt c32")
+        wh = blah2_amd.WienerHopf(dmin, dmax, n, device=local, max_batch=B)  # config.yml uses the same lag window
+        yfilt = torch.empty((B, n), dtype=torch.complex64, device=dev)
+        okflag = torch.zeros(B, dtype=torch.int32, device=dev)
+        hits = torch.zeros((B, 65536, 2), dtype=torch.float64, device=dev)  # 16-byte records
+        hitcnt = torch.zeros(B, dtype=torch.int32, device=dev)
+        L = blah2_amd.load()
     out = torch.zeros((B, nD, nC), dtype=torch.complex64, device=dev)
     met = torch.zeros((B, 2), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream()
@@ -135,7 +148,16 @@ def main():
 
     def step(i):
         r = i % ring
-        if a.fmt == "c32":
+        if wh is not None:
+            wh.process_dev(xs[r].data_ptr(), ys[r].data_ptr(), B, n, yfilt.data_ptr(), okflag.data_ptr(), st)
+            amb.process_dev(blah2_amd.FMT_C32, xs[r].data_ptr(), yfilt.data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
+            if a.cfar == "2d":
+                blah2_amd._lib.check(L.blah2hip_cfar2d_dev(amb._h, out.data_ptr(), met.data_ptr(), B, 1e-5, 2, 6, 1, 3, 5, 15.0,
+                                                           hits.data_ptr(), 65536, hitcnt.data_ptr(), st))
+            else:
+                blah2_amd._lib.check(L.blah2hip_cfar1d_dev(amb._h, out.data_ptr(), met.data_ptr(), B, 1e-5, 2, 6, 5, 15.0,
+                                                           hits.data_ptr(), 65536, hitcnt.data_ptr(), st))
+        elif a.fmt == "c32":
             amb.process_dev(blah2_amd.FMT_C32, xs[r].data_ptr(), ys[r].data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
         else:
             amb.process_dev(blah2_amd.FMT_I16, iqs[r].data_ptr(), 0, B, n, out.data_ptr(), met.data_ptr(), st)
@@ -202,8 +224,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: 2 MS/s, 1 s CPI, +-256 Hz -> {nD} Doppler x {nC} delay bins, "
-                                   f"synthetic {a.fmt} IQ resident in HBM" if a.config == "cfg2" else a.config,
+            "config": {"workload": (f"BASELINE configs[1]: 2 MS/s, 1 s CPI, +-256 Hz -> {nD} Doppler x {nC} delay bins, "
+                                    f"synthetic {a.fmt} IQ resident in HBM" if a.config == "cfg2" else a.config)
+                       + ("" if a.chain == "amb" else f" + clutter filter + {a.cfar} CA-CFAR"),
+                       "chain": a.chain,
                        "batch_cpis_per_step": B, "fmt": a.fmt, "n_samples": n, "fs": fs,
                        "n_doppler_bins": nD, "n_delay_bins": nC, "n_corr": amb.get_n_corr(),
                        "fft_len": amb.dims.fft_len, "n_seg": amb.dims.n_seg, "seg_len": amb.dims.seg_len,

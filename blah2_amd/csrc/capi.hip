@@ -802,7 +802,7 @@ int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
   int rc;
   if ((rc = tic(h, BLAH2HIP_K_CFAR, st))) return rc;
   hipLaunchKernelGGL(sat_rows_kernel, dim3(nD, n_cpi), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(sat_cols_kernel, dim3((nC + 255) / 256, n_cpi), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(sat_cols_kernel, dim3((nC + 63) / 64, n_cpi), dim3(64), 0, st, a);
   hipLaunchKernelGGL(cfar2d_kernel, dim3((nC + 255) / 256, nD, n_cpi), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
   if ((rc = toc(h, BLAH2HIP_K_CFAR, st))) return rc;

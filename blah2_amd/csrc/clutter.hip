@@ -56,7 +56,9 @@ struct CorrArgs {
   float scale;
 };
 
-// grid (nJobs, 2, nCpi): blockIdx.y = 0 -> r (window = xs), 1 -> b (window = y)
+// grid (nJobs, nCpi): per segment FFT(x' = zero-padded xs segment) ONCE, then the
+// xs window (-> r) and the y window (-> b) against it; both partial correlations
+// accumulate in registers across the workgroup's segments.
 template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_kernel(CorrArgs a)
 {
   using W = WgFft<R3>;
@@ -65,149 +67,192 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_ker
   cf *P = reinterpret_cast<cf *>(smem);
   cf *Q = P + W::A_ELEMS;
   const int t = threadIdx.x;
-  const int mode = blockIdx.y;
-  const int cpi = blockIdx.z;
+  const int cpi = blockIdx.y;
   const cf *X = a.x + (int64_t)cpi * a.cpiStride;
   const cf *Y = a.y + (int64_t)cpi * a.cpiStride;
   cf tw1[15], tw3[16];
   W::load_twiddles(t, a.tw, tw1, tw3);
 
-  cf acc[16];
+  cf accR[16], accB[16];
 #pragma unroll
-  for (int e = 0; e < 16; e++) acc[e] = cmake(0.f, 0.f);
+  for (int e = 0; e < 16; e++) { accR[e] = cmake(0.f, 0.f); accB[e] = cmake(0.f, 0.f); }
   for (int g = blockIdx.x; g < a.nSeg; g += a.nJobs) {
     const uint32_t n0 = (uint32_t)g * (uint32_t)a.segLen;
-    cf v[16], yv[16];
+    cf v[16], wv[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int m = t + T * k;
       const uint32_t n = n0 + (uint32_t)m;
-      const uint32_t nc = n < a.N ? n : a.N - 1;
-      const cf xv = X[xs_index(nc, a.dMinU32, a.N)];
-      v[k] = (m < a.segLen && n < a.N) ? xv : cmake(0.f, 0.f);
-      const uint32_t nw = n % a.N; // circular window
-      yv[k] = mode == 0 ? X[xs_index(nw, a.dMinU32, a.N)] : Y[nw];
+      const uint32_t nw = n % a.N; // circular window index
+      const cf xw = X[xs_index(nw, a.dMinU32, a.N)];
+      wv[k] = xw;                                                  // xs window (mode r)
+      v[k] = (m < a.segLen && n < a.N) ? xw : cmake(0.f, 0.f);     // x' = the same samples, cut to the segment
     }
     W::fwd_s1(t, v, tw1, P);
     __syncthreads();
     W::fwd_s2(t, v, P, Q);
     __syncthreads();
-    W::fwd_s3(t, v, tw3, Q);
-    W::fwd_s1(t, yv, tw1, P);
+    W::fwd_s3(t, v, tw3, Q); // v = X' spectrum
+    W::fwd_s1(t, wv, tw1, P);
     __syncthreads();
-    W::fwd_s2(t, yv, P, Q);
+    W::fwd_s2(t, wv, P, Q);
     __syncthreads();
-    W::fwd_s3(t, yv, tw3, Q);
+    W::fwd_s3(t, wv, tw3, Q);
 #pragma unroll
-    for (int e = 0; e < 16; e++) acc[e] = cmacc(acc[e], yv[e], v[e]);
+    for (int e = 0; e < 16; e++) accR[e] = cmacc(accR[e], wv[e], v[e]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) wv[k] = Y[(n0 + (uint32_t)(t + T * k)) % a.N]; // y window (mode b)
+    W::fwd_s1(t, wv, tw1, P);
+    __syncthreads();
+    W::fwd_s2(t, wv, P, Q);
+    __syncthreads();
+    W::fwd_s3(t, wv, tw3, Q);
+#pragma unroll
+    for (int e = 0; e < 16; e++) accB[e] = cmacc(accB[e], wv[e], v[e]);
     __syncthreads();
   }
-  W::inv_s1(t, acc, tw3, P);
-  __syncthreads();
-  W::inv_s2(t, acc, P, Q);
-  __syncthreads();
-  W::inv_s3(t, acc, tw1, Q);
-  cf *dst = a.partial + (((size_t)cpi * 2 + mode) * a.nJobs + blockIdx.x) * a.nBins;
+  // two explicit calls (a runtime-selected register array would be demoted to scratch)
+  auto finish = [&](cf *acc, int mode) {
+    W::inv_s1(t, acc, tw3, P);
+    __syncthreads();
+    W::inv_s2(t, acc, P, Q);
+    __syncthreads();
+    W::inv_s3(t, acc, tw1, Q);
+    cf *dst = a.partial + (((size_t)cpi * 2 + mode) * a.nJobs + blockIdx.x) * a.nBins;
 #pragma unroll
-  for (int c = 0; c < 16; c++) {
-    const int k = t + T * c;
-    if (k < a.nBins) dst[k] = cmake(acc[c].x * a.scale, acc[c].y * a.scale);
-  }
+    for (int c = 0; c < 16; c++) {
+      const int k = t + T * c;
+      if (k < a.nBins) dst[k] = cmake(acc[c].x * a.scale, acc[c].y * a.scale);
+    }
+    __syncthreads();
+  };
+  finish(accR, 0);
+  finish(accB, 1);
 }
 
-// ---- reduction of the partials (fp64) + Levinson solve, one workgroup/CPI ----
+// ---- reduction of the partials (fp64), then the Levinson solve ----------------
 struct SolveArgs {
   const cf *partial; // [nCpi][2][nJobs][nBins]
-  dcx *rb;           // [nCpi][2][nBins] scratch
+  dcx *rb;           // [nCpi][2][nBins]: r then b, fp64
   cf *w;             // [nCpi][nBins]
   int32_t *ok;       // [nCpi]
   int32_t nBins, nJobs;
 };
 
+// grid (ceil(nBins/256), 2, nCpi): fixed-order fp64 sum over the jobs
+__global__ __launch_bounds__(256) void clutter_reduce_kernel(SolveArgs a)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x, mode = blockIdx.y, cpi = blockIdx.z;
+  if (k >= a.nBins) return;
+  const cf *p = a.partial + ((size_t)cpi * 2 + mode) * a.nJobs * a.nBins + k;
+  // four interleaved accumulators: the loads of a group of 8 are independent (fixed order -> deterministic)
+  double sx[4] = {0, 0, 0, 0}, sy[4] = {0, 0, 0, 0};
+  int j = 0;
+  for (; j + 8 <= a.nJobs; j += 8) {
+    cf v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = p[(size_t)(j + u) * a.nBins];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { sx[u & 3] += (double)v[u].x; sy[u & 3] += (double)v[u].y; }
+  }
+  for (; j < a.nJobs; j++) { const cf v = p[(size_t)j * a.nBins]; sx[0] += (double)v.x; sy[0] += (double)v.y; }
+  a.rb[((size_t)cpi * 2 + mode) * a.nBins + k] = {(sx[0] + sx[1]) + (sx[2] + sx[3]), (sy[0] + sy[1]) + (sy[2] + sy[3])};
+}
+
 __device__ __forceinline__ dcx dmul(dcx a, dcx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 __device__ __forceinline__ dcx dconj(dcx a) { return {a.x, -a.y}; }
 
-__device__ dcx block_sum(dcx v, dcx *red)
+// Sum of a double over the 64 lanes of a wave, result uniform.  Row-wise
+// inclusive scan with DPP row_shr (full-rate VALU, no LDS crossbar), then the
+// four row totals are combined through v_readlane.
+template <int CTRL> __device__ __forceinline__ double dpp_shr_add(double v)
 {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+  v = dpp_shr_add<0x111>(v); // row_shr:1
+  v = dpp_shr_add<0x112>(v); // row_shr:2
+  v = dpp_shr_add<0x114>(v); // row_shr:4
+  v = dpp_shr_add<0x118>(v); // row_shr:8  -> lanes 15,31,47,63 hold their row's total
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  double tot = 0.0;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    v.x += __shfl_xor(v.x, off);
-    v.y += __shfl_xor(v.y, off);
-  }
-  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  __syncthreads(); // red[] may still be read from the previous call
-  if ((threadIdx.x & 63) == 0) red[wave] = v;
-  __syncthreads();
-  dcx s = {0.0, 0.0};
-  for (int w = 0; w < nw; w++) { s.x += red[w].x; s.y += red[w].y; }
-  return s;
+  for (int l = 15; l < 64; l += 16)
+    tot += __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
+  return tot;
 }
 
-__global__ __launch_bounds__(256) void clutter_solve_kernel(SolveArgs a)
+// Levinson recursion for the Hermitian Toeplitz system A w = b, A[i][j] = r[i-j]:
+//   f = forward vector (T_m f = e_1), x = running solution; per order m
+//     ef = sum_i r[m-i] f[i],  ex = sum_i r[m-i] x[i]
+//     f <- (f - ef * conj(rev f)) / (1 - |ef|^2)      (f[m] = 0 before)
+//     x <- x + (b[m] - ex) * conj(rev f)
+// The matrix is positive definite iff r[0] > 0 and every 1 - |ef|^2 > 0 -- the
+// condition under which the reference's chol() succeeds (WienerHopf.cpp:111).
+// ONE wave per CPI: the recursion is a chain of nBins dependent steps, so what
+// matters is the latency of a step; a single wave needs no barriers and reduces
+// with DPP.  All four vectors live in LDS.
+// (A fully unrolled variant with clamped unconditional LDS reads was measured
+// slower: it always touches 64*NPL elements, while the average order is n/2.)
+__global__ __launch_bounds__(64) void clutter_solve_kernel(SolveArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n = a.nBins;
-  dcx *f = reinterpret_cast<dcx *>(smem); // forward vector  (T_m f = e_1)
-  dcx *xv = f + n;                        // running solution
-  dcx *red = xv + n;                      // [8] reduction scratch, then 2 broadcast slots
-  const int cpi = blockIdx.x;
-  const int t = threadIdx.x, nt = blockDim.x;
-  dcx *r = a.rb + (size_t)cpi * 2 * n;
+  dcx *f = reinterpret_cast<dcx *>(smem);
+  dcx *xv = f + n;
+  dcx *r = xv + n;
   dcx *b = r + n;
-  for (int k = t; k < n; k += nt) {
-    dcx sr = {0.0, 0.0}, sb = {0.0, 0.0};
-    const cf *pr = a.partial + ((size_t)cpi * 2 + 0) * a.nJobs * n + k;
-    const cf *pb = a.partial + ((size_t)cpi * 2 + 1) * a.nJobs * n + k;
-    for (int j = 0; j < a.nJobs; j++) {
-      sr.x += (double)pr[(size_t)j * n].x; sr.y += (double)pr[(size_t)j * n].y;
-      sb.x += (double)pb[(size_t)j * n].x; sb.y += (double)pb[(size_t)j * n].y;
-    }
-    r[k] = sr;
-    b[k] = sb;
+  const int cpi = blockIdx.x;
+  const int t = threadIdx.x;
+  const dcx *rg = a.rb + (size_t)cpi * 2 * n;
+  for (int k = t; k < n; k += 64) {
+    r[k] = rg[k];
+    b[k] = rg[n + k];
     f[k] = {0.0, 0.0};
     xv[k] = {0.0, 0.0};
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   const double r0 = r[0].x;
-  bool ok = (r0 > 0.0) && isfinite(r0); // a zero/negative diagonal is not positive definite
+  bool ok = (r0 > 0.0) && isfinite(r0);
   if (ok && t == 0) {
     f[0] = {1.0 / r0, 0.0};
     xv[0] = {b[0].x / r0, b[0].y / r0};
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   for (int m = 1; m < n && ok; m++) {
-    // ef = sum_i r[m-i] f[i],  ex = sum_i r[m-i] x[i],  i < m
-    dcx ef = {0.0, 0.0}, ex = {0.0, 0.0};
-    for (int i = t; i < m; i += nt) {
+    double efx = 0.0, efy = 0.0, exx = 0.0, exy = 0.0;
+    for (int i = t; i < m; i += 64) {
       const dcx rr = r[m - i];
       const dcx p1 = dmul(rr, f[i]), p2 = dmul(rr, xv[i]);
-      ef.x += p1.x; ef.y += p1.y;
-      ex.x += p2.x; ex.y += p2.y;
+      efx += p1.x; efy += p1.y;
+      exx += p2.x; exy += p2.y;
     }
-    ef = block_sum(ef, red);
-    ex = block_sum(ex, red);
+    const dcx ef = {wave_sum(efx), wave_sum(efy)};
+    const dcx ex = {wave_sum(exx), wave_sum(exy)};
     const double denom = 1.0 - (ef.x * ef.x + ef.y * ef.y);
-    if (!(denom > 0.0) || !isfinite(denom)) { ok = false; break; } // uniform: every thread sees the same sums
-    // f_new[i] = (f[i] - ef*conj(f[m-i])) / denom, i = 0..m with f[m] = 0; pairs (i, m-i) are independent
+    if (!(denom > 0.0) || !isfinite(denom)) { ok = false; break; } // uniform
     const double inv = 1.0 / denom;
-    for (int i = t; 2 * i <= m; i += nt) {
+    // pairs (i, m-i) are independent; f[m] = 0 before the update
+    for (int i = t; 2 * i <= m; i += 64) {
       const int j = m - i;
       const dcx fi = f[i], fj = (j < m) ? f[j] : dcx{0.0, 0.0};
       const dcx ti = dmul(ef, dconj(fj)), tj = dmul(ef, dconj(fi));
       f[i] = {(fi.x - ti.x) * inv, (fi.y - ti.y) * inv};
       if (j != i) f[j] = {(fj.x - tj.x) * inv, (fj.y - tj.y) * inv};
     }
-    __syncthreads();
-    // x_new[i] = x[i] + (b[m] - ex) * conj(f_new[m-i]), i = 0..m with x[m] = 0
+    __builtin_amdgcn_wave_barrier();
     const dcx d = {b[m].x - ex.x, b[m].y - ex.y};
-    for (int i = t; i <= m; i += nt) {
-      const dcx g = dconj(f[m - i]);
-      const dcx p = dmul(d, g);
+    for (int i = t; i <= m; i += 64) {
+      const dcx p = dmul(d, dconj(f[m - i]));
       xv[i] = {xv[i].x + p.x, xv[i].y + p.y};
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
-  for (int k = t; k < n; k += nt) a.w[(size_t)cpi * n + k] = ok ? cmake((float)xv[k].x, (float)xv[k].y) : cmake(0.f, 0.f);
+  for (int k = t; k < n; k += 64) a.w[(size_t)cpi * n + k] = ok ? cmake((float)xv[k].x, (float)xv[k].y) : cmake(0.f, 0.f);
   if (t == 0) a.ok[cpi] = ok ? 1 : 0;
 }
 
@@ -360,13 +405,14 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   ca.x = x; ca.y = y; ca.cpiStride = stride; ca.N = h->N; ca.dMinU32 = dMinU32;
   ca.nBins = h->nBins; ca.segLen = h->segLen; ca.nSeg = h->nSeg; ca.nJobs = h->nJobs;
   ca.tw = h->d_tw; ca.partial = h->d_partial; ca.scale = 1.0f / (float)h->F;
-  hipLaunchKernelGGL(clutter_corr_kernel<R3>, dim3(h->nJobs, 2, nCpi), dim3(W::T), lds, st, ca);
+  hipLaunchKernelGGL(clutter_corr_kernel<R3>, dim3(h->nJobs, nCpi), dim3(W::T), lds, st, ca);
   CHIP(hipGetLastError());
 
   SolveArgs sa;
   sa.partial = h->d_partial; sa.rb = h->d_rb; sa.w = h->d_w; sa.ok = ok; sa.nBins = h->nBins; sa.nJobs = h->nJobs;
-  const size_t sl = ((size_t)2 * h->nBins + 16) * sizeof(dcx);
-  hipLaunchKernelGGL(clutter_solve_kernel, dim3(nCpi), dim3(256), sl, st, sa);
+  hipLaunchKernelGGL(clutter_reduce_kernel, dim3((h->nBins + 255) / 256, 2, nCpi), dim3(256), 0, st, sa);
+  const size_t sl = (size_t)4 * h->nBins * sizeof(dcx);
+  hipLaunchKernelGGL(clutter_solve_kernel, dim3(nCpi), dim3(64), sl, st, sa);
   CHIP(hipGetLastError());
 
   FirArgs fa;
@@ -406,12 +452,13 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
     if (forced && F != forced) continue;
     const int L = F - nBins + 1;
     if (L < 16) continue;
-    const double cost = (double)F * std::log2((double)F) / (double)L;
+    // measured per-point speed of the three transform kernels (tools/gpu_diag.py)
+    const double cost = (double)F * std::log2((double)F) / (double)L * (r3 == 16 ? 1.4 : (r3 == 4 ? 1.08 : 1.0));
     if (cost < best) { best = cost; bestR3 = r3; }
   }
   if (!bestR3) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip transform lengths (<= 4096)");
-  // the solve keeps two fp64 vectors of nBins in LDS
-  if (((size_t)2 * nBins + 16) * sizeof(dcx) > 160 * 1024 - 64)
+  // the solve keeps four fp64 vectors of nBins in LDS
+  if ((size_t)4 * nBins * sizeof(dcx) > 160 * 1024 - 64)
     CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip Toeplitz solve");
   auto *h = new blah2hip_clutter_s;
   h->device = device;
@@ -422,7 +469,7 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
   h->nSeg = (int)((n_samples + (uint32_t)h->segLen - 1) / (uint32_t)h->segLen);
   hipDeviceProp_t prop;
   CHIP(hipGetDeviceProperties(&prop, device));
-  h->nJobs = std::min(h->nSeg, 4 * prop.multiProcessorCount);
+  h->nJobs = std::min(h->nSeg, 2 * prop.multiProcessorCount); // partial correlations per CPI (x2 modes in one workgroup)
   h->firGrid = std::min(h->nSeg, 8 * prop.multiProcessorCount);
   CHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   std::vector<cf> tw(h->F);

@@ -612,16 +612,30 @@ __global__ __launch_bounds__(256) void sat_rows_kernel(Cfar2dArgs a)
   }
 }
 
-// column-wise running sum of the row prefixes -> summed-area table
-__global__ __launch_bounds__(256) void sat_cols_kernel(Cfar2dArgs a)
+// column-wise running sum of the row prefixes -> summed-area table.  One thread
+// per column; rows are taken 16 at a time so that 16 independent loads are in
+// flight before the (serial) running sum consumes them.
+__global__ __launch_bounds__(64) void sat_cols_kernel(Cfar2dArgs a)
 {
-  const int j = blockIdx.x * 256 + threadIdx.x, cpi = blockIdx.y;
+  const int j = blockIdx.x * 64 + threadIdx.x, cpi = blockIdx.y;
   if (j >= a.nDelay) return;
-  double *col = a.sat + (size_t)cpi * (a.nD + 1) * (a.nDelay + 1) + (j + 1);
+  const size_t W = (size_t)a.nDelay + 1;
+  double *col = a.sat + (size_t)cpi * (a.nD + 1) * W + (j + 1);
   double run = 0.0;
-  for (int i = 1; i <= a.nD; i++) {
-    run += col[(size_t)i * (a.nDelay + 1)];
-    col[(size_t)i * (a.nDelay + 1)] = run;
+  int i = 1;
+  for (; i + 15 <= a.nD; i += 16) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = col[(size_t)(i + k) * W];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      run += v[k];
+      col[(size_t)(i + k) * W] = run;
+    }
+  }
+  for (; i <= a.nD; i++) {
+    run += col[(size_t)i * W];
+    col[(size_t)i * W] = run;
   }
 }
 
