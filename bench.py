@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="CPIs per step (per GPU)")
+    ap.add_argument("--batch", type=int, default=32, help="CPIs per step (per GPU)")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--fmt", default="c32", choices=["c32", "i16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -26,8 +26,9 @@ DST = os.path.join(ROOT, "profiles")
 
 
 def short(name):
-    for k in ("range_kernel", "doppler_fft_kernel", "doppler_dft_kernel", "metrics_kernel", "cfar1d_kernel",
-              "rotate_kernel", "clutter_corr_kernel", "clutter_fir_kernel", "clutter_solve_kernel"):
+    for k in ("range_kernel", "doppler_tile_kernel", "doppler_fft_kernel", "doppler_dft_kernel", "metrics_kernel",
+              "cfar1d_kernel", "cfar2d_kernel", "sat_rows_kernel", "sat_cols_kernel", "rotate_kernel",
+              "clutter_corr_kernel", "clutter_fir_kernel", "clutter_solve_kernel", "clutter_reduce_kernel"):
         if k in name:
             return k
     return None
