@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--chain", default="amb", choices=["amb", "full"],
                     help="amb: range+Doppler+metrics (BASELINE headline); full: clutter filter + amb + CFAR (configs[2])")
     ap.add_argument("--cfar", default="2d", choices=["1d", "2d"])
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent CPI streams per GPU (engine handles on their own HIP streams); successive "
+                         "steps alternate between them so one batch's Doppler stage overlaps the next batch's range stage")
     a = ap.parse_args()
 
     import torch
@@ -114,7 +117,9 @@ def main():
     cfg = CONFIGS[a.config]
     dmin, dmax, fmin, fmax, fs, n = cfg
     B = a.batch
-    amb = blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B)
+    NS = max(1, a.streams) if a.chain == "amb" else 1
+    ambs = [blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B) for _ in range(NS)]
+    amb = ambs[0]
     nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
     cells = nD * nC
     s_in = 8 if a.fmt == "c32" else 4
@@ -141,10 +146,13 @@ def main():
         hits = torch.zeros((B, 65536, 2), dtype=torch.float64, device=dev)  # 16-byte records
         hitcnt = torch.zeros(B, dtype=torch.int32, device=dev)
         L = blah2_amd.load()
-    out = torch.zeros((B, nD, nC), dtype=torch.complex64, device=dev)
-    met = torch.zeros((B, 2), dtype=torch.float64, device=dev)
+    outs = [torch.zeros((B, nD, nC), dtype=torch.complex64, device=dev) for _ in range(NS)]
+    mets = [torch.zeros((B, 2), dtype=torch.float64, device=dev) for _ in range(NS)]
+    out, met = outs[0], mets[0]
     stream = torch.cuda.current_stream()
     st = stream.cuda_stream
+    side = [torch.cuda.Stream(device=dev) for _ in range(NS)] if NS > 1 else [stream]
+    sts = [s_.cuda_stream for s_ in side]
 
     def step(i):
         r = i % ring
@@ -158,9 +166,12 @@ def main():
                 blah2_amd._lib.check(L.blah2hip_cfar1d_dev(amb._h, out.data_ptr(), met.data_ptr(), B, 1e-5, 2, 6, 5, 15.0,
                                                            hits.data_ptr(), 65536, hitcnt.data_ptr(), st))
         elif a.fmt == "c32":
-            amb.process_dev(blah2_amd.FMT_C32, xs[r].data_ptr(), ys[r].data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
+            q = i % NS
+            ambs[q].process_dev(blah2_amd.FMT_C32, xs[r].data_ptr(), ys[r].data_ptr(), B, n, outs[q].data_ptr(),
+                                mets[q].data_ptr(), sts[q])
         else:
-            amb.process_dev(blah2_amd.FMT_I16, iqs[r].data_ptr(), 0, B, n, out.data_ptr(), met.data_ptr(), st)
+            q = i % NS
+            ambs[q].process_dev(blah2_amd.FMT_I16, iqs[r].data_ptr(), 0, B, n, outs[q].data_ptr(), mets[q].data_ptr(), sts[q])
 
     def sync():
         torch.cuda.synchronize()
@@ -183,12 +194,16 @@ def main():
 
     # second, identical region with every kernel bracketed by HIP events on the
     # launch stream: per-kernel durations for the roofline line
-    amb.set_timing(True)
+    for h_ in ambs:
+        h_.set_timing(True)
     for i in range(a.steps):
         step(a.warmup + i)
     torch.cuda.synchronize()
-    kt = amb.get_timing()
-    amb.set_timing(False)
+    kt = {}
+    for h_ in ambs:
+        for k_, (ms_, n_) in h_.get_timing().items():
+            kt[k_] = (kt.get(k_, (0.0, 0))[0] + ms_, kt.get(k_, (0.0, 0))[1] + n_)
+        h_.set_timing(False)
     range_ms, range_n = kt["range"]
     avg_range_s = (range_ms / max(range_n, 1)) * 1e-3
     # algorithmic bytes per launch of the range kernel: every input
@@ -231,7 +246,7 @@ def main():
                        "batch_cpis_per_step": B, "fmt": a.fmt, "n_samples": n, "fs": fs,
                        "n_doppler_bins": nD, "n_delay_bins": nC, "n_corr": amb.get_n_corr(),
                        "fft_len": amb.dims.fft_len, "n_seg": amb.dims.n_seg, "seg_len": amb.dims.seg_len,
-                       "ring_batches": ring, "sharding": f"{world} independent CPI streams, one per GPU"},
+                       "ring_batches": ring, "streams_per_gpu": NS, "sharding": f"{world} independent CPI streams, one per GPU"},
             "cells_per_s": total_cpis * cells / elapsed,
             "us_per_cpi": elapsed / (B * a.steps) * 1e6,
             "outputs_valid": ok,
