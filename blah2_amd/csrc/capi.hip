@@ -153,7 +153,7 @@ bool choose_plan(blah2hip_amb_s *h)
     const int segLen = (nCorr + nSeg - 1) / nSeg;
     // measured on MI355X (tools/gpu_diag.py): at equal butterfly count the one-wave
     // F = 1024 transform is ~8 % slower per point than the multi-wave ones
-    const double cost = (2.0 * nSeg + 1.0) * F * std::log2((double)F) * (r3 == 4 ? 1.08 : 1.0);
+    const double cost = (2.0 * nSeg + 1.0) * F * std::log2((double)F) * (r3 == 4 ? 1.05 : 1.0);
     if (cost < best) {
       best = cost;
       found = true;
@@ -277,8 +277,38 @@ template <int R3, class In> int launch_range_t(blah2hip_amb_s *h, const RangeArg
   return BLAH2HIP_OK;
 }
 
+template <int R4, class In> int launch_range8_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
+{
+  using W = WgFft8<R4>;
+  const size_t lds = (size_t)2 * W::BUF_ELEMS * sizeof(cf);
+  void (*kern)(RangeArgs, In) = range8_kernel<R4, In>;
+  static thread_local const void *configured = nullptr;
+  if (configured != (const void *)kern) {
+    HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = (const void *)kern;
+  }
+  int perCU = std::max(1, std::min((int)((160 * 1024) / lds), 32 / (W::T / 64)));
+  int cap = perCU * h->numCU;
+  if (const char *e = std::getenv("BLAH2HIP_RANGE_GRID")) cap = std::max(1, std::atoi(e));
+  const int grid = std::min<int>(a.nPulses, cap);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(W::T), lds, st, a, in);
+  HIPCHK(hipGetLastError());
+  return BLAH2HIP_OK;
+}
+
 template <class In> int launch_range(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
 {
+  // 8-points-per-thread transform (4 waves/SIMD) vs 16-points-per-thread (2 waves/SIMD)
+  // Measured (tools/gpu_diag.py, cfg 2): F=1024: 10.5 (E8) vs 14.3 us/CPI (E16); F=2048: 10.3 vs 10.0;
+  // F=4096: equal.  Default: E8 only for the one-wave F=1024 case; BLAH2HIP_RANGE_E8=0/1 forces.
+  static const int e8 = [] { const char *e = std::getenv("BLAH2HIP_RANGE_E8"); return e ? std::atoi(e) : -1; }();
+  if (e8 == 1 || (e8 < 0 && h->r3 == 4)) {
+    switch (h->r3) {
+    case 4: return launch_range8_t<2>(h, a, in, st);
+    case 8: return launch_range8_t<4>(h, a, in, st);
+    default: return launch_range8_t<8>(h, a, in, st);
+    }
+  }
   switch (h->r3) {
   case 4: return launch_range_t<4>(h, a, in, st);
   case 8: return launch_range_t<8>(h, a, in, st);

@@ -13,6 +13,7 @@
 
 #include "blah2hip.h"
 #include "range_core.hpp"
+#include "fft_wg8.hpp"
 
 namespace blah2 {
 
@@ -114,6 +115,78 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
     W::template inv_s3<M>(t, acc, tw1, Q);
     store_lags<R3>(a.out, p, cpi, i, t, acc);
     __syncthreads(); // Q is rewritten by the next pulse
+  }
+}
+
+// --------------------------------------------------------------------------
+// Range kernel on the 8-points-per-thread transform (fft_wg8.hpp): identical
+// mathematics and interface, T = F/8 threads per pulse (4 waves for F = 2048),
+// ~half the registers per thread -> 4 waves per SIMD.  The x and y transforms of a
+// segment run one after the other and alternate their starting exchange buffer
+// (x: A,B,A  y: B,A,B), so a buffer is never rewritten before the barrier that
+// follows its last read: 3 barriers per transform and none in between.
+template <int R4, class In>
+__global__ __launch_bounds__(64 * R4, 4) void range8_kernel(RangeArgs a, In in)
+{
+  using W = WgFft8<R4>;
+  constexpr int T = W::T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf *A = reinterpret_cast<cf *>(smem);
+  cf *B = A + W::BUF_ELEMS;
+  const int t = threadIdx.x;
+  cf tw1[7], tw2[7], tw3[7];
+  W::load_twiddles(t, a.tw, tw1, tw2, tw3);
+
+  const RangePlan p = a.plan;
+  for (int pulse = blockIdx.x; pulse < a.nPulses; pulse += gridDim.x) {
+    const int cpi = pulse / p.nDoppler;
+    const int i = pulse - cpi * p.nDoppler;
+    const int64_t base = (int64_t)cpi * a.cpiStride + (int64_t)i * p.nCorr;
+    cf acc[8];
+    for (int s = 0; s < p.nSeg; s++) {
+      cf v[8], yv[8];
+      load_seg_x_g<T, 8>(in, p, base, s, t, v);
+      load_seg_y_g<T, 8>(in, p, base, s, t, yv);
+      mask_seg_x_g<T, 8>(p, s, t, v);
+      W::fwd_s1(t, v, tw1, A);
+      __syncthreads();
+      W::fwd_s2_load(t, v, A);
+      W::fwd_s2_store(t, v, tw2, B);
+      __syncthreads();
+      W::fwd_s3_load(t, v, B);
+      W::fwd_s3_store(t, v, tw3, A);
+      __syncthreads();
+      W::fwd_s4(t, v, A); // v = X spectrum
+
+      mask_seg_y_g<T, 8>(p, s, t, yv);
+      W::fwd_s1(t, yv, tw1, B);
+      __syncthreads();
+      W::fwd_s2_load(t, yv, B);
+      W::fwd_s2_store(t, yv, tw2, A);
+      __syncthreads();
+      W::fwd_s3_load(t, yv, A);
+      W::fwd_s3_store(t, yv, tw3, B);
+      __syncthreads();
+      W::fwd_s4(t, yv, B); // yv = Y spectrum
+      if (s == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = cmulc(yv[e], v[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = cmacc(acc[e], yv[e], v[e]);
+      }
+    }
+    W::inv_s4(t, acc, A);
+    __syncthreads();
+    W::inv_s3_load(t, acc, tw3, A);
+    W::inv_s3_store(t, acc, B);
+    __syncthreads();
+    W::inv_s2_load(t, acc, tw2, B);
+    W::inv_s2_store(t, acc, A);
+    __syncthreads();
+    W::inv_s1(t, acc, tw1, A);
+    store_lags_g<T, 8>(a.out, p, cpi, i, t, acc);
+    __syncthreads(); // A is rewritten by the next pulse's first stage
   }
 }
 

@@ -8,6 +8,7 @@
 //   emulate_fft range R3 nCorr nD dMin dMax nSeg segLen seed
 //                                          -> prints max rel error vs the direct definition
 #include "../../blah2_amd/csrc/range_core.hpp"
+#include "../../blah2_amd/csrc/fft_wg8.hpp"
 
 #include <cmath>
 #include <complex>
@@ -100,6 +101,61 @@ template <int R3> int test_fft()
   return (err / peak < 2e-6 && ierr < 2e-6) ? 0 : 1;
 }
 
+// 8-points-per-thread, four-stage transform (fft_wg8.hpp)
+template <int R4> int test_fft8()
+{
+  using W = WgFft8<R4>;
+  constexpr int T = W::T, F = W::F;
+  std::mt19937 gen(4321 + R4);
+  std::uniform_real_distribution<float> dist(-1.f, 1.f);
+  std::vector<cf> in(F), tw(F);
+  for (auto &c : in) c = cmake(dist(gen), dist(gen));
+  for (int k = 0; k < F; k++) { double a = -2.0 * M_PI * k / F; tw[k] = cmake((float)std::cos(a), (float)std::sin(a)); }
+  std::vector<cf> v(T * 8), tw1(T * 7), tw2(T * 7), tw3(T * 7), A(W::BUF_ELEMS), B(W::BUF_ELEMS);
+  for (int t = 0; t < T; t++) {
+    W::load_twiddles(t, tw.data(), &tw1[t * 7], &tw2[t * 7], &tw3[t * 7]);
+    for (int k = 0; k < 8; k++) v[t * 8 + k] = in[t + T * k];
+  }
+  for (int t = 0; t < T; t++) W::fwd_s1(t, &v[t * 8], &tw1[t * 7], A.data());
+  for (int t = 0; t < T; t++) { W::fwd_s2_load(t, &v[t * 8], A.data()); W::fwd_s2_store(t, &v[t * 8], &tw2[t * 7], B.data()); }
+  for (int t = 0; t < T; t++) { W::fwd_s3_load(t, &v[t * 8], B.data()); W::fwd_s3_store(t, &v[t * 8], &tw3[t * 7], A.data()); }
+  for (int t = 0; t < T; t++) W::fwd_s4(t, &v[t * 8], A.data());
+  std::vector<cd> X(F);
+  for (int m = 0; m < F; m++) {
+    cd acc = 0;
+    for (int n = 0; n < F; n++) {
+      double a = -2.0 * M_PI * (double)(((long)m * n) % F) / F;
+      acc += cd(in[n].x, in[n].y) * cd(std::cos(a), std::sin(a));
+    }
+    X[m] = acc;
+  }
+  double peak = 0, err = 0;
+  for (auto &c : X) peak = std::max(peak, std::abs(c));
+  for (int t = 0; t < T; t++)
+    for (int j = 0; j < W::NP; j++)
+      for (int q4 = 0; q4 < R4; q4++) {
+        const int rho = t + T * j, q12 = rho % 64, q3 = rho / 64;
+        const int m = (q12 / 8) + 8 * (q12 % 8) + 64 * q3 + 512 * q4;
+        const cf g = v[t * 8 + j * R4 + q4];
+        err = std::max(err, std::abs(cd(g.x, g.y) - X[m]));
+      }
+  for (int t = 0; t < T; t++) W::inv_s4(t, &v[t * 8], A.data());
+  for (int t = 0; t < T; t++) { W::inv_s3_load(t, &v[t * 8], &tw3[t * 7], A.data()); }
+  for (int t = 0; t < T; t++) { W::inv_s3_store(t, &v[t * 8], B.data()); }
+  for (int t = 0; t < T; t++) { W::inv_s2_load(t, &v[t * 8], &tw2[t * 7], B.data()); }
+  for (int t = 0; t < T; t++) { W::inv_s2_store(t, &v[t * 8], A.data()); }
+  for (int t = 0; t < T; t++) W::inv_s1(t, &v[t * 8], &tw1[t * 7], A.data());
+  double ierr = 0;
+  for (int t = 0; t < T; t++)
+    for (int c = 0; c < 8; c++) {
+      const cf g = v[t * 8 + c];
+      const cf e = in[t + T * c];
+      ierr = std::max(ierr, (double)std::abs(cd(g.x / F - e.x, g.y / F - e.y)));
+    }
+  std::printf("E8 R4=%d F=%d fwd_rel_err=%.3e inv_abs_err=%.3e\n", R4, F, err / peak, ierr);
+  return (err / peak < 2e-6 && ierr < 2e-6) ? 0 : 1;
+}
+
 template <int R3>
 int test_range(int nCorr, int nD, int dMin, int dMax, int nSeg, int segLen, unsigned seed)
 {
@@ -180,7 +236,7 @@ int test_range(int nCorr, int nD, int dMin, int dMax, int nSeg, int segLen, unsi
 int main(int argc, char **argv)
 {
   if (argc >= 2 && !std::strcmp(argv[1], "fft"))
-    return test_fft<4>() | test_fft<8>() | test_fft<16>();
+    return test_fft<4>() | test_fft<8>() | test_fft<16>() | test_fft8<2>() | test_fft8<4>() | test_fft8<8>();
   if (argc >= 10 && !std::strcmp(argv[1], "range")) {
     const int R3 = std::atoi(argv[2]);
     const int a[7] = {std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]),

@@ -17,8 +17,10 @@ def emu(tmp_path_factory):
 
 
 def test_workgroup_fft_forward_inverse(emu):
+    # both transform families: 16 points/thread (16x16xR3) and 8 points/thread (8x8x8xR4)
     out = subprocess.run([emu, "fft"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("E8 R4=") == 3 and out.stdout.count("R3=") == 3
 
 
 # (R3, nCorr, nDoppler, delayMin, delayMax, nSeg, segLen)
