@@ -1,0 +1,84 @@
+"""GPU: edge geometries of the ambiguity engine against the fp64 oracle: tiny
+pulses, one-sided lag windows at the limits the reference allows
+(Ambiguity.cpp:132-146 needs delayMin <= 1 and delayMax >= -1), ragged tails,
+lag windows that force every transform length, and the documented limits."""
+import numpy as np
+import pytest
+
+from oracle import blah2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def b2(built_lib):
+    import blah2_amd
+    assert blah2_amd.device_count() > 0
+    return blah2_amd
+
+
+def run(b2, args, seed=0, quantise=True):
+    dmin, dmax, fmin, fmax, fs, n, rh = args
+    x, y = O.synth_iq(n, seed=seed, fs=fs, targets=((max(dmin, 0) + 1, 0.3 * fmax, 0.1),), quantise=quantise)
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, rh)
+    d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, rh)
+    assert (amb.get_n_doppler_bins(), amb.get_n_delay_bins(), amb.get_n_corr(), amb.get_nfft()) == \
+        (d.n_doppler_bins, d.n_delay_bins, d.n_corr, d.nfft)
+    m = amb.process(x, y)
+    ref = O.ambiguity_process(d, x, y)
+    err = np.abs(m.data.astype(np.complex128) - ref)
+    assert err.max() / np.abs(ref).max() <= 1e-5, err.max() / np.abs(ref).max()
+    noise, mx = O.map_metrics(ref)
+    assert abs(m.noisePower - noise) <= 1e-3 and abs(m.maxPower - mx) <= 1e-3
+    return amb
+
+
+@pytest.mark.parametrize("args", [
+    (-1, 1, -2, 2, 1000, 1000, False),          # smallest lag window the reference allows, 5 pulses of 200
+    (1, 60, -5, 5, 10_000, 10_000, True),       # delayMin = +1: positive lags only
+    (-60, -1, -5, 5, 10_000, 10_000, True),     # delayMax = -1: negative lags only
+    (0, 0 + 300, -3, 3, 20_000, 19_997, True),  # ragged: n not a multiple of anything
+    (-10, 400, -1, 1, 2_000_000, 2_000_000, True),    # 3 pulses of 666 666 samples: nCorr > uint16 -> wraps like the reference
+    (-5, 1500, -20, 20, 1_000_000, 500_000, True),   # nDelay = 1506 -> F = 2048 or 4096
+    (-100, 3000, -10, 10, 1_000_000, 1_000_000, True),  # nDelay = 3101 -> only F = 4096 fits
+    (-10, 100, -7, 30, 100_000, 100_000, True),      # asymmetric Doppler window -> rotate kernel
+])
+def test_geometries(b2, args):
+    dmin, dmax, fmin, fmax, fs, n, rh = args
+    d = O.ambiguity_dims(*args)
+    if d.n_corr == 0:
+        with pytest.raises(b2.Blah2HipError):
+            b2.Ambiguity(*args)
+        return
+    run(b2, args, seed=abs(dmin) + dmax)
+
+
+def test_doppler_transform_lengths(b2):
+    # nDoppler = 2*floor(fMax*n/fs)+1: exercise 3, 65, 513 (M = 1024 boundary), 515 (first M = 2048), 1025
+    for fmax, n, fs in [(1, 100_000, 100_000), (32, 200_000, 200_000), (256, 400_000, 400_000),
+                        (257, 400_000, 400_000), (512, 800_000, 800_000)]:
+        amb = run(b2, (-4, 40, -fmax, fmax, fs, n, True), seed=fmax)
+        assert amb.get_n_doppler_bins() == 2 * fmax + 1
+
+
+def test_unsupported_geometries_fail_loudly(b2):
+    # lag window wider than the largest on-chip transform
+    with pytest.raises(b2.Blah2HipError) as e:
+        b2.Ambiguity(-100, 4200, -10, 10, 1_000_000, 1_000_000, True)
+    assert e.value.code == -3
+    # outside the range where the reference's own lag gather is in bounds
+    with pytest.raises(b2.Blah2HipError):
+        b2.Ambiguity(5, 100, -10, 10, 1_000_000, 1_000_000, True)
+    with pytest.raises(b2.Blah2HipError):
+        b2.Ambiguity(-10, 100, 10, -10, 1_000_000, 1_000_000, True)
+
+
+def test_zero_cells_poison_the_mean_like_the_reference(b2):
+    # an all-zero surveillance channel gives |z| = 0 cells: 10*log10(0) = -inf and
+    # Map::set_metrics' mean becomes -inf (Map.cpp:187-206 has no guard)
+    n, fs = 20_000, 200_000
+    amb = b2.Ambiguity(-3, 20, -50, 50, fs, n, True)
+    x = np.ones(n, dtype=np.complex128)
+    m = amb.process(x, np.zeros(n, dtype=np.complex128))
+    assert np.all(m.data == 0)
+    assert m.noisePower == -np.inf
