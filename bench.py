@@ -109,7 +109,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):  # under torchrun, also at N = 1
         import torch.distributed as dist_
         dist = dist_
         dist.init_process_group("nccl", device_id=dev)
