@@ -372,6 +372,7 @@ __global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a)
 {
   using W = WgFft<4>;
   constexpr int T = 64;
+  constexpr int NR = 9; // nD <= 513: rows t + 64*k, k < 9, are the only ones that exist
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf *lds = reinterpret_cast<cf *>(smem);
   const int tid = threadIdx.x;
@@ -381,32 +382,50 @@ __global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a)
   constexpr int SH = (NCOL == 16) ? 4 : 3;
   const int sub = blockIdx.x, cpi = blockIdx.y; // sub-tile of NCOL columns
   const int col0 = sub * NCOL;
-  const int col = col0 + w;
-  const bool colok = col < a.nDelay;
   cf *region = lds + w * DOPT_PITCH;
 
-  cf tw1[15], tw3[16];
-  W::load_twiddles(t, a.tw, tw1, tw3);
-
-  // phase 1: coalesced tile read, transposed into the per-column regions
+  // phase 1: coalesced tile read (all loads in flight before the first use),
+  // transposed into the per-column regions
   const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, col0);
   const int cells = nD * NCOL;
-  for (int idx = tid; idx < cells; idx += NT) {
+  cf v[16];
+#pragma unroll
+  for (int j = 0; j < NR; j++) {
+    const int idx = tid + NT * j;
     const int c = idx & (NCOL - 1), row = idx >> SH;
-    lds[c * DOPT_PITCH + row] = Rt[row * 16 + c];
+    v[j] = Rt[idx < cells ? row * 16 + c : 0];
   }
+  // tables while the tile is in flight; the kernel spectrum goes to LDS (16 more
+  // live registers would serialise its 16 loads behind one another)
+  cf *bfL = lds + NCOL * DOPT_PITCH;
+  cf bfs[1024 / NT];
+#pragma unroll
+  for (int j = 0; j < 1024 / NT; j++) bfs[j] = a.bf[tid + NT * j];
+  cf tw1[15], tw3[16], ch[NR];
+  W::load_twiddles(t, a.tw, tw1, tw3);
+#pragma unroll
+  for (int k = 0; k < NR; k++) ch[k] = a.chirp[min(t + T * k, nD - 1)];
+#pragma unroll
+  for (int j = 0; j < NR; j++) {
+    const int idx = tid + NT * j;
+    const int c = idx & (NCOL - 1), row = idx >> SH;
+    if (idx < cells) lds[c * DOPT_PITCH + row] = v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 1024 / NT; j++) bfL[tid + NT * j] = bfs[j];
   __syncthreads();
 
   // phase 2: this wave's column -> registers (DC removal + chirp), then the transform
   const cf r0 = region[0];
-  cf ch[16], v[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
+  for (int k = 0; k < NR; k++) {
     const int i = t + T * k;
-    ch[k] = a.chirp[i < nD ? i : 0];
-    const cf rv = region[i < nD ? i : 0];
-    v[k] = (i < nD) ? cmul(csub(rv, r0), ch[k]) : cmake(0.f, 0.f);
+    const cf rv = region[min(i, nD - 1)];
+    const cf p = cmul(csub(rv, r0), ch[k]);
+    v[k] = cmake(i < nD ? p.x : 0.f, i < nD ? p.y : 0.f);
   }
+#pragma unroll
+  for (int k = NR; k < 16; k++) v[k] = cmake(0.f, 0.f);
   // from here on `region` is this wave's private exchange buffer (A and B alias:
   // a single wave's LDS operations execute in order)
   // __builtin_amdgcn_wave_barrier(): no instruction, only stops the compiler from
@@ -421,7 +440,7 @@ __global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a)
   __builtin_amdgcn_wave_barrier();
   W::fwd_s3(t, v, tw3, region);
 #pragma unroll
-  for (int e = 0; e < 16; e++) v[e] = cmul(v[e], a.bf[e * T + t]);
+  for (int e = 0; e < 16; e++) v[e] = cmul(v[e], bfL[e * T + t]);
   __builtin_amdgcn_wave_barrier();
   W::inv_s1(t, v, tw3, region);
   __builtin_amdgcn_wave_barrier();
@@ -435,15 +454,13 @@ __global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a)
 
   // phase 3: rotate rows by nD/2+1 and park the column back in its region
 #pragma unroll
-  for (int c = 0; c < 16; c++) {
+  for (int c = 0; c < NR; c++) {
     const int k = t + T * c;
-    if (k < nD) {
-      cf d = cmul(v[c], ch[c]);
-      if (k == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
-      int o = k - (nD / 2 + 1);
-      if (o < 0) o += nD;
-      region[o] = d;
-    }
+    cf d = cmul(v[c], ch[c]);
+    if (c == 0 && t == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
+    int o = k - (nD / 2 + 1);
+    if (o < 0) o += nD;
+    if (k < nD) region[o] = d;
   }
   __syncthreads();
 
@@ -452,17 +469,17 @@ __global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a)
   float lmax = 0.f;
   cf *mapb = a.map + (size_t)cpi * nD * a.nDelay + col0;
   const int ncol = min(NCOL, a.nDelay - col0);
-  for (int idx = tid; idx < cells; idx += NT) {
+#pragma unroll
+  for (int j = 0; j < NR; j++) {
+    const int idx = tid + NT * j;
     const int c = idx & (NCOL - 1), o = idx >> SH;
-    if (c < ncol) {
-      const cf d = lds[c * DOPT_PITCH + o];
-      mapb[(size_t)o * a.nDelay + c] = d;
-      const float db = db_of(d);
-      lsum += (double)db;
-      lmax = fmaxf(lmax, db);
-    }
+    const bool ok = idx < cells && c < ncol;
+    const cf d = lds[c * DOPT_PITCH + min(o, nD - 1)];
+    if (ok) mapb[(size_t)o * a.nDelay + c] = d;
+    const float db = db_of(d);
+    lsum += ok ? (double)db : 0.0;
+    lmax = ok ? fmaxf(lmax, db) : lmax;
   }
-  (void)colok;
   const size_t part = (size_t)cpi * gridDim.x + blockIdx.x;
   __shared__ double wsum[16];
   __shared__ float wmax[16];
