@@ -86,7 +86,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="CPIs per step (per GPU)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="CPIs per step (per GPU); default 128 for the 2 MS/s configs (4 GB of IQ per step: a pulse is "
+                         "the scheduling unit of the range kernel and 128 x 513 pulses leave a 1.5 %% tail on 1024 "
+                         "resident workgroups, 32 x 513 leave 6 %%), 8 for cfg3")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--fmt", default="c32", choices=["c32", "i16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -116,7 +119,7 @@ def main():
 
     cfg = CONFIGS[a.config]
     dmin, dmax, fmin, fmax, fs, n = cfg
-    B = a.batch
+    B = a.batch if a.batch > 0 else (8 if a.config == "cfg3" else 128)
     NS = max(1, a.streams) if a.chain == "amb" else 1
     ambs = [blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B) for _ in range(NS)]
     amb = ambs[0]
@@ -129,7 +132,10 @@ def main():
     ring = max(2, -(-int(600e6) // bytes_per_batch))
     xs, ys, iqs = [], [], []
     for r in range(ring):
-        x, y = synth_batch(torch, B, n, 1000 + 17 * rank + r, fs, dev)
+        parts = [synth_batch(torch, min(16, B - c0), n, 1000 + 17 * rank + 131 * r + c0, fs, dev) for c0 in range(0, B, 16)]
+        x = torch.cat([p_[0] for p_ in parts])
+        y = torch.cat([p_[1] for p_ in parts])
+        del parts
         if a.fmt == "c32":
             xs.append(x)
             ys.append(y)
@@ -228,6 +234,26 @@ def main():
         except Exception:
             continue
 
+    # device-copy ceiling beside the 8 TB/s spec figure: a 1 GiB
+    # device-to-device copy, read + written bytes per second
+    src_ = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    dst_ = torch.empty_like(src_)
+    for _ in range(3):
+        dst_.copy_(src_)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        dst_.copy_(src_)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 10 * 2 * src_.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src_, dst_
+    # reference-formulation flops per CPI (5 n log2 n per FFT, 3 nfft-point FFTs
+    # per pulse + one nD-point FFT per delay column) -- what the CPU path would execute
+    import math
+    nfft_ref = amb.get_nfft()
+    ref_flops = 3 * nD * 5 * nfft_ref * math.log2(nfft_ref) + nC * 5 * nD * math.log2(nD)
+
     # sanity: the timed outputs are real (metrics of the last batch are finite, target visible)
     mt = met.cpu().numpy()
     ok = bool((mt == mt).all() and (mt[:, 1] > 0).all())
@@ -253,6 +279,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "range_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes,
+                         "copy_ceiling": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
+                         "chain_achieved": (2 * n * s_in + cells * 8) * total_cpis / world / elapsed / 1e9,
+                         "ref_equivalent_tflops": ref_flops * total_cpis / world / elapsed / 1e12,
                          "avg_launch_us": avg_range_s * 1e6, "launches_timed": range_n,
                          "kernel_us_per_step": {k: v[0] / max(v[1], 1) * 1e3 for k, v in kt.items() if v[1]},
                          "chain_us_per_step": chain_s * 1e6},

@@ -1,5 +1,2 @@
-P='import json,sys; d=json.loads(sys.stdin.readline()); print(d["value"], d["config"]["fft_len"], d["config"]["n_seg"], d["roofline"]["kernel_us_per_step"])'
-python bench.py --no-cpu-baseline | python -c "$P"
-BLAH2HIP_FFT_LEN=1024 python bench.py --no-cpu-baseline | python -c "$P"
-BLAH2HIP_FFT_LEN=4096 python bench.py --no-cpu-baseline | python -c "$P"
-BLAH2HIP_RANGE_E8=1 python bench.py --no-cpu-baseline | python -c "$P"
+P='import json,sys; d=json.loads(sys.stdin.readline()); print(d["config"]["batch_cpis_per_step"], d["value"], d["roofline"]["frac"], d["roofline"]["kernel_us_per_step"])'
+for b in 16 32 33 63 64 95 127 128; do python bench.py --no-cpu-baseline --batch $b --steps 20 | python -c "$P"; done
