@@ -249,9 +249,6 @@ template <int R3, class In> int launch_range_t(blah2hip_amb_s *h, const RangeArg
   // x/y transforms interleaved between barriers: +3..6 % for F <= 2048 (measured), neutral at 4096
   static const bool ilv = [] { const char *e = std::getenv("BLAH2HIP_RANGE_ILV"); return e ? std::atoi(e) != 0 : (R3 <= 8); }();
   void (*kern)(RangeArgs, In) = ilv ? range_kernel<R3, In, true> : range_kernel<R3, In, false>;
-  // software-pipelined loads (next segment requested before this one's butterflies)
-  static const bool pf = [] { const char *e = std::getenv("BLAH2HIP_RANGE_PF"); return e ? std::atoi(e) != 0 : false; }();
-  if (pf && R3 <= 8) kern = range_pf_kernel<R3, In>;
 #ifdef BLAH2HIP_ABLATE
   // profiling build only (tools/gpu_ablate.py; results are wrong by construction):
   // bit0 arithmetic, bit1 LDS, bit2 loads

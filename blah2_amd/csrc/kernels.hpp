@@ -119,85 +119,6 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
 }
 
 // --------------------------------------------------------------------------
-// Software-pipelined form of range_kernel<R3, In, true>: the raw samples of the
-// NEXT segment (or of the next pulse's first segment) are requested before the
-// current segment's butterflies start and are converted only when their turn
-// comes, so an HBM round trip is hidden behind ~4000 VALU instructions instead
-// of being waited for at the top of every segment.  LDS allows 2 waves per SIMD
-// for this kernel, i.e. 256 VGPRs per thread, of which range_kernel uses 120:
-// the 32 extra 8-byte registers are free.
-template <int R3, class In>
-__global__ __launch_bounds__(16 * R3, 2) void range_pf_kernel(RangeArgs a, In in)
-{
-  using W = WgFft<R3>;
-  using raw = typename In::raw;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  cf *P = reinterpret_cast<cf *>(smem);
-  cf *Q = P + W::A_ELEMS;
-  const int t = threadIdx.x;
-  const RangePlan p = a.plan;
-  int pulse = blockIdx.x;
-  if (pulse >= a.nPulses) return;
-
-  raw xr[16], yr[16];
-  {
-    const int cpi = pulse / p.nDoppler;
-    load_seg_raw<R3>(in, p, (int64_t)cpi * a.cpiStride + (int64_t)(pulse - cpi * p.nDoppler) * p.nCorr, 0, t, xr, yr);
-  }
-  cf tw1[15], tw3[16];
-  W::load_twiddles(t, a.tw, tw1, tw3);
-
-  for (; pulse < a.nPulses; pulse += gridDim.x) {
-    const int cpi = pulse / p.nDoppler;
-    const int i = pulse - cpi * p.nDoppler;
-    cf acc[16];
-    for (int s = 0; s < p.nSeg; s++) {
-      cf v[16], yv[16];
-#pragma unroll
-      for (int k = 0; k < 16; k++) { v[k] = In::cvt(xr[k]); yv[k] = In::cvt(yr[k]); }
-      {
-        // what comes after (pulse, s); past the end the last pulse is simply re-read
-        int ns = s + 1, np = pulse;
-        if (ns == p.nSeg) { ns = 0; np = pulse + (int)gridDim.x; }
-        if (np >= a.nPulses) { np = pulse; ns = s; }
-        const int ncpi = np / p.nDoppler;
-        load_seg_raw<R3>(in, p, (int64_t)ncpi * a.cpiStride + (int64_t)(np - ncpi * p.nDoppler) * p.nCorr, ns, t, xr, yr);
-      }
-      mask_seg_x<R3>(p, s, t, v);
-      mask_seg_y<R3>(p, s, t, yv);
-      W::fwd_s1(t, v, tw1, P);
-      W::fwd_s1(t, yv, tw1, Q);
-      __syncthreads();
-      W::fwd_s2_load(t, v, P);
-      W::fwd_s2_load(t, yv, Q);
-      dft16<-1>(v);
-      dft16<-1>(yv);
-      __syncthreads();
-      W::fwd_s2_store(t, v, P);
-      W::fwd_s2_store(t, yv, Q);
-      __syncthreads();
-      W::fwd_s3(t, v, tw3, P);
-      W::fwd_s3(t, yv, tw3, Q);
-      if (s == 0) {
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[e] = cmulc(yv[e], v[e]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[e] = cmacc(acc[e], yv[e], v[e]);
-      }
-      __syncthreads();
-    }
-    W::inv_s1(t, acc, tw3, P);
-    __syncthreads();
-    W::inv_s2(t, acc, P, Q);
-    __syncthreads();
-    W::inv_s3(t, acc, tw1, Q);
-    store_lags<R3>(a.out, p, cpi, i, t, acc);
-    __syncthreads();
-  }
-}
-
-// --------------------------------------------------------------------------
 // Range kernel on the 8-points-per-thread transform (fft_wg8.hpp): identical
 // mathematics and interface, T = F/8 threads per pulse (4 waves for F = 2048),
 // ~half the registers per thread -> 4 waves per SIMD.  The x and y transforms of a

@@ -45,13 +45,6 @@ struct InC32 {
   const cf *y;
   B2_HD cf lx(int64_t i) const { return x[i]; }
   B2_HD cf ly(int64_t i) const { return y[i]; }
-  // raw form: what a load leaves in registers, converted at first use (so that a
-  // prefetch can stay in flight across the previous segment's butterflies)
-  using raw = cf;
-  static constexpr int RSTRIDE = 1; // raw words per sample
-  B2_HD const raw *px(int64_t base) const { return x + base; }
-  B2_HD const raw *py(int64_t base) const { return y + base; }
-  B2_HD static cf cvt(raw r) { return r; }
 };
 
 // .rspduo wire layout: int16 I1 Q1 I2 Q2 per sample pair
@@ -60,11 +53,6 @@ struct InI16 {
   const int16_t *iq;
   B2_HD cf lx(int64_t i) const { return cmake((float)iq[4 * i], (float)iq[4 * i + 1]); }
   B2_HD cf ly(int64_t i) const { return cmake((float)iq[4 * i + 2], (float)iq[4 * i + 3]); }
-  using raw = uint32_t; // I | Q << 16
-  static constexpr int RSTRIDE = 2; // raw words per sample
-  B2_HD const raw *px(int64_t base) const { return reinterpret_cast<const uint32_t *>(iq) + 2 * base; }
-  B2_HD const raw *py(int64_t base) const { return reinterpret_cast<const uint32_t *>(iq) + 2 * base + 1; }
-  B2_HD static cf cvt(raw r) { return cmake((float)(int16_t)(r & 0xffffu), (float)(int16_t)(r >> 16)); }
 };
 
 // Loads are branch-free: the index is clamped into the pulse, all loads of a thread
@@ -82,39 +70,8 @@ struct InF16 {
   const _Float16 *y;
   B2_HD cf lx(int64_t i) const { return cmake((float)x[2 * i], (float)x[2 * i + 1]); }
   B2_HD cf ly(int64_t i) const { return cmake((float)y[2 * i], (float)y[2 * i + 1]); }
-  using raw = uint32_t; // two halves
-  static constexpr int RSTRIDE = 1;
-  B2_HD const raw *px(int64_t base) const { return reinterpret_cast<const uint32_t *>(x) + base; }
-  B2_HD const raw *py(int64_t base) const { return reinterpret_cast<const uint32_t *>(y) + base; }
-  B2_HD static cf cvt(raw r)
-  {
-    return cmake((float)__builtin_bit_cast(_Float16, (uint16_t)(r & 0xffffu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(r >> 16)));
-  }
 };
 #endif
-
-// raw (unconverted, unmasked) loads of segment s of the pulse at pulseBase
-template <int R3, class In>
-B2_HD void load_seg_raw(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, typename In::raw *xr, typename In::raw *yr)
-{
-  constexpr int T = 16 * R3;
-  const int sx = s * p.segLen + t;
-  const int sy = sx + p.delayMin;
-  // wave-uniform base pointer + unsigned 32-bit lane offset: one address register per load
-  const typename In::raw *xb = in.px(pulseBase);
-  const typename In::raw *yb = in.py(pulseBase);
-  const int last = p.nCorr - 1;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int idx = sx + T * k;
-    xr[k] = xb[(uint32_t)(In::RSTRIDE * (idx < last ? idx : last))];
-  }
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int idx = sy + T * k;
-    yr[k] = yb[(uint32_t)(In::RSTRIDE * (idx < 0 ? 0 : (idx < last ? idx : last)))];
-  }
-}
 
 template <int R3, class In>
 B2_HD void load_seg_x(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, cf *v)
