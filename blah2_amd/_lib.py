@@ -65,6 +65,12 @@ SYMBOLS = {
     "blah2hip_clutter_process_c64": (C.c_int, [_vp, _vp, _vp, _u32, _vp, C.POINTER(C.c_int)]),
     "blah2hip_clutter_process_c32": (C.c_int, [_vp, _vp, _vp, _u32, _vp, C.POINTER(C.c_int)]),
     "blah2hip_clutter_process_dev": (C.c_int, [_vp, _vp, _vp, _u32, C.c_uint64, _vp, _vp, _vp]),
+    "blah2hip_spectrum_create": (C.c_int, [_u32, C.c_double, C.c_int, _u32, C.POINTER(_vp)]),
+    "blah2hip_spectrum_destroy": (C.c_int, [_vp]),
+    "blah2hip_spectrum_get_dims": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.c_uint64)]),
+    "blah2hip_spectrum_process_c64": (C.c_int, [_vp, _vp, _u32, _vp]),
+    "blah2hip_spectrum_process_c32": (C.c_int, [_vp, _vp, _u32, _vp]),
+    "blah2hip_spectrum_process_dev": (C.c_int, [_vp, C.c_int, _vp, _u32, C.c_uint64, _vp, _vp]),
     "blah2hip_amb_set_timing": (C.c_int, [_vp, C.c_int]),
     "blah2hip_amb_get_timing": (C.c_int, [_vp, _vp, _vp]),
 }

@@ -35,6 +35,10 @@ public:
   // extension used by the GPU classes: move up to `count` front samples into
   // a contiguous interleaved (re,im) buffer; throws like pop_front on underflow.
   void pop_front_block(double *dst, uint32_t count);
+  // extension: read back what update_spectrum / update_frequency stored (the
+  // reference only exposes them through to_json)
+  const std::vector<std::complex<double>> &get_spectrum() const { return spectrum; }
+  const std::vector<double> &get_frequency() const { return frequency; }
 
 private:
   uint32_t n;

@@ -1,0 +1,41 @@
+#include "process/spectrum/SpectrumAnalyser.h"
+
+#include "blah2hip.h"
+#include "process/ambiguity/Ambiguity.h"
+
+#include <stdexcept>
+#include <string>
+
+SpectrumAnalyser::SpectrumAnalyser(uint32_t _n, double _bandwidth) : n(_n), bandwidth(_bandwidth)
+{
+  if (blah2hip_spectrum_create(n, bandwidth, Ambiguity::default_device(), 1, &engine) != BLAH2HIP_OK)
+    throw std::runtime_error(std::string("SpectrumAnalyser: ") + blah2hip_last_error());
+  blah2hip_spectrum_get_dims(engine, &decimation, &nSpectrum, &nfft);
+  bufX.resize(2 * (size_t)nfft);
+  bufS.resize(2 * (size_t)nSpectrum);
+}
+
+SpectrumAnalyser::~SpectrumAnalyser() { blah2hip_spectrum_destroy(engine); }
+
+void SpectrumAnalyser::process(IqData *x)
+{
+  // SpectrumAnalyser.cpp:33-37: a copy of the FIFO, first nfft entries
+  const std::deque<std::complex<double>> data = x->get_data();
+  if (data.size() < nfft) throw std::runtime_error("SpectrumAnalyser::process: fewer samples than nfft in the buffer");
+  for (uint64_t i = 0; i < nfft; i++) { bufX[2 * i] = data[i].real(); bufX[2 * i + 1] = data[i].imag(); }
+  if (blah2hip_spectrum_process_c64(engine, bufX.data(), (uint32_t)nfft, bufS.data()) != BLAH2HIP_OK)
+    throw std::runtime_error(std::string("SpectrumAnalyser::process: ") + blah2hip_last_error());
+  std::vector<std::complex<double>> spectrum(nSpectrum);
+  for (uint32_t k = 0; k < nSpectrum; k++) spectrum[k] = {bufS[2 * k], bufS[2 * k + 1]};
+  x->update_spectrum(spectrum);
+
+  // SpectrumAnalyser.cpp:57-68.  The loop counter is a uint32_t, so the start value
+  // -nSpectrum/2 is (2^32 - nSpectrum)/2 and the body never runs: the frequency axis
+  // the reference publishes is empty.  Same arithmetic here, on purpose.
+  std::vector<double> frequency;
+  double offset = 0;
+  if (decimation % 2 == 0) offset = bandwidth / 2;
+  for (uint32_t i = -nSpectrum / 2; i < nSpectrum / 2; i++)
+    frequency.push_back(((i * bandwidth) + offset + 204640000) / 1000);
+  x->update_frequency(frequency);
+}

@@ -8,6 +8,7 @@
 #include "data/Map.h"
 #include "process/ambiguity/Ambiguity.h"
 #include "process/clutter/WienerHopf.h"
+#include "process/spectrum/SpectrumAnalyser.h"
 #include "process/detection/Centroid.h"
 #include "process/detection/CfarDetector1D.h"
 #include "process/detection/Interpolate.h"
@@ -84,6 +85,24 @@ int main()
       t += std::complex<double>(0.1 * g(gen), 0.1 * g(gen));
       x.push_back(xs[i]);
       y.push_back({std::round(t.real()), std::round(t.imag())});
+    }
+    // blah2.cpp:264: spectrum of the reference channel, x is not consumed; a few
+    // bins against the defining sum  X[(k*D + nfft/2 + 1) mod nfft]
+    {
+      SpectrumAnalyser spectrumAnalyser(n, 2000);
+      spectrumAnalyser.process(&x);
+      CHECK(x.get_length() == n);
+      const std::string sj = x.to_json(42);
+      CHECK(sj.find("\"frequency\":[],\"spectrum\":[") != std::string::npos); // the axis the reference emits is empty
+      const uint32_t D = 100, nS = 2000, N = 200000;
+      std::vector<std::complex<double>> got = x.get_spectrum();
+      CHECK(got.size() == nS);
+      for (uint32_t k : {0u, 1u, 999u, 1000u, 1999u}) {
+        const uint64_t bin = ((uint64_t)k * D + N / 2 + 1) % N;
+        std::complex<double> acc = 0;
+        for (uint32_t i = 0; i < N; i++) acc += xs[i] * std::exp(std::complex<double>(0, -2 * M_PI * (double)((bin * i) % N) / N));
+        CHECK(got.size() == nS && std::abs(got[k] - acc) <= 1e-9 * std::sqrt((double)N) * 300.0 * 1e3);
+      }
     }
     WienerHopf filter(-10, 100, n);
     Ambiguity ambiguity(-10, 100, -100, 100, fsl, n, true);

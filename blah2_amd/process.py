@@ -314,6 +314,49 @@ class WienerHopf:
         check(self._L.blah2hip_clutter_process_dev(self._h, d_x, d_y, n_cpi, cpi_stride, d_y_out, d_ok, stream))
 
 
+class SpectrumAnalyser:
+    """src/process/spectrum/SpectrumAnalyser.h:53-62: decimated spectrum of the
+    reference channel.  ``process(x)`` returns ``(spectrum, frequency)``: the
+    nSpectrum complex values the reference hands to ``IqData::update_spectrum``
+    (SpectrumAnalyser.cpp:43-55) and the frequency axis it hands to
+    ``update_frequency``, which is always empty (the axis loop runs on a uint32
+    that starts at (2^32 - nSpectrum)/2, :64)."""
+
+    def __init__(self, n, bandwidth, device=0, max_batch=1):
+        L = _lib.load()
+        h = C.c_void_p()
+        check(L.blah2hip_spectrum_create(n, float(bandwidth), device, max_batch, C.byref(h)))
+        self._h, self._L = h, L
+        d, ns, nfft = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        check(L.blah2hip_spectrum_get_dims(h, C.byref(d), C.byref(ns), C.byref(nfft)))
+        self.decimation, self.nSpectrum, self.nfft = d.value, ns.value, nfft.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.blah2hip_spectrum_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process(self, x):
+        x = np.ascontiguousarray(x)
+        out = np.empty(self.nSpectrum, dtype=np.complex128)
+        if x.dtype == np.complex64:
+            check(self._L.blah2hip_spectrum_process_c32(self._h, _ptr(x), x.shape[0], _ptr(out)))
+        else:
+            x = x.astype(np.complex128, copy=False)
+            check(self._L.blah2hip_spectrum_process_c64(self._h, _ptr(x), x.shape[0], _ptr(out)))
+        return out, np.empty(0, dtype=np.float64)
+
+    def process_dev(self, fmt, d_x, n_cpi, cpi_stride, d_out, stream=0):
+        """Enqueue on ``stream``; d_out is [n_cpi][nSpectrum] complex128 in HBM."""
+        check(self._L.blah2hip_spectrum_process_dev(self._h, fmt, d_x, n_cpi, cpi_stride, d_out, stream))
+
+
 def next_hamming(v: int) -> int:
     """src/process/meta/HammingNumber.cpp:38-48."""
     return int(_lib.load().blah2hip_next_hamming(v))

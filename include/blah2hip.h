@@ -58,6 +58,7 @@ extern "C" {
 
 typedef struct blah2hip_amb_s *blah2hip_amb_t;
 typedef struct blah2hip_clutter_s *blah2hip_clutter_t;
+typedef struct blah2hip_spectrum_s *blah2hip_spectrum_t;
 
 /* Derived sizes: the first block reproduces the reference constructor
  * (Ambiguity.cpp:22-65) and is what its getters return; the second block is
@@ -190,6 +191,25 @@ int blah2hip_clutter_process_c32(blah2hip_clutter_t h, const float *x, const flo
 int blah2hip_clutter_process_dev(blah2hip_clutter_t h, const void *d_x, const void *d_y,
                                  uint32_t n_cpi, uint64_t cpi_stride, void *d_y_out, int32_t *d_ok,
                                  void *stream);
+
+/* ---- SpectrumAnalyser (SpectrumAnalyser.h:53-62, called blah2.cpp:264) ----
+ * decimation = uint32(n/bandwidth), nSpectrum = n/decimation, nfft = nSpectrum*decimation
+ * (SpectrumAnalyser.cpp:16-18); spectrum[k] = FFT_nfft(x)[(k*decimation + nfft/2 + 1) mod nfft]
+ * (:33-54).  Output: nSpectrum complex fp64 values (re, im interleaved) per CPI.
+ * Fails with ERR_INVALID when n < bandwidth (the reference divides by zero) and
+ * ERR_UNSUPPORTED when nSpectrum > 4096. */
+int blah2hip_spectrum_create(uint32_t n_samples, double bandwidth, int device, uint32_t max_batch,
+                             blah2hip_spectrum_t *out);
+int blah2hip_spectrum_destroy(blah2hip_spectrum_t h);
+int blah2hip_spectrum_get_dims(blah2hip_spectrum_t h, uint32_t *decimation, uint32_t *n_spectrum, uint64_t *nfft);
+/* host: the first nfft of the n samples of the reference channel are used (:33-37) */
+int blah2hip_spectrum_process_c64(blah2hip_spectrum_t h, const double *x, uint32_t n, double *spectrum_out);
+int blah2hip_spectrum_process_c32(blah2hip_spectrum_t h, const float *x, uint32_t n, double *spectrum_out);
+/* dev: d_x in format fmt (C32: complex fp32 plane; I16: the interleaved .rspduo
+ * buffer, tuner 1 is used; F16: half pairs), d_out [n_cpi][nSpectrum] complex fp64.
+ * Enqueues only. */
+int blah2hip_spectrum_process_dev(blah2hip_spectrum_t h, int fmt, const void *d_x, uint32_t n_cpi,
+                                  uint64_t cpi_stride, double *d_out, void *stream);
 
 /* ---- per-kernel timing (HIP events on the launch stream) ---------------- */
 #define BLAH2HIP_K_RANGE 0

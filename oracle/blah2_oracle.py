@@ -309,6 +309,30 @@ def cfar2d(m, delay_axis, doppler_axis, noise_power, pfa, ng_d, nt_d, ng_f, nt_f
 
 
 # --------------------------------------------------------------------------
+def spectrum_dims(n, bandwidth):
+    """``SpectrumAnalyser::SpectrumAnalyser`` (src/process/spectrum/SpectrumAnalyser.cpp:9-24):
+    (decimation, nSpectrum, nfft); decimation is the double quotient truncated to uint32."""
+    decimation = int(n / float(bandwidth))  # :16
+    n_spectrum = n // decimation            # :17
+    return decimation, n_spectrum, n_spectrum * decimation  # :18
+
+
+def spectrum_process(x, n, bandwidth):
+    """``SpectrumAnalyser::process`` (SpectrumAnalyser.cpp:31-71): returns
+    (spectrum, frequency).  spectrum[k] = FFT(x[:nfft])[(k*decimation + nfft//2 + 1) % nfft]
+    (:43-54).  The frequency loop's uint32 counter starts at (2^32 - nSpectrum)//2
+    (``-nSpectrum/2`` on an unsigned), which is never < nSpectrum//2: the axis is empty (:64)."""
+    decimation, n_spectrum, nfft = spectrum_dims(n, bandwidth)
+    X = _fft.fft(np.asarray(x, dtype=np.complex128)[:nfft])
+    i = np.arange(0, nfft, decimation, dtype=np.int64)
+    spectrum = X[(i + nfft // 2 + 1) % nfft]
+    frequency = np.empty(0, dtype=np.float64)
+    start = ((1 << 32) - n_spectrum) // 2
+    assert not start < n_spectrum // 2
+    return spectrum, frequency
+
+
+# --------------------------------------------------------------------------
 def wiener_hopf(x, y, delay_min, delay_max):
     """``WienerHopf::process`` (src/process/clutter/WienerHopf.cpp:58-163).
 

@@ -46,6 +46,9 @@ def lib():
                                  C.c_int, C.c_double, C.c_int, _dp, _dp, _dp, C.c_int64]
         L.ref_wiener_process.restype = C.c_int
         L.ref_wiener_process.argtypes = [C.c_int32, C.c_int32, C.c_uint32, _dp, _dp, _dp, _dp]
+        if hasattr(L, "ref_spectrum_process"):
+            L.ref_spectrum_process.restype = C.c_int
+            L.ref_spectrum_process.argtypes = [C.c_uint32, C.c_double, _dp, _dp, C.c_uint32, C.POINTER(C.c_uint32)]
         _lib = L
     return _lib
 
@@ -121,3 +124,12 @@ def wiener_hopf(x, y, delay_min, delay_max):
                                   _p(y.view(np.float64)), _p(out.view(np.float64)),
                                   C.cast(C.pointer(secs), _dp))
     return bool(ok), (out if ok else y.copy()), secs.value
+
+
+def spectrum(x, n, bandwidth, cap=1 << 16):
+    """The reference ``SpectrumAnalyser(n, bandwidth).process`` -> (spectrum, n_frequency)."""
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    out = np.zeros(cap, dtype=np.complex128)
+    nf = C.c_uint32(0)
+    m = lib().ref_spectrum_process(n, float(bandwidth), _p(x.view(np.float64)), _p(out.view(np.float64)), cap, C.byref(nf))
+    return out[:m].copy(), nf.value

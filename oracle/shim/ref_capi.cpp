@@ -8,6 +8,10 @@
 
 #include "process/ambiguity/Ambiguity.h"
 #include "process/clutter/WienerHopf.h"
+#include "process/spectrum/SpectrumAnalyser.h"
+
+extern std::vector<std::complex<double>> g_ref_last_spectrum;
+extern std::vector<double> g_ref_last_frequency;
 #include "process/detection/Centroid.h"
 #include "process/detection/CfarDetector1D.h"
 #include "process/detection/Interpolate.h"
@@ -140,6 +144,25 @@ int ref_wiener_process(int32_t dMin, int32_t dMax, uint32_t n, const double *x, 
     for (uint32_t i = 0; i < n && i < d.size(); i++) { y_out[2 * i] = d[i].real(); y_out[2 * i + 1] = d[i].imag(); }
   }
   return ok ? 1 : 0;
+}
+
+// SpectrumAnalyser(n, bandwidth).process(x): writes up to cap spectrum values
+// (re, im) and returns their count; *n_frequency = length of the frequency axis
+// the reference produced.
+int ref_spectrum_process(uint32_t n, double bandwidth, const double *x, double *spectrum_out, uint32_t cap,
+                         uint32_t *n_frequency)
+{
+  SpectrumAnalyser sa(n, bandwidth);
+  IqData qx(n);
+  fill(qx, x, n);
+  sa.process(&qx);
+  const uint32_t m = (uint32_t)g_ref_last_spectrum.size();
+  for (uint32_t i = 0; i < m && i < cap; i++) {
+    spectrum_out[2 * i] = g_ref_last_spectrum[i].real();
+    spectrum_out[2 * i + 1] = g_ref_last_spectrum[i].imag();
+  }
+  if (n_frequency) *n_frequency = (uint32_t)g_ref_last_frequency.size();
+  return (int)m;
 }
 
 } // extern "C"

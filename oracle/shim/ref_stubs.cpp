@@ -44,6 +44,14 @@ std::complex<double> IqData::pop_front()
 
 void IqData::clear() { data->clear(); }
 
+// IqData.cpp:83-91.  The members are private and only reachable through to_json
+// (rapidjson), so the last values handed over are also kept where ref_capi.cpp can
+// read them back.
+std::vector<std::complex<double>> g_ref_last_spectrum;
+std::vector<double> g_ref_last_frequency;
+void IqData::update_spectrum(std::vector<std::complex<double>> s) { spectrum = s; g_ref_last_spectrum = s; }
+void IqData::update_frequency(std::vector<double> f) { frequency = f; g_ref_last_frequency = f; }
+
 // ---------------------------------------------------------------- Map<T> --
 // rows = Doppler, cols = delay; cells start at 1 (Map.cpp:18)
 template <class T>

@@ -34,6 +34,13 @@ CASES = {
                ((37, -63.0, 0.05), (80, 30.0, 0.03)), (-10, 100)),
     "delay_pos_only": (200_000, 30_000, 0, 40, -30, 30, True, 15, ((20, 10.0, 0.05),), (0, 40)),
 }
+# name -> (n, bandwidth, seed)
+SPECTRUM_CASES = {
+    "ragged_odd_decimation": (30_011, 2000.0, 21),     # D = 15, nS = 2000, nfft = 30000 < n
+    "odd_nfft": (44_000, 2001.0, 22),                  # D = 21, nS = 2095, nfft = 43995 (odd)
+    "even_decimation_odd_bins": (45_122, 2000.0, 23), # D = 22, nS = 2051: bins congruent to D/2+1 mod D
+    "small": (5_000, 400.0, 24),                       # D = 12, nS = 416
+}
 DET = dict(pfa=1e-5, n_guard=2, n_train=6, min_delay=5, min_doppler=15.0, n_centroid=6)
 
 
@@ -59,9 +66,11 @@ def main():
         m2, _, _, noise2, peak2, _ = amb2.process(x, yf)
         det_chain = amb2.detect(DET["pfa"], DET["n_guard"], DET["n_train"], DET["min_delay"],
                                 DET["min_doppler"], stage=0)
+        # SpectrumAnalyser on the reference channel with the bandwidth blah2.cpp:198 hard-codes
+        spec, n_freq = R.spectrum(x, n, 2000.0)
         out = os.path.join(HERE, name + ".npz")
         np.savez_compressed(
-            out, iq=iq,
+            out, iq=iq, spectrum=spec, spectrum_n_frequency=np.int64(n_freq),
             params=np.array([fs, n, dmin, dmax, fmin, fmax, int(rh)], dtype=np.int64),
             dims=np.array([amb.n_doppler_bins, amb.n_delay_bins, amb.n_corr, amb.nfft], dtype=np.int64),
             cpi=np.float64(amb.cpi), doppler_middle=np.float64(amb.doppler_middle),
@@ -75,6 +84,19 @@ def main():
         print(f"{name}: nD={amb.n_doppler_bins} nDelay={amb.n_delay_bins} nCorr={amb.n_corr} "
               f"nfft={amb.nfft} cfar={det0[0].size} centroid={det1[0].size} interp={det2[0].size} "
               f"clutter_ok={ok} chain_cfar={det_chain[0].size} -> {os.path.getsize(out)/1024:.0f} KiB")
+    # SpectrumAnalyser geometries the capture fixtures do not reach: nfft < n, odd
+    # decimation, odd nfft, nSpectrum != 2000
+    os.makedirs(os.path.join(HERE, "spectrum"), exist_ok=True)
+    for name, (n, bw, seed) in SPECTRUM_CASES.items():
+        x, _ = O.synth_iq(n, seed=seed, fs=2_000_000)
+        spec, n_freq = R.spectrum(x, n, bw)
+        iq = np.empty((n, 2), dtype=np.int16)
+        iq[:, 0], iq[:, 1] = x.real, x.imag
+        out = os.path.join(HERE, "spectrum", name + ".npz")
+        np.savez_compressed(out, iq=iq, params=np.array([n, bw], dtype=np.float64), spectrum=spec,
+                            n_frequency=np.int64(n_freq))
+        print(f"spectrum/{name}: n={n} bw={bw} dims={O.spectrum_dims(n, bw)} nFrequency={n_freq} "
+              f"-> {os.path.getsize(out)/1024:.0f} KiB")
 
 
 if __name__ == "__main__":

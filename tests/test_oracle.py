@@ -120,3 +120,29 @@ def test_compiled_reference_live_matches_fixture_and_kats():
     m, delay, doppler, noise, mx, left = a.process(g["x"], g["y"])
     assert np.array_equal(m, g["map"])
     assert noise == g["metrics"][0] and mx == g["metrics"][1]
+
+
+# ---- SpectrumAnalyser (SpectrumAnalyser.cpp:9-71) ------------------------------------
+def test_spectrum_restatement_matches_compiled_reference_fixtures():
+    import os
+    from conftest import GOLDEN
+    for name in golden_names():
+        g = load_golden(name)
+        n = int(g["params"][1])
+        spec, freq = O.spectrum_process(g["x"], n, 2000)
+        assert freq.size == int(g["spectrum_n_frequency"]) == 0
+        assert np.max(np.abs(spec - g["spectrum"])) <= 1e-12 * np.max(np.abs(g["spectrum"]))
+    for f in sorted(os.listdir(os.path.join(GOLDEN, "spectrum"))):
+        z = np.load(os.path.join(GOLDEN, "spectrum", f))
+        n, bw = int(z["params"][0]), float(z["params"][1])
+        x = z["iq"][:, 0].astype(np.float64) + 1j * z["iq"][:, 1].astype(np.float64)
+        spec, freq = O.spectrum_process(x, n, bw)
+        assert spec.size == O.spectrum_dims(n, bw)[1] == z["spectrum"].size
+        assert np.max(np.abs(spec - z["spectrum"])) <= 1e-12 * np.max(np.abs(z["spectrum"]))
+
+
+def test_spectrum_dims_of_the_shipped_configurations():
+    # blah2.cpp:198-199: bandwidth 2000 on nSamples = fs * tCpi
+    assert O.spectrum_dims(2_000_000, 2000) == (1000, 2000, 2_000_000)
+    assert O.spectrum_dims(1_500_000, 2000) == (750, 2000, 1_500_000)
+    assert O.spectrum_dims(999_999, 2000) == (499, 2004, 999_996)
