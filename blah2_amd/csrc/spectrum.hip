@@ -17,8 +17,9 @@
 //   u[p]       = W_N^(p*c) * sum_j x[p + nS*j] * W_D^(j*c)
 //   spectrum[k] = X[((k + hq) mod nS)*D + c]
 // i.e. one pass over the samples (spectrum_fold_kernel, HBM-bound: N*8 bytes
-// read once, coalesced along p) and an nS-point DFT of the folded sequence
-// (spectrum_dft_kernel; nS ~ 2000, direct evaluation from an exact root table).
+// read once, coalesced along p), a small reduction (spectrum_reduce_kernel) and an
+// nS-point DFT of the folded sequence (spectrum_dft_kernel; nS ~ 2000, direct
+// evaluation from an exact root table).
 // Everything after the sample load is fp64: the result is the reference's up to
 // fp64 rounding of a differently-ordered sum (the IQ samples are int16-valued, so
 // their fp32 storage is exact).
@@ -44,6 +45,7 @@ struct SpecArgs {
   const dcx *wD;    // exp(-2 pi i m / D), m in [0, D)
   const dcx *wS;    // exp(-2 pi i m / nS), m in [0, nS)
   dcx *part;        // [nCpi][nJ][nS] partial folds
+  dcx *u;           // [nCpi][nS] folded sequence
   dcx *out;         // [nCpi][nS]
   int64_t cpiStride;
   uint32_t D, nS, c, hq, nJ;
@@ -88,41 +90,69 @@ __global__ __launch_bounds__(64 * FOLD_WAVES) void spectrum_fold_kernel(SpecArgs
   }
 }
 
-// grid (ceil(nS/256), nCpi), 256 threads, dynamic LDS 2*nS*16 bytes: the block
-// rebuilds u[] (chunk sum in index order, times W_N^(p*c) evaluated in fp64 from the
-// exactly reduced phase) and the root table in LDS, then one output bin per thread.
-__global__ __launch_bounds__(256) void spectrum_dft_kernel(SpecArgs a)
+// grid (ceil(nS/256), nCpi): u[p] = W_N^(p*c) * (chunk sums in index order); the
+// phase is reduced exactly in integers and evaluated in fp64.
+__global__ __launch_bounds__(256) void spectrum_reduce_kernel(SpecArgs a)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t cpi = blockIdx.y;
+  if (p >= a.nS) return;
+  const dcx *part = a.part + (size_t)cpi * a.nJ * a.nS;
+  dcx s = dmake(0.0, 0.0);
+  for (uint32_t q = 0; q < a.nJ; q++) { const dcx v = part[(size_t)q * a.nS + p]; s.x += v.x; s.y += v.y; }
+  const uint64_t ph = ((uint64_t)p * a.c) % a.N;
+  double sn, cs;
+  sincospi(-2.0 * (double)ph / (double)a.N, &sn, &cs);
+  a.u[(size_t)cpi * a.nS + p] = dmul(s, dmake(cs, sn));
+}
+
+// nS-point DFT of u, direct from the exact root table: grid (ceil(nS/32), nCpi),
+// 256 threads = 32 output bins x 8 slices of the input index (p = slice, slice+8, ...),
+// u and the roots staged in LDS (2*nS*16 bytes), slices folded with DPP-free
+// shuffles at the end.  2000^2 complex fp64 MACs per CPI: ~1 us of fp64 vector rate,
+// the point of the layout is to keep the serial chain per thread at nS/8 steps.
+constexpr int DFT_SLICES = 8;
+constexpr int DFT_BINS = 32;
+
+__global__ __launch_bounds__(DFT_SLICES * DFT_BINS) void spectrum_dft_kernel(SpecArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   dcx *u = reinterpret_cast<dcx *>(smem);
   dcx *w = u + a.nS;
   const uint32_t cpi = blockIdx.y;
-  const dcx *part = a.part + (size_t)cpi * a.nJ * a.nS;
+  const dcx *ug = a.u + (size_t)cpi * a.nS;
   for (uint32_t p = threadIdx.x; p < a.nS; p += blockDim.x) {
-    dcx s = dmake(0.0, 0.0);
-    for (uint32_t q = 0; q < a.nJ; q++) { const dcx v = part[(size_t)q * a.nS + p]; s.x += v.x; s.y += v.y; }
-    const uint64_t ph = ((uint64_t)p * a.c) % a.N;
-    double sn, cs;
-    sincospi(-2.0 * (double)ph / (double)a.N, &sn, &cs);
-    u[p] = dmul(s, dmake(cs, sn));
+    u[p] = ug[p];
     w[p] = a.wS[p];
   }
   __syncthreads();
-  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= a.nS) return;
+  // lanes of a wave: 8 bins x 8 slices, slices in the low bits so that the fold is
+  // three xor-shuffles inside a wave
+  const uint32_t slice = threadIdx.x & (DFT_SLICES - 1);
+  const uint32_t m = blockIdx.x * DFT_BINS + (threadIdx.x >> 3);
+  const uint32_t mm = m < a.nS ? m : 0;
   dcx acc = dmake(0.0, 0.0);
-  uint32_t idx = 0;
-  for (uint32_t p = 0; p < a.nS; p++) {
+  uint32_t idx = (uint32_t)(((uint64_t)slice * mm) % a.nS);
+  const uint32_t step = (uint32_t)(((uint64_t)DFT_SLICES * mm) % a.nS);
+#pragma unroll 4
+  for (uint32_t p = slice; p < a.nS; p += DFT_SLICES) {
     const dcx t = dmul(u[p], w[idx]);
     acc.x += t.x;
     acc.y += t.y;
-    idx += m;
+    idx += step;
     if (idx >= a.nS) idx -= a.nS;
   }
-  // spectrum[k] = Xd[(k + hq) mod nS]  <=>  k = (m - hq) mod nS
-  const uint32_t hqm = a.hq % a.nS;
-  const uint32_t k = m >= hqm ? m - hqm : m + a.nS - hqm;
-  a.out[(size_t)cpi * a.nS + k] = acc;
+#pragma unroll
+  for (int off = 1; off < DFT_SLICES; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off);
+    acc.y += __shfl_xor(acc.y, off);
+  }
+  if (slice == 0 && m < a.nS) {
+    // spectrum[k] = Xd[(k + hq) mod nS]  <=>  k = (m - hq) mod nS
+    const uint32_t hqm = a.hq % a.nS;
+    const uint32_t k = m >= hqm ? m - hqm : m + a.nS - hqm;
+    a.out[(size_t)cpi * a.nS + k] = acc;
+  }
 }
 
 } // namespace
@@ -149,7 +179,7 @@ struct blah2hip_spectrum_s {
   uint64_t N = 0;
   double bandwidth = 0;
   hipStream_t stream = nullptr;
-  dcx *d_wD = nullptr, *d_wS = nullptr, *d_part = nullptr, *d_out = nullptr;
+  dcx *d_wD = nullptr, *d_wS = nullptr, *d_part = nullptr, *d_u = nullptr, *d_out = nullptr;
   cf *d_stage = nullptr;
 };
 
@@ -191,6 +221,7 @@ int blah2hip_spectrum_create(uint32_t n_samples, double bandwidth, int device, u
   SHIP(hipMalloc(&h->d_wS, nS * sizeof(dcx)));
   SHIP(hipMalloc(&h->d_part, (size_t)max_batch * h->nJ * nS * sizeof(dcx)));
   SHIP(hipMalloc(&h->d_out, (size_t)max_batch * nS * sizeof(dcx)));
+  SHIP(hipMalloc(&h->d_u, (size_t)max_batch * nS * sizeof(dcx)));
   SHIP(hipMemcpy(h->d_wD, wD.data(), D * sizeof(dcx), hipMemcpyHostToDevice));
   SHIP(hipMemcpy(h->d_wS, wS.data(), nS * sizeof(dcx), hipMemcpyHostToDevice));
   SHIP(hipFuncSetAttribute((const void *)spectrum_dft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 4096 * sizeof(dcx))));
@@ -206,6 +237,7 @@ int blah2hip_spectrum_destroy(blah2hip_spectrum_t h)
   (void)hipFree(h->d_wS);
   (void)hipFree(h->d_part);
   (void)hipFree(h->d_out);
+  (void)hipFree(h->d_u);
   if (h->d_stage) (void)hipFree(h->d_stage);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -233,6 +265,7 @@ int blah2hip_spectrum_process_dev(blah2hip_spectrum_t h, int fmt, const void *d_
   a.wD = h->d_wD;
   a.wS = h->d_wS;
   a.part = h->d_part;
+  a.u = h->d_u;
   a.out = reinterpret_cast<dcx *>(d_out);
   a.cpiStride = (int64_t)cpi_stride;
   a.D = h->D;
@@ -261,7 +294,9 @@ int blah2hip_spectrum_process_dev(blah2hip_spectrum_t h, int fmt, const void *d_
   default: SFAIL(BLAH2HIP_ERR_INVALID, "unknown sample format");
   }
   SHIP(hipGetLastError());
-  hipLaunchKernelGGL(spectrum_dft_kernel, dim3((h->nS + 255) / 256, n_cpi), dim3(256), 2 * (size_t)h->nS * sizeof(dcx), st, a);
+  hipLaunchKernelGGL(spectrum_reduce_kernel, dim3((h->nS + 255) / 256, n_cpi), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(spectrum_dft_kernel, dim3((h->nS + DFT_BINS - 1) / DFT_BINS, n_cpi), dim3(DFT_SLICES * DFT_BINS),
+                     2 * (size_t)h->nS * sizeof(dcx), st, a);
   SHIP(hipGetLastError());
   return BLAH2HIP_OK;
 }
