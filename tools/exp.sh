@@ -1,2 +1,3 @@
-P='import json,sys; d=json.loads(sys.stdin.readline()); print(d["config"]["batch_cpis_per_step"], d["value"], d["roofline"]["frac"], d["roofline"]["kernel_us_per_step"])'
-for b in 16 32 33 63 64 95 127 128; do python bench.py --no-cpu-baseline --batch $b --steps 20 | python -c "$P"; done
+P='import json,sys; d=json.loads(sys.stdin.readline()); print(d["config"]["batch_cpis_per_step"], d["config"]["streams_per_gpu"], round(d["value"]), round(d["roofline"]["frac"],3), d["roofline"]["kernel_us_per_step"])'
+for s in 1 2 3; do python bench.py --no-cpu-baseline --streams $s | python -c "$P"; done
+for s in 2 4; do python bench.py --no-cpu-baseline --streams $s --batch 64 | python -c "$P"; done
