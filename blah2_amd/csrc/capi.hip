@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -30,6 +32,18 @@ int fail(int code, const std::string &msg)
     hipError_t e_ = (expr);                                                                  \
     if (e_ != hipSuccess)                                                                    \
       return fail(BLAH2HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+extern "C" hipError_t blah2hip_ensure_lds_(const void *kern, int bytes);
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel): the
+// attribute belongs to the function object of the CURRENT device, and a process
+// may hold handles on several devices.
+#define LDSCFG(kern, bytes)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = blah2hip_ensure_lds_((const void *)(kern), (int)(bytes));                 \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(BLAH2HIP_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e_)); \
   } while (0)
 
 // exp(-2*pi*i*k/n) from the exactly reduced angle, fp64 -> fp32
@@ -232,11 +246,7 @@ template <int R3> int launch_doppler_t(blah2hip_amb_s *h, const DopplerArgs &a, 
   using W = WgFft<R3>;
   const size_t lds = (size_t)(R3 == 4 ? W::A_ELEMS : W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
   auto kern = doppler_fft_kernel<R3>;
-  static thread_local const void *configured = nullptr;
-  if (configured != (const void *)kern) {
-    HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = (const void *)kern;
-  }
+  LDSCFG(kern, lds);
   hipLaunchKernelGGL(kern, dim3(h->dopGridX, n_cpi), dim3(W::T), lds, st, a);
   HIPCHK(hipGetLastError());
   return BLAH2HIP_OK;
@@ -266,11 +276,7 @@ template <int R3, class In> int launch_range_t(blah2hip_amb_s *h, const RangeArg
     }
   }
 #endif
-  static thread_local const void *configured = nullptr;
-  if (configured != (const void *)kern) {
-    HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = (const void *)kern;
-  }
+  LDSCFG(kern, lds);
   const int grid = std::min<int>(a.nPulses, h->rangeGridCap);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(W::T), lds, st, a, in);
   HIPCHK(hipGetLastError());
@@ -282,11 +288,7 @@ template <int R4, class In> int launch_range8_t(blah2hip_amb_s *h, const RangeAr
   using W = WgFft8<R4>;
   const size_t lds = (size_t)2 * W::BUF_ELEMS * sizeof(cf);
   void (*kern)(RangeArgs, In) = range8_kernel<R4, In>;
-  static thread_local const void *configured = nullptr;
-  if (configured != (const void *)kern) {
-    HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = (const void *)kern;
-  }
+  LDSCFG(kern, lds);
   int perCU = std::max(1, std::min((int)((160 * 1024) / lds), 32 / (W::T / 64)));
   int cap = perCU * h->numCU;
   if (const char *e = std::getenv("BLAH2HIP_RANGE_GRID")) cap = std::max(1, std::atoi(e));
@@ -621,12 +623,8 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   const int tileGrid = h->dopTile ? (int)((nDelay + h->dopTile - 1) / h->dopTile) : 0;
   if (h->dopTile && (int)n_cpi * tileGrid >= h->numCU / 2) {
     const size_t lds = ((size_t)h->dopTile * DOPT_PITCH + 1024) * sizeof(cf);
-    static thread_local bool configured = false;
-    if (!configured) {
-      HIPCHK(hipFuncSetAttribute((const void *)doppler_tile_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (16 * DOPT_PITCH + 1024) * (int)sizeof(cf)));
-      HIPCHK(hipFuncSetAttribute((const void *)doppler_tile_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (8 * DOPT_PITCH + 1024) * (int)sizeof(cf)));
-      configured = true;
-    }
+    if (h->dopTile == 16) LDSCFG(doppler_tile_kernel<16>, lds);
+    else LDSCFG(doppler_tile_kernel<8>, lds);
     if (h->dopTile == 16) hipLaunchKernelGGL(doppler_tile_kernel<16>, dim3(tileGrid, n_cpi), dim3(1024), lds, st, da);
     else hipLaunchKernelGGL(doppler_tile_kernel<8>, dim3(tileGrid, n_cpi), dim3(512), lds, st, da);
     nPartsUsed = tileGrid;
@@ -990,5 +988,19 @@ int blah2hip_interpolate(const double *delay, const double *doppler, const doubl
 // implemented in clutter.hip; it reports errors through this internal hook so
 // that blah2hip_last_error() covers both translation units
 void blah2hip_set_error_(const char *msg) { g_err = msg ? msg : ""; }
+
+hipError_t blah2hip_ensure_lds_(const void *kern, int bytes)
+{
+  static std::mutex mu;
+  static std::set<std::pair<int, const void *>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.count({dev, kern})) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.insert({dev, kern});
+  return e;
+}
 
 } // extern "C"

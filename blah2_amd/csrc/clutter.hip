@@ -354,6 +354,7 @@ int cfail(int code, const std::string &m)
 
 // The error string is shared with capi.hip through this hook.
 extern "C" void blah2hip_set_error_(const char *msg);
+extern "C" hipError_t blah2hip_ensure_lds_(const void *kern, int bytes);
 
 #define CHIP(expr)                                                                        \
   do {                                                                                    \
@@ -393,13 +394,10 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
 {
   using W = WgFft<R3>;
   const size_t lds = (size_t)(W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
-  static thread_local bool configured = false;
-  if (!configured) {
-    CHIP(hipFuncSetAttribute((const void *)clutter_corr_kernel<R3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CHIP(hipFuncSetAttribute((const void *)clutter_fir_kernel<R3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CHIP(hipFuncSetAttribute((const void *)clutter_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    configured = true;
-  }
+  // once per (device, kernel), see capi.hip
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_corr_kernel<R3>, (int)lds));
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_fir_kernel<R3>, (int)lds));
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel, 160 * 1024 - 64));
   const uint32_t dMinU32 = (uint32_t)h->delayMin;
   CorrArgs ca;
   ca.x = x; ca.y = y; ca.cpiStride = stride; ca.N = h->N; ca.dMinU32 = dMinU32;

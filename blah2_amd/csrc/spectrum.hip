@@ -158,6 +158,7 @@ __global__ __launch_bounds__(DFT_SLICES * DFT_BINS) void spectrum_dft_kernel(Spe
 } // namespace
 
 extern "C" void blah2hip_set_error_(const char *msg);
+extern "C" hipError_t blah2hip_ensure_lds_(const void *kern, int bytes);
 
 #define SHIP(expr)                                                                        \
   do {                                                                                    \
@@ -224,7 +225,7 @@ int blah2hip_spectrum_create(uint32_t n_samples, double bandwidth, int device, u
   SHIP(hipMalloc(&h->d_u, (size_t)max_batch * nS * sizeof(dcx)));
   SHIP(hipMemcpy(h->d_wD, wD.data(), D * sizeof(dcx), hipMemcpyHostToDevice));
   SHIP(hipMemcpy(h->d_wS, wS.data(), nS * sizeof(dcx), hipMemcpyHostToDevice));
-  SHIP(hipFuncSetAttribute((const void *)spectrum_dft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 4096 * sizeof(dcx))));
+  SHIP(blah2hip_ensure_lds_((const void *)spectrum_dft_kernel, (int)(2 * 4096 * sizeof(dcx))));
   *out = h;
   return BLAH2HIP_OK;
 }
