@@ -259,6 +259,10 @@ template <int R3, class In> int launch_range_t(blah2hip_amb_s *h, const RangeArg
   // x/y transforms interleaved between barriers: +3..6 % for F <= 2048 (measured), neutral at 4096
   static const bool ilv = [] { const char *e = std::getenv("BLAH2HIP_RANGE_ILV"); return e ? std::atoi(e) != 0 : (R3 <= 8); }();
   void (*kern)(RangeArgs, In) = ilv ? range_kernel<R3, In, true> : range_kernel<R3, In, false>;
+  // raw buffer loads: the descriptor's range check does the zero padding of the segment windows
+  // (measured at cfg 2, batch 128: complex fp32 input -3 %, int16 input -12 % kernel time)
+  static const bool bl = [] { const char *e = std::getenv("BLAH2HIP_RANGE_BUF"); return e ? std::atoi(e) != 0 : true; }();
+  if (bl) kern = ilv ? range_kernel<R3, In, true, 3, true, true> : range_kernel<R3, In, false, 3, true, true>;
 #ifdef BLAH2HIP_ABLATE
   // profiling build only (tools/gpu_ablate.py; results are wrong by construction):
   // bit0 arithmetic, bit1 LDS, bit2 loads
@@ -287,7 +291,8 @@ template <int R4, class In> int launch_range8_t(blah2hip_amb_s *h, const RangeAr
 {
   using W = WgFft8<R4>;
   const size_t lds = (size_t)2 * W::BUF_ELEMS * sizeof(cf);
-  void (*kern)(RangeArgs, In) = range8_kernel<R4, In>;
+  static const bool bl = [] { const char *e = std::getenv("BLAH2HIP_RANGE_BUF"); return e ? std::atoi(e) != 0 : true; }();
+  void (*kern)(RangeArgs, In) = bl ? range8_kernel<R4, In, true> : range8_kernel<R4, In, false>;
   LDSCFG(kern, lds);
   int perCU = std::max(1, std::min((int)((160 * 1024) / lds), 32 / (W::T / 64)));
   int cap = perCU * h->numCU;

@@ -36,9 +36,135 @@ struct RangeArgs {
   int32_t nPulses;     // nCpi * nDoppler
 };
 
+// ---- raw buffer loads --------------------------------------------------------
+// A buffer descriptor carries (base, num_records); a load whose byte offset is
+// >= num_records -- or negative, i.e. huge as an unsigned -- returns 0 without
+// touching memory.  That is exactly the zero padding of the segment windows:
+//   x': descriptor = [pulse + s*segLen, + min(segLen, nCorr - s*segLen)) samples
+//   y': descriptor = the whole pulse, offset = (s*segLen + delayMin + m) samples
+// so the 32 loads of a segment need no clamp, no select and no per-load address
+// arithmetic: one VGPR offset per channel, the k-dependent part in the
+// instruction's immediate (12 bits) and, in steps of 4 KiB, in a handful of VGPR
+// adds (y) or in soffset (x).  Measured on gfx950 (tools/membench/bufprobe.hip):
+// the range check sees voffset + immediate (32-bit wrap) + soffset, and a negative
+// voffset stays out of range whatever soffset is -- which is why y, whose offset
+// can be negative, keeps everything in voffset + immediate.
+// Written as inline asm: the b64 builtin of this clang loads a single dword, and
+// pairs of b32 builtins do not merge once LICM has hoisted `offset + 4`.  The
+// compiler does not count these loads in its s_waitcnt bookkeeping; bufwait<N>()
+// is the explicit wait and ties the destination registers to it.
+typedef int b2_v4i __attribute__((ext_vector_type(4)));
+typedef float b2_v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ b2_v4i make_rsrc(const void *base, int bytes)
+{
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  b2_v4i d;
+  d.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  d.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) & 0xffff; // stride 0: raw buffer
+  d.z = __builtin_amdgcn_readfirstlane(bytes);
+  d.w = 0x00020000;
+  return d;
+}
+
+template <class In> struct BufLoad;
+template <> struct BufLoad<InC32> {
+  static constexpr int STRIDE = 8;
+  using raw = b2_v2f;
+  static __device__ __forceinline__ const void *xp(const InC32 &in, int64_t i) { return in.x + i; }
+  static __device__ __forceinline__ const void *yp(const InC32 &in, int64_t i) { return in.y + i; }
+  template <int IMM> static __device__ __forceinline__ void ld(raw &r, b2_v4i d, int voff, int soff)
+  {
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:%4" : "=v"(r) : "v"(voff), "s"(d), "s"(soff), "n"(IMM) : "memory");
+  }
+  static __device__ __forceinline__ cf cvt(raw r) { return cmake(r.x, r.y); }
+};
+template <> struct BufLoad<InI16> {
+  static constexpr int STRIDE = 8; // I1 Q1 I2 Q2
+  using raw = uint32_t;
+  static __device__ __forceinline__ const void *xp(const InI16 &in, int64_t i) { return in.iq + 4 * i; }
+  static __device__ __forceinline__ const void *yp(const InI16 &in, int64_t i) { return in.iq + 4 * i + 2; }
+  template <int IMM> static __device__ __forceinline__ void ld(raw &r, b2_v4i d, int voff, int soff)
+  {
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(r) : "v"(voff), "s"(d), "s"(soff), "n"(IMM) : "memory");
+  }
+  static __device__ __forceinline__ cf cvt(raw r) { return cmake((float)(int16_t)(r & 0xffffu), (float)(int16_t)(r >> 16)); }
+};
+template <> struct BufLoad<InF16> {
+  static constexpr int STRIDE = 4;
+  using raw = uint32_t;
+  static __device__ __forceinline__ const void *xp(const InF16 &in, int64_t i) { return in.x + 2 * i; }
+  static __device__ __forceinline__ const void *yp(const InF16 &in, int64_t i) { return in.y + 2 * i; }
+  template <int IMM> static __device__ __forceinline__ void ld(raw &r, b2_v4i d, int voff, int soff)
+  {
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(r) : "v"(voff), "s"(d), "s"(soff), "n"(IMM) : "memory");
+  }
+  static __device__ __forceinline__ cf cvt(raw r)
+  {
+    return cmake((float)__builtin_bit_cast(_Float16, (uint16_t)(r & 0xffffu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(r >> 16)));
+  }
+};
+
+// wait until at most N of the loads issued so far are outstanding; r[0..E) are
+// tied to the wait so that nothing reads them earlier
+template <int N, int E, class R> __device__ __forceinline__ void bufwait(R *r)
+{
+  static_assert(E == 8 || E == 16, "");
+  if constexpr (E == 16)
+    asm volatile("s_waitcnt vmcnt(%16)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]),
+                   "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+                 : "n"(N)
+                 : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                 : "n"(N)
+                 : "memory");
+}
+
+// k-th load of a channel, byte offset voff + k*STEP: the multiple of 4096 goes to
+// soffset (SOFF: x, offsets never negative) or must already be in vbase[k*STEP/4096] (y)
+template <class In, int STEP, int E, bool SOFF, int K = 0>
+__device__ __forceinline__ void bufload_chan(typename BufLoad<In>::raw *r, b2_v4i d, const int *vbase)
+{
+  if constexpr (K < E) {
+    constexpr int OFF = K * STEP;
+    if constexpr (SOFF) BufLoad<In>::template ld<(OFF & 4095)>(r[K], d, vbase[0], OFF & ~4095);
+    else BufLoad<In>::template ld<(OFF & 4095)>(r[K], d, vbase[OFF >> 12], 0);
+    bufload_chan<In, STEP, E, SOFF, K + 1>(r, d, vbase);
+  }
+}
+
+// segment s of the pulse at sample index pulseBase: v[k] = x'[t + T*k], yv[k] = y'[t + T*k]
+template <int T, int E, class In>
+__device__ __forceinline__ void bufload_seg(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, cf *v, cf *yv)
+{
+  using B = BufLoad<In>;
+  constexpr int STEP = T * B::STRIDE;
+  constexpr int NV = ((E - 1) * STEP >> 12) + 1;
+  const int s0 = s * p.segLen;
+  const int cnt = min(p.segLen, p.nCorr - s0);
+  const b2_v4i xd = make_rsrc(B::xp(in, pulseBase + s0), cnt * B::STRIDE);
+  const b2_v4i yd = make_rsrc(B::yp(in, pulseBase), p.nCorr * B::STRIDE);
+  int vx[1] = {t * B::STRIDE};
+  int vy[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) vy[j] = (s0 + p.delayMin + t) * B::STRIDE + j * 4096; // may be negative: reads as zero
+  typename B::raw xr[E], yr[E];
+  bufload_chan<In, STEP, E, true>(xr, xd, vx);
+  bufload_chan<In, STEP, E, false>(yr, yd, vy);
+  bufwait<E, E>(xr);
+#pragma unroll
+  for (int k = 0; k < E; k++) v[k] = B::cvt(xr[k]);
+  bufwait<0, E>(yr);
+#pragma unroll
+  for (int k = 0; k < E; k++) yv[k] = B::cvt(yr[k]);
+}
+
 // M / LD are profiling ablations (tools/gpu_ablate.py): M bit 0 = arithmetic, bit 1 = LDS
 // traffic, LD = global loads.  Production launches use <.., 3, true>.
-template <int R3, class In, bool ILV, int M = 3, bool LD = true>
+template <int R3, class In, bool ILV, int M = 3, bool LD = true, bool BL = false>
 __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
 {
   using W = WgFft<R3>;
@@ -59,15 +185,19 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
     cf v[16], yv[16], acc[16];
     for (int s = 0; s < p.nSeg; s++) {
       // both channels' loads go out first: 32 requests in flight per thread
-      if (LD) {
+      if (BL) {
+        bufload_seg<16 * R3, 16>(in, p, base, s, t, v, yv);
+      } else if (LD) {
         load_seg_x<R3>(in, p, base, s, t, v);
         load_seg_y<R3>(in, p, base, s, t, yv);
       } else {
 #pragma unroll
         for (int k = 0; k < 16; k++) { v[k] = cmake((float)(t + k), (float)s); yv[k] = cmake((float)k, (float)(t - s)); }
       }
-      mask_seg_x<R3>(p, s, t, v);
-      mask_seg_y<R3>(p, s, t, yv);
+      if (!BL) {
+        mask_seg_x<R3>(p, s, t, v);
+        mask_seg_y<R3>(p, s, t, yv);
+      }
       // The x and y transforms advance together, each through its own exchange
       // buffer (P for x, Q for y, used first in the A layout and then in the B
       // layout): every barrier interval holds two independent instruction
@@ -125,7 +255,7 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
 // segment run one after the other and alternate their starting exchange buffer
 // (x: A,B,A  y: B,A,B), so a buffer is never rewritten before the barrier that
 // follows its last read: 3 barriers per transform and none in between.
-template <int R4, class In>
+template <int R4, class In, bool BL = false>
 __global__ __launch_bounds__(64 * R4, 4) void range8_kernel(RangeArgs a, In in)
 {
   using W = WgFft8<R4>;
@@ -145,9 +275,13 @@ __global__ __launch_bounds__(64 * R4, 4) void range8_kernel(RangeArgs a, In in)
     cf acc[8];
     for (int s = 0; s < p.nSeg; s++) {
       cf v[8], yv[8];
-      load_seg_x_g<T, 8>(in, p, base, s, t, v);
-      load_seg_y_g<T, 8>(in, p, base, s, t, yv);
-      mask_seg_x_g<T, 8>(p, s, t, v);
+      if (BL) {
+        bufload_seg<T, 8>(in, p, base, s, t, v, yv);
+      } else {
+        load_seg_x_g<T, 8>(in, p, base, s, t, v);
+        load_seg_y_g<T, 8>(in, p, base, s, t, yv);
+        mask_seg_x_g<T, 8>(p, s, t, v);
+      }
       W::fwd_s1(t, v, tw1, A);
       __syncthreads();
       W::fwd_s2_load(t, v, A);
@@ -158,7 +292,7 @@ __global__ __launch_bounds__(64 * R4, 4) void range8_kernel(RangeArgs a, In in)
       __syncthreads();
       W::fwd_s4(t, v, A); // v = X spectrum
 
-      mask_seg_y_g<T, 8>(p, s, t, yv);
+      if (!BL) mask_seg_y_g<T, 8>(p, s, t, yv);
       W::fwd_s1(t, yv, tw1, B);
       __syncthreads();
       W::fwd_s2_load(t, yv, B);

@@ -1,0 +1,159 @@
+// Load pattern of the range kernel, nothing else: which part of it keeps the
+// kernel at ~3.5 TB/s when a plain stream reaches 6.3?  One workgroup of 128
+// threads per pulse (grid-stride), per segment 16 x-loads + 16 y-loads per thread
+// (8 bytes each), wait, next segment.
+//   mode 0: the kernel's pattern: x[s0 + m], y[s0 + dmin + m] for all m < F (clamped to the pulse)
+//   mode 1: only the lanes that matter: m < segLen for x, m < segLen + nDelay - 1 for y (others skipped by exec mask)
+//   mode 2: no overlap between segments: x and y both m < segLen only
+//   mode 3: mode 1 with the loads of two segments in flight before the first wait
+//   mode 4: mode 1, y first then x
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+struct f2 { float x, y; };
+
+template <int MODE>
+__global__ __launch_bounds__(128, 2) void pat(const f2 *x, const f2 *y, f2 *rmap, float *out, int nPulses, int nCorr, int segLen, int nSeg, int nDelay, int dmin)
+{
+  const int t = threadIdx.x;
+  float acc = 0.f, prevAcc = 0.f;
+  int prevPulse = -1;
+  for (int pulse = blockIdx.x; pulse < nPulses; pulse += gridDim.x) {
+    const f2 *xp = x + (long)pulse * nCorr, *yp = y + (long)pulse * nCorr;
+    if (MODE == 3) {
+      for (int s = 0; s < nSeg; s += 2) {
+        f2 v[2][16], w[2][16];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int s0 = (s + u) * segLen;
+#pragma unroll
+          for (int k = 0; k < 16; k++) {
+            const int m = t + 128 * k;
+            v[u][k] = f2{0, 0}; w[u][k] = f2{0, 0};
+            if (s + u < nSeg && m < segLen && s0 + m < nCorr) v[u][k] = xp[s0 + m];
+            const int iy = s0 + dmin + m;
+            if (s + u < nSeg && m < segLen + nDelay - 1 && iy >= 0 && iy < nCorr) w[u][k] = yp[iy];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+          for (int k = 0; k < 16; k++) acc += v[u][k].x + w[u][k].y;
+      }
+      continue;
+    }
+    for (int s = 0; s < nSeg; s++) {
+      const int s0 = s * segLen;
+      f2 v[16], w[16];
+      if (MODE == 4) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int m = t + 128 * k, iy = s0 + dmin + m;
+          w[k] = f2{0, 0};
+          if (m < segLen + nDelay - 1 && iy >= 0 && iy < nCorr) w[k] = yp[iy];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const int m = t + 128 * k;
+        if (MODE == 0 || MODE >= 5) {
+          const int ix = s0 + m;
+          v[k] = xp[ix < nCorr ? ix : nCorr - 1];
+        } else {
+          v[k] = f2{0, 0};
+          if (m < segLen && s0 + m < nCorr) v[k] = xp[s0 + m];
+        }
+      }
+      if (MODE != 4) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int m = t + 128 * k;
+          if (MODE == 0 || MODE >= 5) {
+            const int iy = s0 + dmin + m;
+            w[k] = yp[iy < 0 ? 0 : (iy < nCorr ? iy : nCorr - 1)];
+          } else if (MODE == 2) {
+            w[k] = f2{0, 0};
+            if (m < segLen && s0 + m < nCorr) w[k] = yp[s0 + m];
+          } else {
+            const int iy = s0 + dmin + m;
+            w[k] = f2{0, 0};
+            if (m < segLen + nDelay - 1 && iy >= 0 && iy < nCorr) w[k] = yp[iy];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 16; k++) acc += v[k].x + w[k].y;
+      if (MODE == 10 && s == 0 && prevPulse >= 0) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int lag = t + 128 * c;
+          if (lag < nDelay) {
+            const int cpi = prevPulse / 513, i = prevPulse - cpi * 513;
+            rmap[(((long)cpi * 26 + (lag >> 4)) * 513 + i) * 16 + (lag & 15)] = f2{prevAcc, prevAcc};
+          }
+        }
+      }
+      if (MODE >= 5) {
+#pragma unroll
+        for (int b = 0; b < 7; b++) __syncthreads();
+      }
+    }
+    if (MODE == 10) { prevPulse = pulse; prevAcc = acc; }
+    if (MODE >= 6 && MODE <= 9) {
+      // the kernel's lag store: tiled [lag/16][pulse][16], 411 lags per pulse
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int lag = t + 128 * c;
+        if (MODE == 6 && lag < nDelay) rmap[((long)(lag >> 4) * nPulses + pulse) * 16 + (lag & 15)] = f2{acc, acc};
+        if (MODE == 7 && lag < nDelay) rmap[(long)pulse * nDelay + lag] = f2{acc, acc};                     // row-major
+        if (MODE == 8 && lag < nDelay) rmap[(long)pulse * 416 + lag] = f2{acc, acc};                        // row-major, 128-B aligned rows
+        if (MODE == 9 && lag < nDelay) {                                                                    // the kernel's real layout [cpi][lag/16][pulse][16]
+          const int cpi = pulse / 513, i = pulse - cpi * 513;
+          rmap[(((long)cpi * 26 + (lag >> 4)) * 513 + i) * 16 + (lag & 15)] = f2{acc, acc};
+        }
+      }
+    }
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+template <int MODE> void run(const f2 *x, const f2 *y, f2 *rmap, float *out, int nCpi, int grid)
+{
+  const int nD = 513, nCorr = 3898, segLen = 1300, nSeg = 3, nDelay = 411, dmin = -10;
+  const int nPulses = nCpi * nD;
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  pat<MODE><<<grid, 128>>>(x, y, rmap, out, nPulses, nCorr, segLen, nSeg, nDelay, dmin);
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  for (int i = 0; i < 5; i++) pat<MODE><<<grid, 128>>>(x, y, rmap, out, nPulses, nCorr, segLen, nSeg, nDelay, dmin);
+  hipEventRecord(b);
+  hipEventSynchronize(b);
+  float ms = 0; hipEventElapsedTime(&ms, a, b);
+  const double usPerCpi = ms * 1e3 / 5 / nCpi;
+  std::printf("mode %d grid %4d: %.2f us/CPI, %.2f TB/s of unique bytes\n", MODE, grid, usPerCpi, 2.0 * nD * nCorr * 8 / usPerCpi / 1e6);
+}
+
+int main()
+{
+  const int nCpi = 128;
+  const size_t n = (size_t)nCpi * 2000000;
+  f2 *x, *y, *rmap; float *out;
+  hipMalloc(&x, n * 8); hipMalloc(&y, n * 8); hipMalloc(&out, 64); hipMalloc(&rmap, (size_t)nCpi * 513 * 416 * 8);
+  hipMemset(x, 1, n * 8); hipMemset(y, 1, n * 8);
+  for (int grid : {1024}) {
+    run<0>(x, y, rmap, out, nCpi, grid);
+    run<5>(x, y, rmap, out, nCpi, grid);
+    run<6>(x, y, rmap, out, nCpi, grid);
+    run<7>(x, y, rmap, out, nCpi, grid);
+    run<8>(x, y, rmap, out, nCpi, grid);
+    run<9>(x, y, rmap, out, nCpi, grid);
+    run<10>(x, y, rmap, out, nCpi, grid);
+    run<1>(x, y, rmap, out, nCpi, grid);
+    run<2>(x, y, rmap, out, nCpi, grid);
+    run<3>(x, y, rmap, out, nCpi, grid);
+    run<4>(x, y, rmap, out, nCpi, grid);
+  }
+  return 0;
+}
