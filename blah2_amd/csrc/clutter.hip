@@ -43,13 +43,29 @@ struct dcx {
   double x, y;
 };
 
-// WienerHopf.cpp:67: (i - delayMin) evaluated in uint32, then mod N
-__device__ __forceinline__ uint32_t xs_index(uint32_t i, uint32_t dMinU32, uint32_t N) { return (i - dMinU32) % N; }
+// WienerHopf.cpp:67: xs[i] = x[(i - delayMin) % N] with (i - delayMin) evaluated in
+// uint32.  Without a division (i < N, |delayMin| < N):
+//   delayMin <= 0: i + |delayMin| < 2N                     -> one conditional subtract
+//   delayMin > 0 : i >= delayMin -> i - delayMin < N
+//                  i <  delayMin -> the uint32 difference wraps to 2^32 + i - delayMin,
+//                                   whose residue is (i + wrapC) mod N, wrapC = (2^32 - delayMin) mod N
+// thresh = max(delayMin, 0), sub = delayMin as uint32, wrapC precomputed on the host.
+struct XsMap {
+  uint32_t N, thresh, sub, wrapC;
+};
+__device__ __forceinline__ uint32_t xs_index(uint32_t i, const XsMap &m)
+{
+  uint32_t j = (i >= m.thresh) ? i - m.sub : i + m.wrapC;
+  return j >= m.N ? j - m.N : j;
+}
+// n < 2N -> n mod N
+__device__ __forceinline__ uint32_t wrapN(uint32_t n, uint32_t N) { return n >= N ? n - N : n; }
 
 struct CorrArgs {
   const cf *x, *y;
   int64_t cpiStride;
-  uint32_t N, dMinU32;
+  uint32_t N;
+  XsMap xs;
   int32_t nBins, segLen, nSeg, nJobs;
   const cf *tw;
   cf *partial; // [nCpi][2][nJobs][nBins]
@@ -78,15 +94,18 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_ker
   for (int e = 0; e < 16; e++) { accR[e] = cmake(0.f, 0.f); accB[e] = cmake(0.f, 0.f); }
   for (int g = blockIdx.x; g < a.nSeg; g += a.nJobs) {
     const uint32_t n0 = (uint32_t)g * (uint32_t)a.segLen;
-    cf v[16], wv[16];
+    // all 32 loads of the segment first (the y window is consumed last)
+    cf v[16], wv[16], yw[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const uint32_t nw = wrapN(n0 + (uint32_t)(t + T * k), a.N); // circular window index, n0 + m < N + F
+      wv[k] = X[xs_index(nw, a.xs)];                               // xs window (mode r)
+      yw[k] = Y[nw];                                               // y window (mode b)
+    }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int m = t + T * k;
-      const uint32_t n = n0 + (uint32_t)m;
-      const uint32_t nw = n % a.N; // circular window index
-      const cf xw = X[xs_index(nw, a.dMinU32, a.N)];
-      wv[k] = xw;                                                  // xs window (mode r)
-      v[k] = (m < a.segLen && n < a.N) ? xw : cmake(0.f, 0.f);     // x' = the same samples, cut to the segment
+      v[k] = (m < a.segLen && n0 + (uint32_t)m < a.N) ? wv[k] : cmake(0.f, 0.f); // x' = the same samples, cut to the segment
     }
     W::fwd_s1(t, v, tw1, P);
     __syncthreads();
@@ -100,15 +119,13 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_ker
     W::fwd_s3(t, wv, tw3, Q);
 #pragma unroll
     for (int e = 0; e < 16; e++) accR[e] = cmacc(accR[e], wv[e], v[e]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) wv[k] = Y[(n0 + (uint32_t)(t + T * k)) % a.N]; // y window (mode b)
-    W::fwd_s1(t, wv, tw1, P);
+    W::fwd_s1(t, yw, tw1, P);
     __syncthreads();
-    W::fwd_s2(t, wv, P, Q);
+    W::fwd_s2(t, yw, P, Q);
     __syncthreads();
-    W::fwd_s3(t, wv, tw3, Q);
+    W::fwd_s3(t, yw, tw3, Q);
 #pragma unroll
-    for (int e = 0; e < 16; e++) accB[e] = cmacc(accB[e], wv[e], v[e]);
+    for (int e = 0; e < 16; e++) accB[e] = cmacc(accB[e], yw[e], v[e]);
     __syncthreads();
   }
   // two explicit calls (a runtime-selected register array would be demoted to scratch)
@@ -261,7 +278,8 @@ struct FirArgs {
   const cf *x, *y;
   cf *yout;
   int64_t cpiStride, outStride;
-  uint32_t N, dMinU32;
+  uint32_t N;
+  XsMap xs;
   int32_t nBins, segLen, nSeg;
   const cf *w;       // [nCpi][nBins]
   const int32_t *ok; // [nCpi]
@@ -301,21 +319,20 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_fir_kern
   __syncthreads();
 
   const int hist = a.nBins - 1; // samples of history in front of each block
+  const int N = (int)a.N;       // < 2^31 - 8192 (checked at create): 32-bit sample indices throughout
   for (int g = blockIdx.x; g < a.nSeg; g += gridDim.x) {
-    const int64_t n0 = (int64_t)g * a.segLen;
+    const int n0 = g * a.segLen;
     cf v[16], yv[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int m = t + T * k;
-      const int64_t src = n0 - hist + m;
-      const bool in = src >= 0 && src < (int64_t)a.N;
-      const uint32_t sc = in ? (uint32_t)src : 0u;
-      const cf xv = X[xs_index(sc, a.dMinU32, a.N)];
+      const int src = n0 - hist + m;
+      const bool in = src >= 0 && src < N;
+      const cf xv = X[xs_index(in ? (uint32_t)src : 0u, a.xs)];
       v[k] = in ? xv : cmake(0.f, 0.f);
-      // y of the output sample this register will end up holding
-      const int64_t n = n0 + (m - hist);
-      const bool outv = (m >= hist) && (m < hist + a.segLen) && (n < (int64_t)a.N);
-      yv[k] = Y[outv ? n : 0];
+      // y of the output sample this register will end up holding (n = src)
+      const bool outv = (m >= hist) && (m < hist + a.segLen) && (src < N);
+      yv[k] = Y[outv ? src : 0];
     }
     if (ok) {
       W::fwd_s1(t, v, tw1, P);
@@ -336,8 +353,8 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_fir_kern
 #pragma unroll
     for (int c = 0; c < 16; c++) {
       const int m = t + T * c;
-      const int64_t n = n0 + (m - hist);
-      if (m >= hist && m < hist + a.segLen && n < (int64_t)a.N)
+      const int n = n0 + (m - hist);
+      if (m >= hist && m < hist + a.segLen && n < N)
         O[n] = ok ? csub(yv[c], v[c]) : yv[c]; // not PD: surveillance channel passes through
     }
   }
@@ -398,9 +415,13 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   CHIP(blah2hip_ensure_lds_((const void *)clutter_corr_kernel<R3>, (int)lds));
   CHIP(blah2hip_ensure_lds_((const void *)clutter_fir_kernel<R3>, (int)lds));
   CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel, 160 * 1024 - 64));
-  const uint32_t dMinU32 = (uint32_t)h->delayMin;
+  XsMap xs;
+  xs.N = h->N;
+  xs.thresh = h->delayMin > 0 ? (uint32_t)h->delayMin : 0u;
+  xs.sub = (uint32_t)h->delayMin;
+  xs.wrapC = (uint32_t)(((1ull << 32) - (uint64_t)(h->delayMin > 0 ? h->delayMin : 0)) % h->N);
   CorrArgs ca;
-  ca.x = x; ca.y = y; ca.cpiStride = stride; ca.N = h->N; ca.dMinU32 = dMinU32;
+  ca.x = x; ca.y = y; ca.cpiStride = stride; ca.N = h->N; ca.xs = xs;
   ca.nBins = h->nBins; ca.segLen = h->segLen; ca.nSeg = h->nSeg; ca.nJobs = h->nJobs;
   ca.tw = h->d_tw; ca.partial = h->d_partial; ca.scale = 1.0f / (float)h->F;
   hipLaunchKernelGGL(clutter_corr_kernel<R3>, dim3(h->nJobs, nCpi), dim3(W::T), lds, st, ca);
@@ -414,7 +435,7 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   CHIP(hipGetLastError());
 
   FirArgs fa;
-  fa.x = x; fa.y = y; fa.yout = yout; fa.cpiStride = stride; fa.outStride = outStride; fa.N = h->N; fa.dMinU32 = dMinU32;
+  fa.x = x; fa.y = y; fa.yout = yout; fa.cpiStride = stride; fa.outStride = outStride; fa.N = h->N; fa.xs = xs;
   fa.nBins = h->nBins; fa.segLen = h->segLen; fa.nSeg = h->nSeg; fa.w = h->d_w; fa.ok = ok; fa.tw = h->d_tw;
   fa.scale = 1.0f / (float)h->F;
   hipLaunchKernelGGL(clutter_fir_kernel<R3>, dim3(h->firGrid, nCpi), dim3(W::T), lds, st, fa);
@@ -433,6 +454,9 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
   *out = nullptr;
   if (delay_max <= delay_min) CFAIL(BLAH2HIP_ERR_INVALID, "clutter filter needs delayMax > delayMin");
   if (n_samples == 0) CFAIL(BLAH2HIP_ERR_INVALID, "nSamples must be positive");
+  if (n_samples > 0x7fffffffu - 8192u) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nSamples >= 2^31 - 8192 (32-bit sample indices)");
+  if ((uint64_t)(delay_min < 0 ? -(int64_t)delay_min : (int64_t)delay_min) >= n_samples)
+    CFAIL(BLAH2HIP_ERR_INVALID, "|delayMin| >= nSamples");
   const int nBins = delay_max - delay_min;
   if (max_batch == 0) max_batch = 1;
   int ndev = 0;
