@@ -505,18 +505,19 @@ int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_mi
 int blah2hip_amb_destroy(blah2hip_amb_t h)
 {
   if (!h) return BLAH2HIP_OK;
-  hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
+  // teardown: nothing useful can be done with a failure here
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void *p : {(void *)h->d_tw, (void *)h->d_dopW, (void *)h->d_R, (void *)h->d_map,
                   (void *)h->d_partSum, (void *)h->d_partMax, (void *)h->d_metrics,
                   (void *)h->d_doppler, (void *)h->d_alpha, h->d_in, (void *)h->d_rot,
                   (void *)h->d_hits, (void *)h->d_count, (void *)h->d_sat, (void *)h->d_alpha2, (void *)h->d_dopCnt, (void *)h->d_dtw, (void *)h->d_chirp,
                   (void *)h->d_bf})
-    if (p) hipFree(p);
+    if (p) (void)hipFree(p);
   for (auto &v : h->ev)
-    for (auto &p : v) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-  for (auto &p : h->evPool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-  if (h->stream) hipStreamDestroy(h->stream);
+    for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto &p : h->evPool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return BLAH2HIP_OK;
 }

@@ -360,12 +360,6 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_fir_kern
   }
 }
 
-thread_local std::string g_cerr;
-int cfail(int code, const std::string &m)
-{
-  g_cerr = m;
-  return code;
-}
 
 } // namespace
 
@@ -512,12 +506,12 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
 int blah2hip_clutter_destroy(blah2hip_clutter_t h)
 {
   if (!h) return BLAH2HIP_OK;
-  hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void *p : {(void *)h->d_tw, (void *)h->d_partial, (void *)h->d_rb, (void *)h->d_w, (void *)h->d_ok,
                   (void *)h->d_stage})
-    if (p) hipFree(p);
-  if (h->stream) hipStreamDestroy(h->stream);
+    if (p) (void)hipFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return BLAH2HIP_OK;
 }

@@ -118,6 +118,14 @@ __global__ __launch_bounds__(128, 2) void pat(const f2 *x, const f2 *y, f2 *rmap
   if (acc == 12345.678f) out[0] = acc;
 }
 
+__global__ void fill_random(unsigned *p, size_t n)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (h & 0x007fffffu) | 0x43000000u; // floats in [128, 256)
+  }
+}
+
 template <int MODE> void run(const f2 *x, const f2 *y, f2 *rmap, float *out, int nCpi, int grid)
 {
   const int nD = 513, nCorr = 3898, segLen = 1300, nSeg = 3, nDelay = 411, dmin = -10;
@@ -142,6 +150,7 @@ int main()
   f2 *x, *y, *rmap; float *out;
   hipMalloc(&x, n * 8); hipMalloc(&y, n * 8); hipMalloc(&out, 64); hipMalloc(&rmap, (size_t)nCpi * 513 * 416 * 8);
   hipMemset(x, 1, n * 8); hipMemset(y, 1, n * 8);
+  if (std::getenv("RANDOM_FILL")) { fill_random<<<4096, 256>>>((unsigned *)x, n * 2); fill_random<<<4096, 256>>>((unsigned *)y, n * 2); hipDeviceSynchronize(); std::printf("random fill\n"); }
   for (int grid : {1024}) {
     run<0>(x, y, rmap, out, nCpi, grid);
     run<5>(x, y, rmap, out, nCpi, grid);
