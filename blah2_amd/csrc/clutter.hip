@@ -308,8 +308,9 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_fir_kern
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     const int m = t + T * k;
-    const cf wv = a.w[(size_t)cpi * a.nBins + (m < a.nBins ? m : 0)];
-    ws[k] = (m < a.nBins) ? cmake(wv.x * a.scale, wv.y * a.scale) : cmake(0.f, 0.f);
+    const cf wv = a.w[(size_t)cpi * a.nBins + min(m, a.nBins - 1)];
+    const float keep = (m < a.nBins) ? a.scale : 0.f; // branch-free: the 16 loads go out together
+    ws[k] = cmake(wv.x * keep, wv.y * keep);
   }
   W::fwd_s1(t, ws, tw1, P);
   __syncthreads();
@@ -387,7 +388,7 @@ struct blah2hip_clutter_s {
   uint32_t N = 0, maxBatch = 1;
   int32_t nBins = 0;
   int r3 = 8;
-  int F = 2048, segLen = 0, nSeg = 0, nJobs = 0, firGrid = 0;
+  int F = 2048, segLen = 0, nSeg = 0, nJobs = 0, firGrid = 0, numCU = 256;
   hipStream_t stream = nullptr;
   cf *d_tw = nullptr;
   cf *d_partial = nullptr;
@@ -414,15 +415,22 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   xs.thresh = h->delayMin > 0 ? (uint32_t)h->delayMin : 0u;
   xs.sub = (uint32_t)h->delayMin;
   xs.wrapC = (uint32_t)(((1ull << 32) - (uint64_t)(h->delayMin > 0 ? h->delayMin : 0)) % h->N);
+  // Workgroups per CPI shrink as the batch grows: a correlation workgroup ends with two
+  // inverse transforms and a partial write, a FIR workgroup starts with the transform of
+  // the taps -- per-workgroup costs that a long walk over segments amortises.  Two
+  // resident generations' worth keeps the tail short.
+  const int slots = 4 * h->numCU; // residency of these kernels: 4 workgroups per CU (LDS)
+  const int nJobs = std::max(1, std::min(h->nJobs, (2 * slots + (int)nCpi - 1) / (int)nCpi));
+  const int firGrid = std::max(1, std::min(h->firGrid, (2 * slots + (int)nCpi - 1) / (int)nCpi));
   CorrArgs ca;
   ca.x = x; ca.y = y; ca.cpiStride = stride; ca.N = h->N; ca.xs = xs;
-  ca.nBins = h->nBins; ca.segLen = h->segLen; ca.nSeg = h->nSeg; ca.nJobs = h->nJobs;
+  ca.nBins = h->nBins; ca.segLen = h->segLen; ca.nSeg = h->nSeg; ca.nJobs = nJobs;
   ca.tw = h->d_tw; ca.partial = h->d_partial; ca.scale = 1.0f / (float)h->F;
-  hipLaunchKernelGGL(clutter_corr_kernel<R3>, dim3(h->nJobs, nCpi), dim3(W::T), lds, st, ca);
+  hipLaunchKernelGGL(clutter_corr_kernel<R3>, dim3(nJobs, nCpi), dim3(W::T), lds, st, ca);
   CHIP(hipGetLastError());
 
   SolveArgs sa;
-  sa.partial = h->d_partial; sa.rb = h->d_rb; sa.w = h->d_w; sa.ok = ok; sa.nBins = h->nBins; sa.nJobs = h->nJobs;
+  sa.partial = h->d_partial; sa.rb = h->d_rb; sa.w = h->d_w; sa.ok = ok; sa.nBins = h->nBins; sa.nJobs = nJobs;
   hipLaunchKernelGGL(clutter_reduce_kernel, dim3((h->nBins + 255) / 256, 2, nCpi), dim3(256), 0, st, sa);
   const size_t sl = (size_t)4 * h->nBins * sizeof(dcx);
   hipLaunchKernelGGL(clutter_solve_kernel, dim3(nCpi), dim3(64), sl, st, sa);
@@ -432,7 +440,7 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   fa.x = x; fa.y = y; fa.yout = yout; fa.cpiStride = stride; fa.outStride = outStride; fa.N = h->N; fa.xs = xs;
   fa.nBins = h->nBins; fa.segLen = h->segLen; fa.nSeg = h->nSeg; fa.w = h->d_w; fa.ok = ok; fa.tw = h->d_tw;
   fa.scale = 1.0f / (float)h->F;
-  hipLaunchKernelGGL(clutter_fir_kernel<R3>, dim3(h->firGrid, nCpi), dim3(W::T), lds, st, fa);
+  hipLaunchKernelGGL(clutter_fir_kernel<R3>, dim3(firGrid, nCpi), dim3(W::T), lds, st, fa);
   CHIP(hipGetLastError());
   return BLAH2HIP_OK;
 }
@@ -485,6 +493,7 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
   h->nSeg = (int)((n_samples + (uint32_t)h->segLen - 1) / (uint32_t)h->segLen);
   hipDeviceProp_t prop;
   CHIP(hipGetDeviceProperties(&prop, device));
+  h->numCU = prop.multiProcessorCount;
   h->nJobs = std::min(h->nSeg, 2 * prop.multiProcessorCount); // partial correlations per CPI (x2 modes in one workgroup)
   h->firGrid = std::min(h->nSeg, 8 * prop.multiProcessorCount);
   CHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));

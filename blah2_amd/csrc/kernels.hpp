@@ -14,6 +14,7 @@
 #include "blah2hip.h"
 #include "range_core.hpp"
 #include "fft_wg8.hpp"
+#include "bufload.hpp"
 
 namespace blah2 {
 
@@ -35,106 +36,6 @@ struct RangeArgs {
   int64_t cpiStride;   // samples between consecutive CPIs of the batch
   int32_t nPulses;     // nCpi * nDoppler
 };
-
-// ---- raw buffer loads --------------------------------------------------------
-// A buffer descriptor carries (base, num_records); a load whose byte offset is
-// >= num_records -- or negative, i.e. huge as an unsigned -- returns 0 without
-// touching memory.  That is exactly the zero padding of the segment windows:
-//   x': descriptor = [pulse + s*segLen, + min(segLen, nCorr - s*segLen)) samples
-//   y': descriptor = the whole pulse, offset = (s*segLen + delayMin + m) samples
-// so the 32 loads of a segment need no clamp, no select and no per-load address
-// arithmetic: one VGPR offset per channel, the k-dependent part in the
-// instruction's immediate (12 bits) and, in steps of 4 KiB, in a handful of VGPR
-// adds (y) or in soffset (x).  Measured on gfx950 (tools/membench/bufprobe.hip):
-// the range check sees voffset + immediate (32-bit wrap) + soffset, and a negative
-// voffset stays out of range whatever soffset is -- which is why y, whose offset
-// can be negative, keeps everything in voffset + immediate.
-// Written as inline asm: the b64 builtin of this clang loads a single dword, and
-// pairs of b32 builtins do not merge once LICM has hoisted `offset + 4`.  The
-// compiler does not count these loads in its s_waitcnt bookkeeping; bufwait<N>()
-// is the explicit wait and ties the destination registers to it.
-typedef int b2_v4i __attribute__((ext_vector_type(4)));
-typedef float b2_v2f __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ b2_v4i make_rsrc(const void *base, int bytes)
-{
-  const uint64_t a = reinterpret_cast<uint64_t>(base);
-  b2_v4i d;
-  d.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-  d.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) & 0xffff; // stride 0: raw buffer
-  d.z = __builtin_amdgcn_readfirstlane(bytes);
-  d.w = 0x00020000;
-  return d;
-}
-
-template <class In> struct BufLoad;
-template <> struct BufLoad<InC32> {
-  static constexpr int STRIDE = 8;
-  using raw = b2_v2f;
-  static __device__ __forceinline__ const void *xp(const InC32 &in, int64_t i) { return in.x + i; }
-  static __device__ __forceinline__ const void *yp(const InC32 &in, int64_t i) { return in.y + i; }
-  template <int IMM> static __device__ __forceinline__ void ld(raw &r, b2_v4i d, int voff, int soff)
-  {
-    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:%4" : "=v"(r) : "v"(voff), "s"(d), "s"(soff), "n"(IMM) : "memory");
-  }
-  static __device__ __forceinline__ cf cvt(raw r) { return cmake(r.x, r.y); }
-};
-template <> struct BufLoad<InI16> {
-  static constexpr int STRIDE = 8; // I1 Q1 I2 Q2
-  using raw = uint32_t;
-  static __device__ __forceinline__ const void *xp(const InI16 &in, int64_t i) { return in.iq + 4 * i; }
-  static __device__ __forceinline__ const void *yp(const InI16 &in, int64_t i) { return in.iq + 4 * i + 2; }
-  template <int IMM> static __device__ __forceinline__ void ld(raw &r, b2_v4i d, int voff, int soff)
-  {
-    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(r) : "v"(voff), "s"(d), "s"(soff), "n"(IMM) : "memory");
-  }
-  static __device__ __forceinline__ cf cvt(raw r) { return cmake((float)(int16_t)(r & 0xffffu), (float)(int16_t)(r >> 16)); }
-};
-template <> struct BufLoad<InF16> {
-  static constexpr int STRIDE = 4;
-  using raw = uint32_t;
-  static __device__ __forceinline__ const void *xp(const InF16 &in, int64_t i) { return in.x + 2 * i; }
-  static __device__ __forceinline__ const void *yp(const InF16 &in, int64_t i) { return in.y + 2 * i; }
-  template <int IMM> static __device__ __forceinline__ void ld(raw &r, b2_v4i d, int voff, int soff)
-  {
-    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(r) : "v"(voff), "s"(d), "s"(soff), "n"(IMM) : "memory");
-  }
-  static __device__ __forceinline__ cf cvt(raw r)
-  {
-    return cmake((float)__builtin_bit_cast(_Float16, (uint16_t)(r & 0xffffu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(r >> 16)));
-  }
-};
-
-// wait until at most N of the loads issued so far are outstanding; r[0..E) are
-// tied to the wait so that nothing reads them earlier
-template <int N, int E, class R> __device__ __forceinline__ void bufwait(R *r)
-{
-  static_assert(E == 8 || E == 16, "");
-  if constexpr (E == 16)
-    asm volatile("s_waitcnt vmcnt(%16)"
-                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]),
-                   "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
-                 : "n"(N)
-                 : "memory");
-  else
-    asm volatile("s_waitcnt vmcnt(%8)"
-                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
-                 : "n"(N)
-                 : "memory");
-}
-
-// k-th load of a channel, byte offset voff + k*STEP: the multiple of 4096 goes to
-// soffset (SOFF: x, offsets never negative) or must already be in vbase[k*STEP/4096] (y)
-template <class In, int STEP, int E, bool SOFF, int K = 0>
-__device__ __forceinline__ void bufload_chan(typename BufLoad<In>::raw *r, b2_v4i d, const int *vbase)
-{
-  if constexpr (K < E) {
-    constexpr int OFF = K * STEP;
-    if constexpr (SOFF) BufLoad<In>::template ld<(OFF & 4095)>(r[K], d, vbase[0], OFF & ~4095);
-    else BufLoad<In>::template ld<(OFF & 4095)>(r[K], d, vbase[OFF >> 12], 0);
-    bufload_chan<In, STEP, E, SOFF, K + 1>(r, d, vbase);
-  }
-}
 
 // segment s of the pulse at sample index pulseBase: v[k] = x'[t + T*k], yv[k] = y'[t + T*k]
 template <int T, int E, class In>
