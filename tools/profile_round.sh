@@ -21,7 +21,7 @@ cd $REPO
 python bench.py > $OUT/bench_r1.log 2>&1
 python bench.py --batch 1 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_r1_b1.log 2>&1
 python bench.py --fmt i16 --no-cpu-baseline > $OUT/bench_r1_i16.log 2>&1
-python bench.py --chain full --batch 16 --no-cpu-baseline > $OUT/bench_r1_full.log 2>&1
+python bench.py --chain full --batch 64 --no-cpu-baseline > $OUT/bench_r1_full.log 2>&1
 python bench.py --config cfg3 --batch 8 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_r1_cfg3.log 2>&1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_r1_torchrun.log 2>&1
 tail -n 1 $OUT/bench_r1*.log
