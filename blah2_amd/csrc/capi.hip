@@ -627,6 +627,15 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   // The tile kernel (coalesced, one 16-wave workgroup per CU) wins once a launch carries
   // enough tiles to fill the chip; small launches (single CPI) keep the per-column kernel.
   const int tileGrid = h->dopTile ? (int)((nDelay + h->dopTile - 1) / h->dopTile) : 0;
+  static const bool tileM = [] { const char *e = std::getenv("BLAH2HIP_DOPPLER_TILEM"); return e ? std::atoi(e) != 0 : true; }();
+  const int tileGridM = (int)((nDelay + DOPM_NCOL - 1) / DOPM_NCOL);
+  if (tileM && h->dopR3 == DOPM_R3 && nD <= 1025 && (int)n_cpi * tileGridM >= h->numCU / 2) {
+    const size_t lds = (size_t)DOPM_LDS_ELEMS * sizeof(cf);
+    LDSCFG(doppler_tilem_kernel, lds);
+    hipLaunchKernelGGL(doppler_tilem_kernel, dim3(tileGridM, n_cpi), dim3(1024), lds, st, da);
+    nPartsUsed = tileGridM;
+    HIPCHK(hipGetLastError());
+  } else
   if (h->dopTile && (int)n_cpi * tileGrid >= h->numCU / 2) {
     const size_t lds = ((size_t)h->dopTile * DOPT_PITCH + 1024) * sizeof(cf);
     if (h->dopTile == 16) LDSCFG(doppler_tile_kernel<16>, lds);

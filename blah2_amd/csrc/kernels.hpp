@@ -534,6 +534,140 @@ __global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a)
   }
 }
 
+// Tile variant for 513 < nD <= 1025 (M = 2048: a column is a 128-thread, two-wave
+// transform): 8 columns per 1024-thread workgroup, same phases as doppler_tile_kernel.
+// A column's exchange buffer is ONE region (stage 2 works inside rows of 8 consecutive
+// threads, i.e. inside a wave, so it runs in place); the stage boundaries are
+// workgroup barriers, all columns advance in lockstep.  155 KB of LDS: one workgroup
+// per CU, 4 waves per SIMD.
+constexpr int DOPM_R3 = 8;
+constexpr int DOPM_NCOL = 8;
+constexpr int DOPM_REGION = WgFft<DOPM_R3>::A_ELEMS; // 2176 complex values per column
+constexpr int DOPM_LDS_ELEMS = DOPM_NCOL * DOPM_REGION + WgFft<DOPM_R3>::F;
+
+__global__ __launch_bounds__(1024) void doppler_tilem_kernel(DopplerArgs a)
+{
+  using W = WgFft<DOPM_R3>;
+  constexpr int T = W::T;   // 128 threads per column
+  constexpr int NCOL = DOPM_NCOL;
+  constexpr int NT = 1024;
+  constexpr int NR = 9;     // rows t + 128*k, k < 9, cover nD <= 1025 (+ padding)
+  constexpr int NRT = 9;    // tile cells per thread: nD * 8 / 1024 <= 8.01
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf *lds = reinterpret_cast<cf *>(smem);
+  const int tid = threadIdx.x;
+  const int w = tid / T, t = tid % T; // column of the tile, thread inside the column's transform
+  const int nD = a.nD;
+  const int sub = blockIdx.x, cpi = blockIdx.y;
+  const int col0 = sub * NCOL;
+  cf *region = lds + w * DOPM_REGION;
+  cf *bfL = lds + NCOL * DOPM_REGION;
+
+  // phase 1: coalesced tile read, all loads in flight before the first use
+  const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, col0);
+  const int cells = nD * NCOL;
+  cf v[16];
+#pragma unroll
+  for (int j = 0; j < NRT; j++) {
+    const int idx = tid + NT * j;
+    const int c = idx & (NCOL - 1), row = idx >> 3;
+    v[j] = Rt[idx < cells ? row * 16 + c : 0];
+  }
+  cf bfs[W::F / NT];
+#pragma unroll
+  for (int j = 0; j < W::F / NT; j++) bfs[j] = a.bf[tid + NT * j];
+  cf tw1[15], tw3[16], ch[NR];
+  W::load_twiddles(t, a.tw, tw1, tw3);
+#pragma unroll
+  for (int k = 0; k < NR; k++) ch[k] = a.chirp[min(t + T * k, nD - 1)];
+#pragma unroll
+  for (int j = 0; j < NRT; j++) {
+    const int idx = tid + NT * j;
+    const int c = idx & (NCOL - 1), row = idx >> 3;
+    if (idx < cells) lds[c * DOPM_REGION + row] = v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < W::F / NT; j++) bfL[tid + NT * j] = bfs[j];
+  __syncthreads();
+
+  // phase 2: column -> registers (DC removal + chirp), transform, x kernel spectrum, inverse
+  const cf r0 = region[0];
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    const int i = t + T * k;
+    const cf rv = region[min(i, nD - 1)];
+    const cf p = cmul(csub(rv, r0), ch[k]);
+    v[k] = cmake(i < nD ? p.x : 0.f, i < nD ? p.y : 0.f);
+  }
+#pragma unroll
+  for (int k = NR; k < 16; k++) v[k] = cmake(0.f, 0.f);
+  __syncthreads(); // every thread of the column has taken its rows out of the region
+  W::fwd_s1(t, v, tw1, region);
+  __syncthreads();
+  W::fwd_s2_load(t, v, region);
+  dft16<-1>(v);
+  W::fwd_s2_store(t, v, region);
+  __syncthreads();
+  W::fwd_s3(t, v, tw3, region);
+#pragma unroll
+  for (int e = 0; e < 16; e++) v[e] = cmul(v[e], bfL[e * T + t]);
+  __syncthreads();
+  W::inv_s1(t, v, tw3, region);
+  __syncthreads();
+  W::inv_s2_load(t, v, region);
+  dft16<+1>(v);
+  W::inv_s2_store(t, v, region);
+  __syncthreads();
+  W::inv_s3(t, v, tw1, region);
+  __syncthreads();
+
+  // phase 3: rotate rows by nD/2+1 and park the column back in its region
+#pragma unroll
+  for (int c = 0; c < NR; c++) {
+    const int k = t + T * c;
+    cf d = cmul(v[c], ch[c]);
+    if (c == 0 && t == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
+    int o = k - (nD / 2 + 1);
+    if (o < 0) o += nD;
+    if (k < nD) region[o] = d;
+  }
+  __syncthreads();
+
+  // phase 4: coalesced row-segment stores + Map::set_metrics partials
+  double lsum = 0.0;
+  float lmax = 0.f;
+  cf *mapb = a.map + (size_t)cpi * nD * a.nDelay + col0;
+  const int ncol = min(NCOL, a.nDelay - col0);
+#pragma unroll
+  for (int j = 0; j < NRT; j++) {
+    const int idx = tid + NT * j;
+    const int c = idx & (NCOL - 1), o = idx >> 3;
+    const bool ok = idx < cells && c < ncol;
+    const cf d = lds[c * DOPM_REGION + min(o, nD - 1)];
+    if (ok) mapb[(size_t)o * a.nDelay + c] = d;
+    const float db = db_of(d);
+    lsum += ok ? (double)db : 0.0;
+    lmax = ok ? fmaxf(lmax, db) : lmax;
+  }
+  const size_t part = (size_t)cpi * gridDim.x + blockIdx.x;
+  __shared__ double wsum[16];
+  __shared__ float wmax[16];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lsum += __shfl_xor(lsum, off);
+    lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+  }
+  if ((tid & 63) == 0) { wsum[tid >> 6] = lsum; wmax[tid >> 6] = lmax; }
+  __syncthreads();
+  if (tid == 0) {
+    double sacc = 0.0;
+    float m = 0.f; // Map.cpp:193: the running max starts at 0
+    for (int i = 0; i < NT / 64; i++) { sacc += wsum[i]; m = fmaxf(m, wmax[i]); }
+    a.partSum[part] = sacc;
+    a.partMax[part] = m;
+  }
+}
+
 // Fallback for nD > 2049 (transform longer than the on-chip FFT covers):
 // direct DFT, lane <-> delay column, KPT output rows per thread, the 4 waves
 // split the pulse axis and reduce through LDS.  Same DC handling as above.

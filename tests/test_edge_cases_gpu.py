@@ -82,3 +82,11 @@ def test_zero_cells_poison_the_mean_like_the_reference(b2):
     m = amb.process(x, np.zeros(n, dtype=np.complex128))
     assert np.all(m.data == 0)
     assert m.noisePower == -np.inf
+
+
+def test_two_wave_doppler_tile_kernel(b2):
+    # 513 < nD <= 1025 with enough delay tiles to take the multi-wave tile kernel from a single
+    # CPI (csrc/kernels.hpp doppler_tilem_kernel): nD = 601 / 1025, ragged last tile (nDelay % 8 != 0)
+    for fmax, n, fs, dmax in [(300, 1_000_000, 1_000_000, 1100), (512, 2_000_000, 2_000_000, 1029)]:
+        amb = run(b2, (-5, dmax, -fmax, fmax, fs, n, True), seed=fmax)
+        assert amb.get_n_doppler_bins() == 2 * fmax + 1
