@@ -33,11 +33,17 @@ std::complex<double> IqData::pop_front()
 
 void IqData::pop_front_block(double *dst, uint32_t count)
 {
-  for (uint32_t i = 0; i < count; i++) {
-    const std::complex<double> s = pop_front();
-    dst[2 * i] = s.real();
-    dst[2 * i + 1] = s.imag();
+  // same observable behaviour as `count` calls of pop_front() (the FIFO is emptied and the
+  // same exception is thrown on underflow), without the per-sample bookkeeping
+  const size_t have = data->size();
+  const size_t take = have < count ? have : (size_t)count;
+  auto it = data->begin();
+  for (size_t i = 0; i < take; i++, ++it) {
+    dst[2 * i] = it->real();
+    dst[2 * i + 1] = it->imag();
   }
+  data->erase(data->begin(), data->begin() + (std::ptrdiff_t)take);
+  if (take < count) throw std::runtime_error("Attempting to pop from an empty deque");
 }
 
 void IqData::print()

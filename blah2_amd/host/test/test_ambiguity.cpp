@@ -14,6 +14,7 @@
 #include "process/detection/Interpolate.h"
 #include "process/meta/HammingNumber.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <random>
@@ -58,8 +59,12 @@ int main()
     IqData x{nSamples}, y{nSamples};
     random_iq(x, 1);
     random_iq(y, 2);
+    const auto t0 = std::chrono::steady_clock::now();
     auto map = ambiguity.process(&x, &y);
     map->set_metrics();
+    const auto t1 = std::chrono::steady_clock::now();
+    std::printf("Ambiguity::process(IqData*, IqData*) + set_metrics, %u samples: %.2f ms wall (FIFO pops, c64->c32, H2D, kernels, D2H, Map fill)\n",
+                nSamples, std::chrono::duration<double, std::milli>(t1 - t0).count());
     CHECK(map->maxPower > 0.0);
     CHECK(map->noisePower > 0.0);
     CHECK(x.get_length() == nSamples - 3322u * 301u); // process() consumes by pop_front
