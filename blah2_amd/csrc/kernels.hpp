@@ -1,10 +1,17 @@
 // HIP kernels of the blah2 cross-ambiguity engine (gfx950 / MI355X only).
 //
-//   range_kernel        Hot loop A  Ambiguity.cpp:106-149  (segmented on-chip FFT correlation)
-//   doppler_dft_kernel  Hot loop B  Ambiguity.cpp:152-169  (+ partial sums of Map::set_metrics)
-//   metrics_kernel      Map::set_metrics                    Map.cpp:187-206
-//   cfar1d_kernel       CfarDetector1D::process             CfarDetector1D.cpp:23-100
-//   rotate_kernel       Doppler-centre shift                Ambiguity.cpp:95-102
+//   range_kernel / range8_kernel   Hot loop A  Ambiguity.cpp:106-149  (segmented on-chip FFT correlation;
+//                                  16 / 8 points per thread)
+//   doppler_tile_kernel            Hot loop B  Ambiguity.cpp:152-169  nD <= 513, batched launches
+//   doppler_tilem_kernel                                              513 < nD <= 1025
+//   doppler_fft_kernel                                                nD <= 2049, one column per workgroup
+//   doppler_dft_kernel                                                direct fallback
+//                                  (all with the per-workgroup partial sums of Map::set_metrics)
+//   metrics_kernel                 Map::set_metrics                   Map.cpp:187-206
+//   cfar1d_kernel                  CfarDetector1D::process            CfarDetector1D.cpp:23-100
+//   sat_rows / sat_cols / cfar2d   2-D CA-CFAR (BASELINE configs[2]; extension)
+//   rotate_kernel                  Doppler-centre shift               Ambiguity.cpp:95-102
+// The clutter filter and the spectrum analyser live in clutter.hip / spectrum.hip.
 //
 // All paths are relative to /root/reference/src.
 #pragma once
