@@ -416,15 +416,16 @@ int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_mi
   HIPCHK(hipSetDevice(device));
 
   auto *h = new blah2hip_amb_s;
+  // everything that can fail runs inside `build`; a partially built handle is torn down by destroy()
+  auto build = [&]() -> int {
   h->device = device;
   h->delayMin = delay_min; h->delayMax = delay_max;
   h->dopplerMin = doppler_min; h->dopplerMax = doppler_max;
   h->fs = fs;
   derive_dims(h, n, round_hamming != 0);
   h->dims.max_batch = max_batch;
-  if (h->dims.n_corr == 0) { delete h; return fail(BLAH2HIP_ERR_INVALID, "nCorr == 0"); }
+  if (h->dims.n_corr == 0) return fail(BLAH2HIP_ERR_INVALID, "nCorr == 0");
   if (!choose_plan(h)) {
-    delete h;
     return fail(BLAH2HIP_ERR_UNSUPPORTED, "nDelayBins too large for the on-chip transform lengths (<= 4096)");
   }
   hipDeviceProp_t prop;
@@ -499,6 +500,13 @@ int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_mi
     HIPCHK(hipMemcpy(h->d_dtw, dtw.data(), dtw.size() * sizeof(cf), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_chirp, chirp.data(), chirp.size() * sizeof(cf), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_bf, bf.data(), bf.size() * sizeof(cf), hipMemcpyHostToDevice));
+  }
+  return BLAH2HIP_OK;
+  };
+  const int rc = build();
+  if (rc != BLAH2HIP_OK) {
+    blah2hip_amb_destroy(h);
+    return rc;
   }
   *out = h;
   return BLAH2HIP_OK;

@@ -485,6 +485,8 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
   if ((size_t)4 * nBins * sizeof(dcx) > 160 * 1024 - 64)
     CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip Toeplitz solve");
   auto *h = new blah2hip_clutter_s;
+  // everything that can fail runs inside `build`; a partially built handle is torn down by destroy()
+  auto build = [&]() -> int {
   h->device = device;
   h->delayMin = delay_min; h->delayMax = delay_max;
   h->N = n_samples; h->maxBatch = max_batch; h->nBins = nBins;
@@ -508,6 +510,13 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
   CHIP(hipMalloc(&h->d_rb, (size_t)max_batch * 2 * nBins * sizeof(dcx)));
   CHIP(hipMalloc(&h->d_w, (size_t)max_batch * nBins * sizeof(cf)));
   CHIP(hipMalloc(&h->d_ok, max_batch * sizeof(int32_t)));
+  return BLAH2HIP_OK;
+  };
+  const int rc = build();
+  if (rc != BLAH2HIP_OK) {
+    blah2hip_clutter_destroy(h);
+    return rc;
+  }
   *out = h;
   return BLAH2HIP_OK;
 }

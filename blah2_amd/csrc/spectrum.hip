@@ -200,6 +200,8 @@ int blah2hip_spectrum_create(uint32_t n_samples, double bandwidth, int device, u
   if (device < 0 || device >= count) SFAIL(BLAH2HIP_ERR_NO_DEVICE, "no such HIP device");
   SHIP(hipSetDevice(device));
   auto *h = new blah2hip_spectrum_s;
+  // everything that can fail runs inside `build`; a partially built handle is torn down by destroy()
+  auto build = [&]() -> int {
   h->device = device;
   h->n = n_samples;
   h->bandwidth = bandwidth;
@@ -226,6 +228,13 @@ int blah2hip_spectrum_create(uint32_t n_samples, double bandwidth, int device, u
   SHIP(hipMemcpy(h->d_wD, wD.data(), D * sizeof(dcx), hipMemcpyHostToDevice));
   SHIP(hipMemcpy(h->d_wS, wS.data(), nS * sizeof(dcx), hipMemcpyHostToDevice));
   SHIP(blah2hip_ensure_lds_((const void *)spectrum_dft_kernel, (int)(2 * 4096 * sizeof(dcx))));
+  return BLAH2HIP_OK;
+  };
+  const int rc = build();
+  if (rc != BLAH2HIP_OK) {
+    blah2hip_spectrum_destroy(h);
+    return rc;
+  }
   *out = h;
   return BLAH2HIP_OK;
 }
