@@ -89,7 +89,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="CPIs per step (per GPU); default 128 for the 2 MS/s configs (4 GB of IQ per step: a pulse is "
                          "the scheduling unit of the range kernel and 128 x 513 pulses leave a 1.5 %% tail on 1024 "
-                         "resident workgroups, 32 x 513 leave 6 %%), 8 for cfg3")
+                         "resident workgroups, 32 x 513 leave 6 %%), 8 for cfg3 (64 with --chain full: the Toeplitz solve costs "
+                         "a fixed ~8 ms per launch there)")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--fmt", default="c32", choices=["c32", "i16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -119,7 +120,7 @@ def main():
 
     cfg = CONFIGS[a.config]
     dmin, dmax, fmin, fmax, fs, n = cfg
-    B = a.batch if a.batch > 0 else (8 if a.config == "cfg3" else 128)
+    B = a.batch if a.batch > 0 else ((64 if a.chain == "full" else 8) if a.config == "cfg3" else 128)
     NS = max(1, a.streams) if a.chain == "amb" else 1
     ambs = [blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B) for _ in range(NS)]
     amb = ambs[0]

@@ -852,29 +852,37 @@ struct Cfar2dArgs {
   uint32_t cap;
 };
 
-// row-wise inclusive prefix of |z|^2 (column 0 zeroed) into sat[i+1][1..]
+// row-wise inclusive prefix of |z|^2 (column 0 zeroed) into sat[i+1][1..]: the row is
+// walked in coalesced chunks of 256 cells; inside a chunk a wave scans with shuffles,
+// the four wave totals and the running carry are combined through LDS.
 __global__ __launch_bounds__(256) void sat_rows_kernel(Cfar2dArgs a)
 {
-  __shared__ double tot[256];
+  __shared__ double wtot[2][4];
   const int row = blockIdx.x, cpi = blockIdx.y, t = threadIdx.x;
+  const int lane = t & 63, wv = t >> 6;
   const cf *z = a.map + ((size_t)cpi * a.nD + row) * a.nDelay;
   double *out = a.sat + ((size_t)cpi * (a.nD + 1) + row + 1) * (a.nDelay + 1) + 1;
-  const int per = (a.nDelay + 255) / 256;
-  const int j0 = t * per, j1 = min(a.nDelay, j0 + per);
-  double run = 0.0;
-  for (int j = j0; j < j1; j++) {
-    const cf c = z[j];
-    run += (j == 0) ? 0.0 : (double)c.x * (double)c.x + (double)c.y * (double)c.y;
-  }
-  tot[t] = run;
-  __syncthreads();
-  double off = 0.0;
-  for (int i = 0; i < t; i++) off += tot[i]; // 256-entry serial prefix per thread: tiny
-  run = off;
-  for (int j = j0; j < j1; j++) {
-    const cf c = z[j];
-    run += (j == 0) ? 0.0 : (double)c.x * (double)c.x + (double)c.y * (double)c.y;
-    out[j] = run;
+  double carry = 0.0;
+  int buf = 0;
+  for (int j0 = 0; j0 < a.nDelay; j0 += 256, buf ^= 1) {
+    const int j = j0 + t;
+    double val = 0.0;
+    if (j < a.nDelay && j != 0) {
+      const cf c = z[j];
+      val = (double)c.x * (double)c.x + (double)c.y * (double)c.y;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double n = __shfl_up(val, off);
+      if (lane >= off) val += n;
+    }
+    if (lane == 63) wtot[buf][wv] = val;
+    __syncthreads(); // double-buffered totals: one barrier per chunk is enough
+    double pre = carry;
+#pragma unroll
+    for (int w = 0; w < 4; w++) pre += (w < wv) ? wtot[buf][w] : 0.0;
+    if (j < a.nDelay) out[j] = val + pre;
+    carry += (wtot[buf][0] + wtot[buf][1]) + (wtot[buf][2] + wtot[buf][3]);
   }
 }
 
