@@ -210,66 +210,82 @@ __device__ __forceinline__ double wave_sum(double v)
 //     x <- x + (b[m] - ex) * conj(rev f)
 // The matrix is positive definite iff r[0] > 0 and every 1 - |ef|^2 > 0 -- the
 // condition under which the reference's chol() succeeds (WienerHopf.cpp:111).
-// ONE wave per CPI: the recursion is a chain of nBins dependent steps, so what
-// matters is the latency of a step; a single wave needs no barriers and reduces
-// with DPP.  All four vectors live in LDS.
-// (A fully unrolled variant with clamped unconditional LDS reads was measured
-// slower: it always touches 64*NPL elements, while the average order is n/2.)
-__global__ __launch_bounds__(64) void clutter_solve_kernel(SolveArgs a)
+// One workgroup of 4 waves per CPI.  The recursion is a chain of nBins dependent
+// steps, so what matters is the latency of a step: a single wave (the first version)
+// needs no barriers but streams ~6m 16-byte LDS accesses per step through one wave's
+// LDS issue rate (505 us for nBins = 410, 7.7 ms for 2047); four waves split that
+// traffic for the price of two workgroup barriers per step.  All four vectors live in
+// LDS.  (A fully unrolled variant with clamped unconditional LDS reads was measured
+// slower: it always touches every element, while the average order is n/2.)
+constexpr int SOLVE_WAVES = 4;
+
+__global__ __launch_bounds__(64 * SOLVE_WAVES) void clutter_solve_kernel(SolveArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[2][SOLVE_WAVES][4];
   const int n = a.nBins;
   dcx *f = reinterpret_cast<dcx *>(smem);
   dcx *xv = f + n;
   dcx *r = xv + n;
   dcx *b = r + n;
   const int cpi = blockIdx.x;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, wv = t >> 6;
+  constexpr int NT = 64 * SOLVE_WAVES;
   const dcx *rg = a.rb + (size_t)cpi * 2 * n;
-  for (int k = t; k < n; k += 64) {
+  for (int k = t; k < n; k += NT) {
     r[k] = rg[k];
     b[k] = rg[n + k];
     f[k] = {0.0, 0.0};
     xv[k] = {0.0, 0.0};
   }
-  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
   const double r0 = r[0].x;
   bool ok = (r0 > 0.0) && isfinite(r0);
   if (ok && t == 0) {
     f[0] = {1.0 / r0, 0.0};
     xv[0] = {b[0].x / r0, b[0].y / r0};
   }
-  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
+  // Two barriers per order: (A) partial dot products -> wave sums -> LDS, (B) every pair
+  // (i, m-i) is updated by one thread, which holds the old f[i], f[m-i] and therefore also
+  // the NEW f[m-i], f[i] that the solution update x[i] += d*conj(f_new[m-i]) needs.
   for (int m = 1; m < n && ok; m++) {
     double efx = 0.0, efy = 0.0, exx = 0.0, exy = 0.0;
-    for (int i = t; i < m; i += 64) {
+    for (int i = t; i < m; i += NT) {
       const dcx rr = r[m - i];
       const dcx p1 = dmul(rr, f[i]), p2 = dmul(rr, xv[i]);
       efx += p1.x; efy += p1.y;
       exx += p2.x; exy += p2.y;
     }
-    const dcx ef = {wave_sum(efx), wave_sum(efy)};
-    const dcx ex = {wave_sum(exx), wave_sum(exy)};
+    efx = wave_sum(efx); efy = wave_sum(efy); exx = wave_sum(exx); exy = wave_sum(exy);
+    double (*rd)[4] = red[m & 1];
+    if ((t & 63) == 0) { rd[wv][0] = efx; rd[wv][1] = efy; rd[wv][2] = exx; rd[wv][3] = exy; }
+    __syncthreads();
+    dcx ef = {0.0, 0.0}, ex = {0.0, 0.0};
+#pragma unroll
+    for (int w = 0; w < SOLVE_WAVES; w++) { ef.x += rd[w][0]; ef.y += rd[w][1]; ex.x += rd[w][2]; ex.y += rd[w][3]; }
     const double denom = 1.0 - (ef.x * ef.x + ef.y * ef.y);
-    if (!(denom > 0.0) || !isfinite(denom)) { ok = false; break; } // uniform
+    if (!(denom > 0.0) || !isfinite(denom)) { ok = false; break; } // uniform: every thread sees the same sums
     const double inv = 1.0 / denom;
-    // pairs (i, m-i) are independent; f[m] = 0 before the update
-    for (int i = t; 2 * i <= m; i += 64) {
-      const int j = m - i;
-      const dcx fi = f[i], fj = (j < m) ? f[j] : dcx{0.0, 0.0};
-      const dcx ti = dmul(ef, dconj(fj)), tj = dmul(ef, dconj(fi));
-      f[i] = {(fi.x - ti.x) * inv, (fi.y - ti.y) * inv};
-      if (j != i) f[j] = {(fj.x - tj.x) * inv, (fj.y - tj.y) * inv};
-    }
-    __builtin_amdgcn_wave_barrier();
     const dcx d = {b[m].x - ex.x, b[m].y - ex.y};
-    for (int i = t; i <= m; i += 64) {
-      const dcx p = dmul(d, dconj(f[m - i]));
-      xv[i] = {xv[i].x + p.x, xv[i].y + p.y};
+    for (int i = t; 2 * i <= m; i += NT) {
+      const int j = m - i;
+      const dcx fi = f[i], fj = (j < m) ? f[j] : dcx{0.0, 0.0}; // f[m] = 0 before the update
+      const dcx ti = dmul(ef, dconj(fj)), tj = dmul(ef, dconj(fi));
+      const dcx ni = {(fi.x - ti.x) * inv, (fi.y - ti.y) * inv};
+      const dcx nj = {(fj.x - tj.x) * inv, (fj.y - tj.y) * inv};
+      const dcx pi = dmul(d, dconj(nj)), pj = dmul(d, dconj(ni));
+      const dcx xi = xv[i], xj = xv[j];
+      f[i] = ni;
+      xv[i] = {xi.x + pi.x, xi.y + pi.y};
+      if (j != i) {
+        f[j] = nj;
+        xv[j] = {xj.x + pj.x, xj.y + pj.y};
+      }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
-  for (int k = t; k < n; k += 64) a.w[(size_t)cpi * n + k] = ok ? cmake((float)xv[k].x, (float)xv[k].y) : cmake(0.f, 0.f);
+  for (int k = t; k < n; k += NT) a.w[(size_t)cpi * n + k] = ok ? cmake((float)xv[k].x, (float)xv[k].y) : cmake(0.f, 0.f);
   if (t == 0) a.ok[cpi] = ok ? 1 : 0;
 }
 
@@ -409,7 +425,7 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   // once per (device, kernel), see capi.hip
   CHIP(blah2hip_ensure_lds_((const void *)clutter_corr_kernel<R3>, (int)lds));
   CHIP(blah2hip_ensure_lds_((const void *)clutter_fir_kernel<R3>, (int)lds));
-  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel, 160 * 1024 - 64));
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel, 160 * 1024 - 512));
   XsMap xs;
   xs.N = h->N;
   xs.thresh = h->delayMin > 0 ? (uint32_t)h->delayMin : 0u;
@@ -433,7 +449,7 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   sa.partial = h->d_partial; sa.rb = h->d_rb; sa.w = h->d_w; sa.ok = ok; sa.nBins = h->nBins; sa.nJobs = nJobs;
   hipLaunchKernelGGL(clutter_reduce_kernel, dim3((h->nBins + 255) / 256, 2, nCpi), dim3(256), 0, st, sa);
   const size_t sl = (size_t)4 * h->nBins * sizeof(dcx);
-  hipLaunchKernelGGL(clutter_solve_kernel, dim3(nCpi), dim3(64), sl, st, sa);
+  hipLaunchKernelGGL(clutter_solve_kernel, dim3(nCpi), dim3(64 * SOLVE_WAVES), sl, st, sa);
   CHIP(hipGetLastError());
 
   FirArgs fa;
@@ -482,7 +498,7 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
   }
   if (!bestR3) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip transform lengths (<= 4096)");
   // the solve keeps four fp64 vectors of nBins in LDS
-  if ((size_t)4 * nBins * sizeof(dcx) > 160 * 1024 - 64)
+  if ((size_t)4 * nBins * sizeof(dcx) > 160 * 1024 - 512)
     CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip Toeplitz solve");
   auto *h = new blah2hip_clutter_s;
   // everything that can fail runs inside `build`; a partially built handle is torn down by destroy()
