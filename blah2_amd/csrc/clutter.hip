@@ -217,8 +217,7 @@ __device__ __forceinline__ double wave_sum(double v)
 // traffic for the price of two workgroup barriers per step.  All four vectors live in
 // LDS.  (A fully unrolled variant with clamped unconditional LDS reads was measured
 // slower: it always touches every element, while the average order is n/2.)
-constexpr int SOLVE_WAVES = 4;
-
+template <int SOLVE_WAVES>
 __global__ __launch_bounds__(64 * SOLVE_WAVES) void clutter_solve_kernel(SolveArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -425,7 +424,9 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   // once per (device, kernel), see capi.hip
   CHIP(blah2hip_ensure_lds_((const void *)clutter_corr_kernel<R3>, (int)lds));
   CHIP(blah2hip_ensure_lds_((const void *)clutter_fir_kernel<R3>, (int)lds));
-  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel, 160 * 1024 - 512));
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<4>, 160 * 1024 - 2048));
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<8>, 160 * 1024 - 2048));
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<16>, 160 * 1024 - 2048));
   XsMap xs;
   xs.N = h->N;
   xs.thresh = h->delayMin > 0 ? (uint32_t)h->delayMin : 0u;
@@ -449,7 +450,12 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   sa.partial = h->d_partial; sa.rb = h->d_rb; sa.w = h->d_w; sa.ok = ok; sa.nBins = h->nBins; sa.nJobs = nJobs;
   hipLaunchKernelGGL(clutter_reduce_kernel, dim3((h->nBins + 255) / 256, 2, nCpi), dim3(256), 0, st, sa);
   const size_t sl = (size_t)4 * h->nBins * sizeof(dcx);
-  hipLaunchKernelGGL(clutter_solve_kernel, dim3(nCpi), dim3(64 * SOLVE_WAVES), sl, st, sa);
+  // waves per CPI: more waves split the per-order LDS traffic, fewer keep the barriers cheap
+  static const int swEnv = [] { const char *e = std::getenv("BLAH2HIP_SOLVE_WAVES"); return e ? std::atoi(e) : 0; }();
+  const int sw = swEnv ? swEnv : (h->nBins > 1024 ? 8 : 4); // measured: 410 orders 408 / 481 / 743 us, 2047 orders 3128 / 3023 / 4507 us with 4 / 8 / 16 waves
+  if (sw == 16) hipLaunchKernelGGL(clutter_solve_kernel<16>, dim3(nCpi), dim3(1024), sl, st, sa);
+  else if (sw == 8) hipLaunchKernelGGL(clutter_solve_kernel<8>, dim3(nCpi), dim3(512), sl, st, sa);
+  else hipLaunchKernelGGL(clutter_solve_kernel<4>, dim3(nCpi), dim3(256), sl, st, sa);
   CHIP(hipGetLastError());
 
   FirArgs fa;
@@ -498,7 +504,7 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
   }
   if (!bestR3) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip transform lengths (<= 4096)");
   // the solve keeps four fp64 vectors of nBins in LDS
-  if ((size_t)4 * nBins * sizeof(dcx) > 160 * 1024 - 512)
+  if ((size_t)4 * nBins * sizeof(dcx) > 160 * 1024 - 2048)
     CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip Toeplitz solve");
   auto *h = new blah2hip_clutter_s;
   // everything that can fail runs inside `build`; a partially built handle is torn down by destroy()
