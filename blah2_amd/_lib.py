@@ -52,6 +52,7 @@ SYMBOLS = {
     "blah2hip_amb_process_i16": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "blah2hip_amb_process_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _u32, C.c_uint64, _vp, _vp, _vp]),
     "blah2hip_amb_read_last": (C.c_int, [_vp, _u32, _vp, _vp]),
+    "blah2hip_amb_db_dev": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp]),
     "blah2hip_cfar1d_dev": (C.c_int, [_vp, _vp, _vp, _u32, _dbl, _i32, _i32, _i32, _dbl, _vp, _u32, _vp, _vp]),
     "blah2hip_cfar1d_process": (C.c_int, [_vp, _u32, _dbl, _i32, _i32, _i32, _dbl, _vp, _vp, _vp, _u32, C.POINTER(_u32)]),
     "blah2hip_cfar2d_dev": (C.c_int, [_vp, _vp, _vp, _u32, _dbl, _i32, _i32, _i32, _i32, _i32, _dbl, _vp, _u32, _vp, _vp]),

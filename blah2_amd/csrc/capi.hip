@@ -687,6 +687,21 @@ int blah2hip_amb_read_last(blah2hip_amb_t h, uint32_t cpi, float *map_out, doubl
   return BLAH2HIP_OK;
 }
 
+int blah2hip_amb_db_dev(blah2hip_amb_t h, const void *d_map, const double *d_metrics, uint32_t n_cpi, float *d_db,
+                        void *stream)
+{
+  if (!h || !d_db) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (n_cpi == 0 || n_cpi > h->dims.max_batch) return fail(BLAH2HIP_ERR_INVALID, "n_cpi outside [1, max_batch]");
+  HIPCHK(hipSetDevice(h->device));
+  const uint32_t cells = h->dims.n_doppler_bins * h->dims.n_delay_bins;
+  const cf *map = d_map ? (const cf *)d_map : h->d_map;
+  const double *met = d_metrics ? d_metrics : h->d_metrics;
+  const int gx = (int)std::min<uint32_t>((cells + 255) / 256, 4u * (uint32_t)h->numCU);
+  hipLaunchKernelGGL(db_map_kernel, dim3(gx, n_cpi), dim3(256), 0, (hipStream_t)stream, map, met, d_db, cells);
+  HIPCHK(hipGetLastError());
+  return BLAH2HIP_OK;
+}
+
 int blah2hip_amb_process_c32(blah2hip_amb_t h, const float *x, const float *y, uint32_t n,
                              float *map_out, double *metrics)
 {

@@ -781,6 +781,17 @@ __global__ void metrics_kernel(const double *partSum, const float *partMax, int 
 // sum runs in the reference's index order (leading cells need k > 0, trailing
 // k >= 0, :61,:68).  alpha[n] = n*(pfa^(-1/n)-1) is tabulated on the host with
 // the same libm pow the reference calls (:76).  Hits are appended through a
+// Map::to_json's cell values (Map.cpp:115-185): db[i] = 10*log10|z| - noisePower as fp32,
+// half the bytes of the complex map for a front-end that only plots.
+__global__ __launch_bounds__(256) void db_map_kernel(const cf *map, const double *metrics, float *db, uint32_t cells)
+{
+  const uint32_t cpi = blockIdx.y;
+  const float noise = (float)metrics[2 * cpi];
+  const cf *z = map + (size_t)cpi * cells;
+  float *o = db + (size_t)cpi * cells;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += gridDim.x * blockDim.x) o[i] = db_of(z[i]) - noise;
+}
+
 // per-CPI atomic counter; the host API sorts them into row-major order.
 struct CfarArgs {
   const cf *map;         // [nCpi][nD][nDelay]

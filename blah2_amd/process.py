@@ -173,6 +173,10 @@ class Ambiguity:
         check(self._L.blah2hip_amb_read_last(self._h, cpi, _ptr(out), _ptr(met)))
         return self._result(out, met, cpi)
 
+    def db_dev(self, d_map, d_metrics, n_cpi, d_db, stream=0):
+        """Enqueue the fp32 dB map Map::to_json prints (10*log10|M| - noisePower) for n_cpi maps."""
+        check(self._L.blah2hip_amb_db_dev(self._h, d_map, d_metrics, n_cpi, d_db, stream))
+
     # -- per-kernel timing -----------------------------------------------------
     def set_timing(self, enable=True):
         check(self._L.blah2hip_amb_set_timing(self._h, 1 if enable else 0))

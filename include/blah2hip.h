@@ -123,6 +123,11 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
                              void *stream);
 /* copies CPI `cpi` of the handle's internal map/metrics to the host (synchronises) */
 int blah2hip_amb_read_last(blah2hip_amb_t h, uint32_t cpi, float *map_out, double *metrics);
+/* The values Map::to_json prints (Map.cpp:148-155): d_db[cpi][doppler][delay] =
+ * 10*log10|M| - noisePower as fp32, from d_map/d_metrics as written by
+ * blah2hip_amb_process_dev (NULL = the handle's internal buffers).  Enqueues only. */
+int blah2hip_amb_db_dev(blah2hip_amb_t h, const void *d_map, const double *d_metrics, uint32_t n_cpi,
+                        float *d_db, void *stream);
 
 /* ---- CfarDetector1D (CfarDetector1D.h:46-55) ---------------------------- */
 /* dev: d_map/d_metrics as written by blah2hip_amb_process_dev (NULL = the

@@ -197,3 +197,25 @@ def test_json_db_map_within_half_a_hundredth(b2, args):
     got_db = 10.0 * np.log10(np.abs(m.data.astype(np.complex128))) - m.noisePower
     ref_db = 10.0 * np.log10(np.abs(ref)) - noise
     assert np.max(np.abs(got_db - ref_db)) <= 0.005
+
+
+def test_device_db_map_matches_to_json_values(b2):
+    """blah2hip_amb_db_dev: the fp32 dB map a front-end plots, for a batch, against the fp64
+    oracle's Map::to_json values (same 0.005 dB gate)."""
+    torch = pytest.importorskip("torch")
+    g = load_golden("medium")
+    fs, n, dmin, dmax, fmin, fmax, rh = (int(v) for v in g["params"])
+    B = 2
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, bool(rh), max_batch=B)
+    x = torch.from_numpy(np.stack([g["x"], g["x"]]).astype(np.complex64)).cuda()
+    y = torch.from_numpy(np.stack([g["y"], 2 * g["y"]]).astype(np.complex64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    amb.process_dev(b2.FMT_C32, x.data_ptr(), y.data_ptr(), B, n, None, None, st)
+    nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
+    db = torch.zeros((B, nD, nC), dtype=torch.float32, device="cuda")
+    amb.db_dev(None, None, B, db.data_ptr(), st)
+    torch.cuda.synchronize()
+    want = 10.0 * np.log10(np.abs(g["map"])) - g["metrics"][0]
+    got = db.cpu().numpy()
+    assert np.max(np.abs(got[0] - want)) <= 0.005
+    assert np.max(np.abs(got[1] - want)) <= 0.005  # scaling y shifts |M| and noisePower alike
