@@ -27,6 +27,7 @@ CONFIGS = {
     "cfg2": (-10, 400, -256, 256, 2_000_000, 2_000_000),
     "test": (-10, 300, -300, 300, 2_000_000, 1_000_000),
     "cfg3": (-24, 2023, -512, 512, 10_000_000, 10_000_000),
+    "cfg5": (-10, 400, -512, 512, 20_000_000, 40_000_000),  # 2 s CPI -> 2049 Doppler bins; use --fmt f16
 }
 
 
@@ -92,7 +93,7 @@ def main():
                          "resident workgroups, 32 x 513 leave 6 %%), 8 for cfg3 (64 with --chain full: the Toeplitz solve costs "
                          "a fixed ~8 ms per launch there)")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--fmt", default="c32", choices=["c32", "i16"])
+    ap.add_argument("--fmt", default="c32", choices=["c32", "i16", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chain", default="amb", choices=["amb", "full"],
                     help="amb: range+Doppler+metrics (BASELINE headline); full: clutter filter + amb + CFAR (configs[2])")
@@ -120,7 +121,7 @@ def main():
 
     cfg = CONFIGS[a.config]
     dmin, dmax, fmin, fmax, fs, n = cfg
-    B = a.batch if a.batch > 0 else ((64 if a.chain == "full" else 8) if a.config == "cfg3" else 128)
+    B = a.batch if a.batch > 0 else ({"cfg3": 64 if a.chain == "full" else 8, "cfg5": 4}.get(a.config, 128))
     NS = max(1, a.streams) if a.chain == "amb" else 1
     ambs = [blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B) for _ in range(NS)]
     amb = ambs[0]
@@ -140,6 +141,9 @@ def main():
         if a.fmt == "c32":
             xs.append(x)
             ys.append(y)
+        elif a.fmt == "f16":  # half-precision storage of the int16-valued IQ (exact up to 2048, rounded above)
+            xs.append(torch.view_as_real(x).to(torch.float16).contiguous())
+            ys.append(torch.view_as_real(y).to(torch.float16).contiguous())
         else:
             iq = torch.stack([x.real, x.imag, y.real, y.imag], dim=-1).to(torch.int16).contiguous()
             iqs.append(iq)
@@ -172,10 +176,10 @@ def main():
             else:
                 blah2_amd._lib.check(L.blah2hip_cfar1d_dev(amb._h, out.data_ptr(), met.data_ptr(), B, 1e-5, 2, 6, 5, 15.0,
                                                            hits.data_ptr(), 65536, hitcnt.data_ptr(), st))
-        elif a.fmt == "c32":
+        elif a.fmt in ("c32", "f16"):
             q = i % NS
-            ambs[q].process_dev(blah2_amd.FMT_C32, xs[r].data_ptr(), ys[r].data_ptr(), B, n, outs[q].data_ptr(),
-                                mets[q].data_ptr(), sts[q])
+            ambs[q].process_dev(blah2_amd.FMT_C32 if a.fmt == "c32" else blah2_amd.FMT_F16, xs[r].data_ptr(), ys[r].data_ptr(),
+                                B, n, outs[q].data_ptr(), mets[q].data_ptr(), sts[q])
         else:
             q = i % NS
             ambs[q].process_dev(blah2_amd.FMT_I16, iqs[r].data_ptr(), 0, B, n, outs[q].data_ptr(), mets[q].data_ptr(), sts[q])
