@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--chain", default="amb", choices=["amb", "full"],
                     help="amb: range+Doppler+metrics (BASELINE headline); full: clutter filter + amb + CFAR (configs[2])")
     ap.add_argument("--cfar", default="2d", choices=["1d", "2d"])
+    ap.add_argument("--n-doppler", type=int, default=0,
+                    help="explicit number of Doppler bins (extension; 0 = the reference constructor's rule, which gives "
+                         "513 at the headline configuration; 512 gives the literal BASELINE wording)")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent CPI streams per GPU (engine handles on their own HIP streams); successive "
                          "steps alternate between them so one batch's Doppler stage overlaps the next batch's range stage")
@@ -123,7 +126,8 @@ def main():
     dmin, dmax, fmin, fmax, fs, n = cfg
     B = a.batch if a.batch > 0 else ({"cfg3": 64 if a.chain == "full" else 8, "cfg5": 4}.get(a.config, 128))
     NS = max(1, a.streams) if a.chain == "amb" else 1
-    ambs = [blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B) for _ in range(NS)]
+    ambs = [blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B, n_doppler_bins=a.n_doppler)
+            for _ in range(NS)]
     amb = ambs[0]
     nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
     cells = nD * nC

@@ -44,6 +44,7 @@ SYMBOLS = {
     "blah2hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "blah2hip_next_hamming": (_u32, [_u32]),
     "blah2hip_amb_create": (C.c_int, [_i32, _i32, _i32, _i32, _u32, _u32, C.c_int, C.c_int, _u32, C.POINTER(_vp)]),
+    "blah2hip_amb_create_ex": (C.c_int, [_i32, _i32, _i32, _i32, _u32, _u32, C.c_int, _u32, C.c_int, _u32, C.POINTER(_vp)]),
     "blah2hip_amb_destroy": (C.c_int, [_vp]),
     "blah2hip_amb_get_dims": (C.c_int, [_vp, C.POINTER(AmbDims)]),
     "blah2hip_amb_get_axes": (C.c_int, [_vp, _vp, _vp]),

@@ -117,7 +117,7 @@ namespace {
 // ---------------------------------------------------------------- planning --
 // Ambiguity::Ambiguity, Ambiguity.cpp:11-82 (same fp64 expressions, same
 // uint16 narrowing of nDelayBins / nDopplerBins / nCorr, Ambiguity.h:80-89)
-void derive_dims(blah2hip_amb_s *h, uint32_t n, bool roundHamming)
+void derive_dims(blah2hip_amb_s *h, uint32_t n, bool roundHamming, uint32_t nDopplerExplicit)
 {
   auto &d = h->dims;
   d.n_samples = n;
@@ -133,6 +133,9 @@ void derive_dims(blah2hip_amb_s *h, uint32_t n, bool roundHamming)
     i++;
   }
   d.n_doppler_bins = (uint16_t)doppler.size();
+  // extension: an explicit bin count, e.g. exactly 512; everything below is the
+  // reference's arithmetic with that count, including the shift (j + nD/2 + 1) % nD of :165
+  if (nDopplerExplicit) d.n_doppler_bins = (uint16_t)nDopplerExplicit;
   d.n_corr = (uint16_t)(n / d.n_doppler_bins);
   d.cpi = ((double)d.n_corr * d.n_doppler_bins) / h->fs;
   res = 1.0 / d.cpi;
@@ -143,7 +146,7 @@ void derive_dims(blah2hip_amb_s *h, uint32_t n, bool roundHamming)
   i = 1;
   while (ax.size() < d.n_doppler_bins) {
     ax.push_back(d.doppler_middle + (i * res));
-    ax.push_front(d.doppler_middle - (i * res));
+    if (ax.size() < d.n_doppler_bins) ax.push_front(d.doppler_middle - (i * res)); // even counts: the extra bin is the last one
     i++;
   }
   h->dopplerAxis.assign(ax.begin(), ax.end());
@@ -400,6 +403,13 @@ int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_mi
                         int32_t doppler_max, uint32_t fs, uint32_t n, int round_hamming, int device,
                         uint32_t max_batch, blah2hip_amb_t *out)
 {
+  return blah2hip_amb_create_ex(delay_min, delay_max, doppler_min, doppler_max, fs, n, round_hamming, 0, device, max_batch, out);
+}
+
+int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler_min,
+                           int32_t doppler_max, uint32_t fs, uint32_t n, int round_hamming,
+                           uint32_t n_doppler_bins, int device, uint32_t max_batch, blah2hip_amb_t *out)
+{
   if (!out) return fail(BLAH2HIP_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (fs == 0 || n == 0) return fail(BLAH2HIP_ERR_INVALID, "fs and n must be positive");
@@ -408,6 +418,7 @@ int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_mi
   // the reference's lag gather (Ambiguity.cpp:132-146) is only in range for these
   if (delay_min > 1 || delay_max < -1)
     return fail(BLAH2HIP_ERR_UNSUPPORTED, "reference requires delayMin <= 1 and delayMax >= -1");
+  if (n_doppler_bins > 65535u || n_doppler_bins > n) return fail(BLAH2HIP_ERR_INVALID, "explicit Doppler bin count outside [1, min(65535, n)]");
   if (max_batch == 0) max_batch = 1;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -422,7 +433,7 @@ int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_mi
   h->delayMin = delay_min; h->delayMax = delay_max;
   h->dopplerMin = doppler_min; h->dopplerMax = doppler_max;
   h->fs = fs;
-  derive_dims(h, n, round_hamming != 0);
+  derive_dims(h, n, round_hamming != 0, n_doppler_bins);
   h->dims.max_batch = max_batch;
   if (h->dims.n_corr == 0) return fail(BLAH2HIP_ERR_INVALID, "nCorr == 0");
   if (!choose_plan(h)) {

@@ -72,11 +72,13 @@ class Ambiguity:
     """src/process/ambiguity/Ambiguity.h:34-58."""
 
     def __init__(self, delayMin, delayMax, dopplerMin, dopplerMax, fs, n, roundHamming=False,
-                 device=0, max_batch=1):
+                 device=0, max_batch=1, n_doppler_bins=0):
+        """``n_doppler_bins`` (extension): an explicit number of Doppler bins, e.g. exactly 512;
+        0 = the reference's rule (always odd)."""
         L = _lib.load()
         h = C.c_void_p()
-        check(L.blah2hip_amb_create(delayMin, delayMax, dopplerMin, dopplerMax, fs, n,
-                                    1 if roundHamming else 0, device, max_batch, C.byref(h)))
+        check(L.blah2hip_amb_create_ex(delayMin, delayMax, dopplerMin, dopplerMax, fs, n,
+                                       1 if roundHamming else 0, n_doppler_bins, device, max_batch, C.byref(h)))
         self._h = h
         self._L = L
         self.dims = AmbDims()

@@ -96,6 +96,15 @@ uint32_t blah2hip_next_hamming(uint32_t v);
 int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_min,
                         int32_t doppler_max, uint32_t fs, uint32_t n, int round_hamming,
                         int device, uint32_t max_batch, blah2hip_amb_t *out);
+/* Extension (not in the reference, whose constructor only yields odd counts): the same
+ * engine with an EXPLICIT number of Doppler bins / pulses, n_doppler_bins (0 = the
+ * reference's rule).  nCorr = n / n_doppler_bins, cpi, both axes and the row shift
+ * (j + nD/2 + 1) % nD of Ambiguity.cpp:165 follow from it unchanged; for an even count
+ * the Nyquist bin is the last row.  This is how "512 / 1024 / 2048 Doppler bins" of
+ * BASELINE.json can be had literally. */
+int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler_min, int32_t doppler_max,
+                           uint32_t fs, uint32_t n, int round_hamming, uint32_t n_doppler_bins,
+                           int device, uint32_t max_batch, blah2hip_amb_t *out);
 int blah2hip_amb_destroy(blah2hip_amb_t h);
 int blah2hip_amb_get_dims(blah2hip_amb_t h, blah2hip_amb_dims_t *dims);
 /* Map::delay (bins, length n_delay_bins) and Map::doppler (Hz, length n_doppler_bins) */

@@ -77,7 +77,7 @@ class AmbiguityDims:
     doppler: np.ndarray = field(default_factory=lambda: np.zeros(0))
 
 
-def ambiguity_dims(delay_min, delay_max, doppler_min, doppler_max, fs, n, round_hamming=False):
+def ambiguity_dims(delay_min, delay_max, doppler_min, doppler_max, fs, n, round_hamming=False, n_doppler_bins=0):
     d = AmbiguityDims(int(delay_min), int(delay_max), int(doppler_min), int(doppler_max),
                       int(fs), int(n), bool(round_hamming))
     # :22 uint16 narrowing
@@ -89,13 +89,18 @@ def ambiguity_dims(delay_min, delay_max, doppler_min, doppler_max, fs, n, round_
     while d.doppler_middle + (i * res) <= d.doppler_max:
         i += 1
     d.n_doppler_bins = (2 * (i - 1) + 1) & 0xFFFF
+    if n_doppler_bins:
+        # extension (not reachable through the reference's constructor): an explicit
+        # bin count with the reference's arithmetic below unchanged; for an even count the axis
+        # gets its extra bin at the end, where (j + nD//2 + 1) % nD of :165 puts Nyquist
+        d.n_doppler_bins = int(n_doppler_bins) & 0xFFFF
     d.n_corr = (d.n_samples // d.n_doppler_bins) & 0xFFFF  # :39
     d.cpi = (float(d.n_corr) * d.n_doppler_bins) / d.fs  # :40
     res = 1.0 / d.cpi  # :43
     d.delay = np.arange(d.delay_min, d.delay_min + d.n_delay_bins, dtype=np.int64)  # :49-50
     h = (d.n_doppler_bins - 1) // 2
     # :52-59  mid -/+ i*res, evaluated exactly as the reference does (i*res, then add)
-    k = np.arange(-h, h + 1, dtype=np.float64)
+    k = np.arange(-h, d.n_doppler_bins - h, dtype=np.float64)
     d.doppler = d.doppler_middle + k * res
     d.nfft = 2 * d.n_corr - 1  # :62
     if d.round_hamming:

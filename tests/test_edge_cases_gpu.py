@@ -90,3 +90,25 @@ def test_two_wave_doppler_tile_kernel(b2):
     for fmax, n, fs, dmax in [(300, 1_000_000, 1_000_000, 1100), (512, 2_000_000, 2_000_000, 1029)]:
         amb = run(b2, (-5, dmax, -fmax, fmax, fs, n, True), seed=fmax)
         assert amb.get_n_doppler_bins() == 2 * fmax + 1
+
+
+def test_explicit_power_of_two_doppler_bins(b2):
+    """Extension of SURVEY.md 8g: exactly 512 / 1024 / 2048 Doppler bins (the reference's
+    constructor only yields odd counts); oracle = the NumPy restatement with the same count."""
+    for nD, n, fs, dmax in [(512, 2_000_000, 2_000_000, 400), (1024, 2_000_000, 2_000_000, 100), (2048, 4_000_000, 2_000_000, 60),
+                            (64, 100_000, 100_000, 30), (2, 50_000, 100_000, 10)]:
+        args = (-10, dmax, -(nD // 2), nD // 2, fs, n, True)
+        amb = b2.Ambiguity(*args, n_doppler_bins=nD)
+        d = O.ambiguity_dims(*args, n_doppler_bins=nD)
+        assert (amb.get_n_doppler_bins(), amb.get_n_corr(), amb.get_nfft()) == (nD, d.n_corr, d.nfft) == (nD, n // nD, d.nfft)
+        assert np.allclose(amb.doppler, d.doppler, rtol=0, atol=1e-9) and amb.doppler.size == nD
+        f_t = float(d.doppler[nD // 4])  # a target exactly on a bin
+        x, y = O.synth_iq(n, seed=nD, fs=fs, targets=((7, f_t, 0.1),))
+        m = amb.process(x, y)
+        ref = O.ambiguity_process(d, x, y)
+        err = np.abs(m.data.astype(np.complex128) - ref)
+        assert err.max() / np.abs(ref).max() <= 1e-5
+        noise, mx = O.map_metrics(ref)
+        assert abs(m.noisePower - noise) <= 1e-3 and abs(m.maxPower - mx) <= 1e-3
+    with pytest.raises(b2.Blah2HipError):
+        b2.Ambiguity(-10, 100, -50, 50, 100_000, 1000, True, n_doppler_bins=70_000)
