@@ -15,8 +15,18 @@ LIB_PATH = os.path.join(PKG, "libblah2hip.so")
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_UNDERFLOW, ERR_NO_DEVICE, ERR_CAPACITY = -1, -2, -3, -4, -5, -6
 FMT_C32, FMT_I16, FMT_F16 = 0, 1, 2
-K_RANGE, K_DOPPLER, K_METRICS, K_CFAR, K_COUNT = 0, 1, 2, 3, 8
-KERNEL_NAMES = {K_RANGE: "range", K_DOPPLER: "doppler", K_METRICS: "metrics", K_CFAR: "cfar"}
+K_RANGE, K_DOPPLER, K_METRICS, K_CFAR, K_SAT_ROWS, K_SAT_COLS, K_ROTATE, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 8
+KERNEL_NAMES = {K_RANGE: "range", K_DOPPLER: "doppler", K_METRICS: "metrics", K_CFAR: "cfar",
+                K_SAT_ROWS: "sat_rows", K_SAT_COLS: "sat_cols", K_ROTATE: "rotate"}
+CK_CORR, CK_REDUCE, CK_SOLVE, CK_FIR, CK_COUNT = 0, 1, 2, 3, 4
+CLUTTER_KERNEL_NAMES = {CK_CORR: "clutter_corr", CK_REDUCE: "clutter_reduce", CK_SOLVE: "clutter_solve",
+                        CK_FIR: "clutter_fir"}
+OPT_DOPPLER_KERNEL, OPT_RANGE_GRID = 1, 2
+DOP_AUTO, DOP_TILE8, DOP_TILE16, DOP_TILEM, DOP_COLUMN, DOP_DIRECT = 0, 1, 2, 3, 4, 5
+DOPPLER_KERNEL_NAMES = {DOP_AUTO: "auto", DOP_TILE8: "tile8", DOP_TILE16: "tile16", DOP_TILEM: "tilem",
+                        DOP_COLUMN: "column", DOP_DIRECT: "direct"}
+RANGE_E16, RANGE_E8 = 1, 2
+INFO_LAST_DOPPLER_KERNEL, INFO_LAST_RANGE_KERNEL, INFO_DOPPLER_FFT_LEN, INFO_RANGE_GRID, INFO_NUM_CU = 1, 2, 3, 4, 5
 
 
 class Blah2HipError(RuntimeError):
@@ -48,6 +58,8 @@ SYMBOLS = {
     "blah2hip_amb_destroy": (C.c_int, [_vp]),
     "blah2hip_amb_get_dims": (C.c_int, [_vp, C.POINTER(AmbDims)]),
     "blah2hip_amb_get_axes": (C.c_int, [_vp, _vp, _vp]),
+    "blah2hip_amb_set_option": (C.c_int, [_vp, C.c_int, C.c_int64]),
+    "blah2hip_amb_get_info": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64)]),
     "blah2hip_amb_process_c64": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp]),
     "blah2hip_amb_process_c32": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp]),
     "blah2hip_amb_process_i16": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
@@ -55,7 +67,11 @@ SYMBOLS = {
     "blah2hip_amb_read_last": (C.c_int, [_vp, _u32, _vp, _vp]),
     "blah2hip_amb_db_dev": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp]),
     "blah2hip_cfar1d_dev": (C.c_int, [_vp, _vp, _vp, _u32, _dbl, _i32, _i32, _i32, _dbl, _vp, _u32, _vp, _vp]),
+    "blah2hip_cfar1d_prepare": (C.c_int, [_vp, _dbl, _i32]),
+    "blah2hip_cfar2d_prepare": (C.c_int, [_vp, _dbl, _i32, _i32, _i32, _i32]),
     "blah2hip_cfar1d_process": (C.c_int, [_vp, _u32, _dbl, _i32, _i32, _i32, _dbl, _vp, _vp, _vp, _u32, C.POINTER(_u32)]),
+    "blah2hip_cfar1d_map": (C.c_int, [_vp, _u32, _u32, _vp, _vp, _dbl, _dbl, _i32, _i32, _i32, _dbl, C.c_int, _vp, _vp, _vp, _u32,
+                                      C.POINTER(_u32)]),
     "blah2hip_cfar2d_dev": (C.c_int, [_vp, _vp, _vp, _u32, _dbl, _i32, _i32, _i32, _i32, _i32, _dbl, _vp, _u32, _vp, _vp]),
     "blah2hip_cfar2d_process": (C.c_int, [_vp, _u32, _dbl, _i32, _i32, _i32, _i32, _i32, _dbl, _vp, _vp, _vp, _u32,
                                           C.POINTER(_u32)]),
@@ -67,6 +83,10 @@ SYMBOLS = {
     "blah2hip_clutter_process_c64": (C.c_int, [_vp, _vp, _vp, _u32, _vp, C.POINTER(C.c_int)]),
     "blah2hip_clutter_process_c32": (C.c_int, [_vp, _vp, _vp, _u32, _vp, C.POINTER(C.c_int)]),
     "blah2hip_clutter_process_dev": (C.c_int, [_vp, _vp, _vp, _u32, C.c_uint64, _vp, _vp, _vp]),
+    "blah2hip_clutter_get_dims": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "blah2hip_clutter_read_last": (C.c_int, [_vp, _u32, _vp, _vp, C.POINTER(C.c_int)]),
+    "blah2hip_clutter_set_timing": (C.c_int, [_vp, C.c_int]),
+    "blah2hip_clutter_get_timing": (C.c_int, [_vp, _vp, _vp]),
     "blah2hip_spectrum_create": (C.c_int, [_u32, C.c_double, C.c_int, _u32, C.POINTER(_vp)]),
     "blah2hip_spectrum_destroy": (C.c_int, [_vp]),
     "blah2hip_spectrum_get_dims": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.c_uint64)]),
@@ -85,9 +105,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # BLAH2HIP_LIBRARY: another BUILD of the same HIP library (tools/ A/B runs of compile-time variants)
+    path = os.environ.get("BLAH2HIP_LIBRARY", LIB_PATH)
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m blah2_amd.build` "
+            f"{path} is missing: build it with `python -m blah2_amd.build` "
             "(there is no CPU fallback for the HIP path)")
     # The PyTorch-ROCm wheel bundles its own libamdhip64/libhsa-runtime64.  Two HIP
     # runtimes in one process cannot both own the device, so when torch is installed
@@ -99,7 +121,7 @@ def load():
             import torch  # noqa: F401
         except ImportError:
             pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError when the library does not export a declared symbol
         fn.restype = res

@@ -50,8 +50,7 @@ def build_hip(force=False, verbose=True):
     deps = srcs + _sources(CSRC, (".hpp",)) + [os.path.join(ROOT, "include", "blah2hip.h")]
     if not force and not _newer(LIB, deps):
         return LIB
-    extra = ["-DBLAH2HIP_ABLATE"] if os.environ.get("BLAH2HIP_ABLATE") == "1" else []  # profiling variants
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", *extra,
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wno-unused-value", "-fno-slp-vectorize", "-I", os.path.join(ROOT, "include"), "-I", CSRC, *srcs, "-o", LIB]
     if verbose:
         print("[blah2_amd.build]", " ".join(cmd), flush=True)

@@ -2,6 +2,7 @@
 // planning, table generation and kernel launches.  gfx950 only; links against
 // libamdhip64 and nothing else.
 #include "kernels.hpp"
+#include "timing.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -56,10 +57,6 @@ cf root_of_unity(int64_t k, int64_t n)
   return cmake((float)std::cos(a), (float)std::sin(a));
 }
 
-struct EventPair {
-  hipEvent_t a, b;
-};
-
 } // namespace
 
 struct blah2hip_amb_s {
@@ -73,7 +70,7 @@ struct blah2hip_amb_s {
   std::vector<double> dopplerAxis;
   hipStream_t stream = nullptr;
   int numCU = 256;
-  int rangeGridCap = 1024;
+  int rangeGridCap = 1024, rangeGridDefault = 1024;
   size_t rangeLds = 0;
   void *h_pin = nullptr;            // pinned host staging of the c64 entry point
   size_t h_pin_bytes = 0;
@@ -86,7 +83,6 @@ struct blah2hip_amb_s {
   float *d_partMax = nullptr;
   double *d_metrics = nullptr;
   double *d_doppler = nullptr;
-  double *d_alpha = nullptr;
   void *d_in = nullptr; // staging for the host entry points
   size_t d_in_bytes = 0;
   cf *d_rot = nullptr; // rotated reference / converted planes for asymmetric Doppler limits
@@ -95,21 +91,21 @@ struct blah2hip_amb_s {
   uint32_t hitCap = 0;
   int dopTilesX = 0, dopTilesY = 0; // direct-DFT fallback grid
   int dopR3 = 0;                    // 0 = direct fallback, else Bluestein on WgFft<dopR3>
-  int dopTile = 0;                  // nD <= 513: columns per workgroup of the tile kernel (0 = off, 8 or 16)
   int dopGridX = 0;
   int nParts = 0;                   // metrics partials per CPI
   int nTiles = 0;                   // 16-column tiles of the range map
+  // execution plan: per handle, fixed at create or through blah2hip_amb_set_option
+  int dopForce = BLAH2HIP_DOP_AUTO; // BLAH2HIP_OPT_DOPPLER_KERNEL
+  int lastDoppler = 0;              // BLAH2HIP_INFO_LAST_DOPPLER_KERNEL
+  int lastRange = 0;                // BLAH2HIP_INFO_LAST_RANGE_KERNEL
+  struct AlphaTable { double pfa; size_t n; double *d; };
+  std::vector<AlphaTable> alphaTables; // CFAR threshold factors, one per (pfa, size) seen
   cf *d_dtw = nullptr;              // exp(-2 pi i k/M)
   cf *d_chirp = nullptr;            // exp(-i pi n^2/nD)
   cf *d_bf = nullptr;               // chirp-kernel spectrum / M in register layout
   double *d_sat = nullptr;          // 2-D CFAR summed-area table [max_batch][nD+1][nDelay+1]
-  double *d_alpha2 = nullptr;       // 2-D CFAR alpha table
-  size_t alpha2Cap = 0;
-  uint32_t *d_dopCnt = nullptr;     // per-CPI arrival tickets of the Doppler kernel (zero between launches)
 
-  bool timing = false;
-  std::vector<EventPair> ev[BLAH2HIP_K_COUNT];
-  std::vector<EventPair> evPool;
+  KernelTimer<BLAH2HIP_K_COUNT> timer;
 };
 
 namespace {
@@ -261,34 +257,12 @@ template <int R3, class In> int launch_range_t(blah2hip_amb_s *h, const RangeArg
 {
   using W = WgFft<R3>;
   const size_t lds = (size_t)(W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
-  // x/y transforms interleaved between barriers: +3..6 % for F <= 2048 (measured), neutral at 4096
-  static const bool ilv = [] { const char *e = std::getenv("BLAH2HIP_RANGE_ILV"); return e ? std::atoi(e) != 0 : (R3 <= 8); }();
-  void (*kern)(RangeArgs, In) = ilv ? range_kernel<R3, In, true> : range_kernel<R3, In, false>;
-  // raw buffer loads: the descriptor's range check does the zero padding of the segment windows
-  // (measured at cfg 2, batch 128: complex fp32 input -3 %, int16 input -12 % kernel time)
-  static const bool bl = [] { const char *e = std::getenv("BLAH2HIP_RANGE_BUF"); return e ? std::atoi(e) != 0 : true; }();
-  if (bl) kern = ilv ? range_kernel<R3, In, true, 3, true, true> : range_kernel<R3, In, false, 3, true, true>;
-#ifdef BLAH2HIP_ABLATE
-  // profiling build only (tools/gpu_ablate.py; results are wrong by construction):
-  // bit0 arithmetic, bit1 LDS, bit2 loads
-  static const int abl = [] { const char *e = std::getenv("BLAH2HIP_RANGE_ABLATE"); return e ? std::atoi(e) : 7; }();
-  if (abl != 7 && R3 <= 8) {
-    switch (abl) {
-    case 0: kern = range_kernel<R3, In, false, 0, false>; break;
-    case 1: kern = range_kernel<R3, In, false, 1, false>; break;
-    case 2: kern = range_kernel<R3, In, false, 2, false>; break;
-    case 3: kern = range_kernel<R3, In, false, 3, false>; break;
-    case 4: kern = range_kernel<R3, In, false, 0, true>; break;
-    case 5: kern = range_kernel<R3, In, false, 1, true>; break;
-    case 6: kern = range_kernel<R3, In, false, 2, true>; break;
-    default: break;
-    }
-  }
-#endif
+  auto kern = range_kernel<R3, In>;
   LDSCFG(kern, lds);
   const int grid = std::min<int>(a.nPulses, h->rangeGridCap);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(W::T), lds, st, a, in);
   HIPCHK(hipGetLastError());
+  h->lastRange = BLAH2HIP_RANGE_E16;
   return BLAH2HIP_OK;
 }
 
@@ -296,33 +270,21 @@ template <int R4, class In> int launch_range8_t(blah2hip_amb_s *h, const RangeAr
 {
   using W = WgFft8<R4>;
   const size_t lds = (size_t)2 * W::BUF_ELEMS * sizeof(cf);
-  static const bool bl = [] { const char *e = std::getenv("BLAH2HIP_RANGE_BUF"); return e ? std::atoi(e) != 0 : true; }();
-  void (*kern)(RangeArgs, In) = bl ? range8_kernel<R4, In, true> : range8_kernel<R4, In, false>;
+  auto kern = range8_kernel<R4, In>;
   LDSCFG(kern, lds);
-  int perCU = std::max(1, std::min((int)((160 * 1024) / lds), 32 / (W::T / 64)));
-  int cap = perCU * h->numCU;
-  if (const char *e = std::getenv("BLAH2HIP_RANGE_GRID")) cap = std::max(1, std::atoi(e));
-  const int grid = std::min<int>(a.nPulses, cap);
+  const int grid = std::min<int>(a.nPulses, h->rangeGridCap);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(W::T), lds, st, a, in);
   HIPCHK(hipGetLastError());
+  h->lastRange = BLAH2HIP_RANGE_E8;
   return BLAH2HIP_OK;
 }
 
+// F = 1024: 8 points per thread (one-wave transforms: 10.5 vs 14.3 us/CPI at cfg 2 with 16 points per
+// thread); F = 2048 / 4096: 16 points per thread (10.0 vs 10.3 us/CPI; equal at 4096).  Measured, round 1.
 template <class In> int launch_range(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
 {
-  // 8-points-per-thread transform (4 waves/SIMD) vs 16-points-per-thread (2 waves/SIMD)
-  // Measured (tools/gpu_diag.py, cfg 2): F=1024: 10.5 (E8) vs 14.3 us/CPI (E16); F=2048: 10.3 vs 10.0;
-  // F=4096: equal.  Default: E8 only for the one-wave F=1024 case; BLAH2HIP_RANGE_E8=0/1 forces.
-  static const int e8 = [] { const char *e = std::getenv("BLAH2HIP_RANGE_E8"); return e ? std::atoi(e) : -1; }();
-  if (e8 == 1 || (e8 < 0 && h->r3 == 4)) {
-    switch (h->r3) {
-    case 4: return launch_range8_t<2>(h, a, in, st);
-    case 8: return launch_range8_t<4>(h, a, in, st);
-    default: return launch_range8_t<8>(h, a, in, st);
-    }
-  }
   switch (h->r3) {
-  case 4: return launch_range_t<4>(h, a, in, st);
+  case 4: return launch_range8_t<2>(h, a, in, st);
   case 8: return launch_range_t<8>(h, a, in, st);
   default: return launch_range_t<16>(h, a, in, st);
   }
@@ -330,24 +292,13 @@ template <class In> int launch_range(blah2hip_amb_s *h, const RangeArgs &a, In i
 
 int tic(blah2hip_amb_s *h, int k, hipStream_t st)
 {
-  if (!h->timing) return BLAH2HIP_OK;
-  EventPair p;
-  if (!h->evPool.empty()) {
-    p = h->evPool.back();
-    h->evPool.pop_back();
-  } else {
-    HIPCHK(hipEventCreate(&p.a));
-    HIPCHK(hipEventCreate(&p.b));
-  }
-  HIPCHK(hipEventRecord(p.a, st));
-  h->ev[k].push_back(p);
+  HIPCHK(h->timer.tic(k, st));
   return BLAH2HIP_OK;
 }
 
 int toc(blah2hip_amb_s *h, int k, hipStream_t st)
 {
-  if (!h->timing) return BLAH2HIP_OK;
-  HIPCHK(hipEventRecord(h->ev[k].back().b, st));
+  HIPCHK(h->timer.toc(k, st));
   return BLAH2HIP_OK;
 }
 
@@ -368,6 +319,64 @@ int host_tail(blah2hip_amb_s *h, float *map_out, double *metrics)
   if (map_out) HIPCHK(hipMemcpyAsync(map_out, h->d_map, cells * sizeof(cf), hipMemcpyDeviceToHost, h->stream));
   if (metrics) HIPCHK(hipMemcpyAsync(metrics, h->d_metrics, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return BLAH2HIP_OK;
+}
+
+// Which Doppler kernel a launch of n_cpi CPIs runs.  The tile kernels (coalesced tile
+// reads, a 512/1024-thread workgroup per 8/16/4 columns) win once a launch carries enough
+// tiles to fill the chip; small launches (single CPI) keep the per-column kernel.
+bool doppler_kernel_applicable(const blah2hip_amb_s *h, int which)
+{
+  const int nD = (int)h->dims.n_doppler_bins;
+  switch (which) {
+  case BLAH2HIP_DOP_TILE8:
+  case BLAH2HIP_DOP_TILE16: return h->dopR3 == 4;
+  case BLAH2HIP_DOP_TILEM: return (h->dopR3 == 8 && nD <= DopM<8>::MAX_ND) || (h->dopR3 == 16 && nD <= DopM<16>::MAX_ND);
+  case BLAH2HIP_DOP_COLUMN: return h->dopR3 != 0;
+  case BLAH2HIP_DOP_DIRECT: return true;
+  default: return false;
+  }
+}
+
+int pick_doppler(const blah2hip_amb_s *h, uint32_t n_cpi)
+{
+  if (h->dopForce != BLAH2HIP_DOP_AUTO) return h->dopForce;
+  if (!h->dopR3) return BLAH2HIP_DOP_DIRECT;
+  const int nDelay = (int)h->dims.n_delay_bins;
+  const int ncol = h->dopR3 == 4 ? 8 : (h->dopR3 == 8 ? DopM<8>::NCOL : DopM<16>::NCOL);
+  const int tiles = (nDelay + ncol - 1) / ncol;
+  const bool fills = (int)n_cpi * tiles >= h->numCU / 2;
+  if (fills && h->dopR3 == 4) return BLAH2HIP_DOP_TILE8; // 8 columns x 2 workgroups per CU beat 16 x 1 (57 vs 74 us per 32 CPIs)
+  if (fills && doppler_kernel_applicable(h, BLAH2HIP_DOP_TILEM)) return BLAH2HIP_DOP_TILEM;
+  return BLAH2HIP_DOP_COLUMN;
+}
+
+// CFAR threshold factors alpha[n] = n*(pfa^(-1/n) - 1), n = 1..maxN, evaluated with the
+// same libm pow the reference calls (CfarDetector1D.cpp:76).  One device table per
+// (pfa, maxN) the handle has seen: the first call with a new tuple uploads it (blocking);
+// afterwards the dev entry points only enqueue.
+int alpha_table(blah2hip_amb_s *h, double pfa, size_t maxN, const double **out)
+{
+  for (auto &t : h->alphaTables)
+    if (t.pfa == pfa && t.n >= maxN) { *out = t.d; return BLAH2HIP_OK; }
+  std::vector<double> alpha(maxN + 1);
+  alpha[0] = std::nan("");
+  for (size_t n = 1; n <= maxN; n++) alpha[n] = (double)n * (pow(pfa, -1.0 / (double)n) - 1);
+  blah2hip_amb_s::AlphaTable t{pfa, maxN, nullptr};
+  HIPCHK(hipMalloc(&t.d, (maxN + 1) * sizeof(double)));
+  hipError_t e = hipMemcpy(t.d, alpha.data(), (maxN + 1) * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(t.d); return fail(BLAH2HIP_ERR_HIP, std::string("alpha table upload: ") + hipGetErrorString(e)); }
+  h->alphaTables.push_back(t);
+  *out = t.d;
+  return BLAH2HIP_OK;
+}
+
+int ensure_sat(blah2hip_amb_s *h)
+{
+  if (h->d_sat) return BLAH2HIP_OK;
+  const size_t satElems = (size_t)(h->dims.n_doppler_bins + 1) * (h->dims.n_delay_bins + 1);
+  HIPCHK(hipMalloc(&h->d_sat, satElems * h->dims.max_batch * sizeof(double)));
+  HIPCHK(hipMemset(h->d_sat, 0, satElems * h->dims.max_batch * sizeof(double))); // zero borders
   return BLAH2HIP_OK;
 }
 
@@ -436,6 +445,16 @@ int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler
   derive_dims(h, n, round_hamming != 0, n_doppler_bins);
   h->dims.max_batch = max_batch;
   if (h->dims.n_corr == 0) return fail(BLAH2HIP_ERR_INVALID, "nCorr == 0");
+  {
+    // Ambiguity.cpp:132-146 gathers lag d from index d (d >= 0) or nfft + d (d < 0) of an nfft-point
+    // CIRCULAR correlation of nCorr-sample pulses: lags beyond nfft - nCorr alias onto the
+    // opposite-sign lags.  This engine computes the linear correlation; refuse what would differ.
+    const int64_t lim = (int64_t)h->dims.nfft - (int64_t)h->dims.n_corr;
+    const int64_t lagMax = std::max<int64_t>(std::llabs((long long)delay_min), std::llabs((long long)delay_max));
+    if (lagMax > lim)
+      return fail(BLAH2HIP_ERR_UNSUPPORTED, "lag window reaches the lags the reference's circular correlation aliases "
+                                             "(max |delay| > nfft - nCorr)");
+  }
   if (!choose_plan(h)) {
     return fail(BLAH2HIP_ERR_UNSUPPORTED, "nDelayBins too large for the on-chip transform lengths (<= 4096)");
   }
@@ -456,8 +475,7 @@ int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler
     const int wavesPerWg = (16 * h->r3) / 64;
     perCU = std::min(perCU, 32 / wavesPerWg);
     perCU = std::max(perCU, 1);
-    h->rangeGridCap = perCU * h->numCU;
-    if (const char *e = std::getenv("BLAH2HIP_RANGE_GRID")) h->rangeGridCap = std::max(1, std::atoi(e));
+    h->rangeGridCap = h->rangeGridDefault = perCU * h->numCU;
   }
 
   std::vector<cf> tw(F);
@@ -471,20 +489,11 @@ int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler
   h->dopR3 = 0;
   for (int r3 : {4, 8, 16})
     if (256 * r3 >= 2 * (int)nD - 2) { h->dopR3 = r3; break; }
-  if (const char *e = std::getenv("BLAH2HIP_DOPPLER_DIRECT")) if (std::atoi(e)) h->dopR3 = 0;
   h->dopTilesX = (nDelay + 63) / 64;
   h->dopTilesY = (nD + DOP_KPT - 1) / DOP_KPT;
-  h->dopTile = (h->dopR3 == 4) ? 8 : 0; // measured: 8 columns x 2 workgroups per CU beats 16 x 1 (57 vs 74 us per 32 CPIs)
-  if (const char *e = std::getenv("BLAH2HIP_DOPPLER_TILE")) {
-    const int v = std::atoi(e);
-    h->dopTile = (h->dopR3 == 4 && (v == 8 || v == 16)) ? v : 0;
-  }
-  if (h->dopR3) {
-    h->dopGridX = 8 * ((h->nTiles + 7) / 8) * 16; // per-column kernel: one workgroup per column, tiles padded to a multiple of 8
-    h->nParts = h->dopGridX;                      // (>= the tile kernel's workgroup count)
-  } else {
-    h->nParts = h->dopTilesX * h->dopTilesY;
-  }
+  h->dopGridX = 8 * ((h->nTiles + 7) / 8) * 16; // per-column kernel: one workgroup per column, tiles padded to a multiple of 8
+  // metrics partials per CPI: the largest workgroup count of any Doppler kernel this handle may launch
+  h->nParts = std::max(h->dopGridX, h->dopTilesX * h->dopTilesY);
 
   HIPCHK(hipMalloc(&h->d_tw, F * sizeof(cf)));
   HIPCHK(hipMalloc(&h->d_dopW, nD * sizeof(cf)));
@@ -494,10 +503,7 @@ int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler
   HIPCHK(hipMalloc(&h->d_partMax, (size_t)h->nParts * max_batch * sizeof(float)));
   HIPCHK(hipMalloc(&h->d_metrics, 2 * max_batch * sizeof(double)));
   HIPCHK(hipMalloc(&h->d_doppler, nD * sizeof(double)));
-  HIPCHK(hipMalloc(&h->d_alpha, 256 * sizeof(double)));
   HIPCHK(hipMalloc(&h->d_count, max_batch * sizeof(uint32_t)));
-  HIPCHK(hipMalloc(&h->d_dopCnt, max_batch * sizeof(uint32_t)));
-  HIPCHK(hipMemset(h->d_dopCnt, 0, max_batch * sizeof(uint32_t)));
   HIPCHK(hipMemset(h->d_R, 0, rcells * max_batch * sizeof(cf))); // padding columns stay finite
   HIPCHK(hipMemcpy(h->d_tw, tw.data(), F * sizeof(cf), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->d_dopW, dw.data(), nD * sizeof(cf), hipMemcpyHostToDevice));
@@ -531,14 +537,14 @@ int blah2hip_amb_destroy(blah2hip_amb_t h)
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void *p : {(void *)h->d_tw, (void *)h->d_dopW, (void *)h->d_R, (void *)h->d_map,
                   (void *)h->d_partSum, (void *)h->d_partMax, (void *)h->d_metrics,
-                  (void *)h->d_doppler, (void *)h->d_alpha, h->d_in, (void *)h->d_rot,
-                  (void *)h->d_hits, (void *)h->d_count, (void *)h->d_sat, (void *)h->d_alpha2, (void *)h->d_dopCnt, (void *)h->d_dtw, (void *)h->d_chirp,
+                  (void *)h->d_doppler, h->d_in, (void *)h->d_rot,
+                  (void *)h->d_hits, (void *)h->d_count, (void *)h->d_sat, (void *)h->d_dtw, (void *)h->d_chirp,
                   (void *)h->d_bf})
     if (p) (void)hipFree(p);
+  for (auto &t : h->alphaTables)
+    if (t.d) (void)hipFree(t.d);
   if (h->h_pin) (void)hipHostFree(h->h_pin);
-  for (auto &v : h->ev)
-    for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-  for (auto &p : h->evPool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  h->timer.destroy();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return BLAH2HIP_OK;
@@ -557,6 +563,36 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler)
   if (delay) std::memcpy(delay, h->delayAxis.data(), h->delayAxis.size() * sizeof(int32_t));
   if (doppler) std::memcpy(doppler, h->dopplerAxis.data(), h->dopplerAxis.size() * sizeof(double));
   return BLAH2HIP_OK;
+}
+
+int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
+{
+  if (!h) return fail(BLAH2HIP_ERR_INVALID, "NULL handle");
+  switch (option) {
+  case BLAH2HIP_OPT_DOPPLER_KERNEL:
+    if (value != BLAH2HIP_DOP_AUTO && !doppler_kernel_applicable(h, (int)value))
+      return fail(BLAH2HIP_ERR_UNSUPPORTED, "this Doppler kernel does not cover the handle's Doppler length");
+    h->dopForce = (int)value;
+    return BLAH2HIP_OK;
+  case BLAH2HIP_OPT_RANGE_GRID:
+    if (value < 0 || value > (1 << 20)) return fail(BLAH2HIP_ERR_INVALID, "range grid outside [0, 2^20]");
+    h->rangeGridCap = value ? (int)value : h->rangeGridDefault;
+    return BLAH2HIP_OK;
+  default: return fail(BLAH2HIP_ERR_INVALID, "unknown option");
+  }
+}
+
+int blah2hip_amb_get_info(blah2hip_amb_t h, int key, int64_t *value)
+{
+  if (!h || !value) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  switch (key) {
+  case BLAH2HIP_INFO_LAST_DOPPLER_KERNEL: *value = h->lastDoppler; return BLAH2HIP_OK;
+  case BLAH2HIP_INFO_LAST_RANGE_KERNEL: *value = h->lastRange; return BLAH2HIP_OK;
+  case BLAH2HIP_INFO_DOPPLER_FFT_LEN: *value = 256 * h->dopR3; return BLAH2HIP_OK;
+  case BLAH2HIP_INFO_RANGE_GRID: *value = h->rangeGridCap; return BLAH2HIP_OK;
+  case BLAH2HIP_INFO_NUM_CU: *value = h->numCU; return BLAH2HIP_OK;
+  default: return fail(BLAH2HIP_ERR_INVALID, "unknown info key");
+  }
 }
 
 int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const void *d_y,
@@ -593,6 +629,7 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     cf *xo = h->d_rot, *yo = h->d_rot + plane * h->dims.max_batch;
     const uint32_t nrot = h->dims.n_used; // later samples are never read by the range loop
     dim3 grid(std::min<uint32_t>((nrot + 255) / 256, 2048), n_cpi);
+    if ((rc = tic(h, BLAH2HIP_K_ROTATE, st))) return rc;
     if (fmt == BLAH2HIP_FMT_C32) {
       InC32 in{(const cf *)d_x, (const cf *)d_y};
       hipLaunchKernelGGL(rotate_kernel<InC32>, grid, dim3(256), 0, st, in, xo, yo,
@@ -607,6 +644,7 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
                          (int64_t)cpi_stride, (int64_t)plane, nrot, m2, h->fs);
     }
     HIPCHK(hipGetLastError());
+    if ((rc = toc(h, BLAH2HIP_K_ROTATE, st))) return rc;
     ra.cpiStride = (int64_t)plane;
     InC32 in2{xo, yo};
     if ((rc = tic(h, BLAH2HIP_K_RANGE, st))) return rc;
@@ -640,40 +678,55 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   da.nD = (int32_t)nD;
   da.nDelay = (int32_t)nDelay;
   da.nTiles = h->nTiles;
-  da.nGroups = 0;
-  da.counter = h->d_dopCnt;
-  da.metrics = met;
-  da.cells = (double)nD * (double)nDelay;
-  int nPartsUsed = h->nParts;
+  int nPartsUsed = 0;
   if ((rc = tic(h, BLAH2HIP_K_DOPPLER, st))) return rc;
-  // The tile kernel (coalesced, one 16-wave workgroup per CU) wins once a launch carries
-  // enough tiles to fill the chip; small launches (single CPI) keep the per-column kernel.
-  const int tileGrid = h->dopTile ? (int)((nDelay + h->dopTile - 1) / h->dopTile) : 0;
-  static const bool tileM = [] { const char *e = std::getenv("BLAH2HIP_DOPPLER_TILEM"); return e ? std::atoi(e) != 0 : true; }();
-  const int tileGridM = (int)((nDelay + DOPM_NCOL - 1) / DOPM_NCOL);
-  if (tileM && h->dopR3 == DOPM_R3 && nD <= 1025 && (int)n_cpi * tileGridM >= h->numCU / 2) {
-    const size_t lds = (size_t)DOPM_LDS_ELEMS * sizeof(cf);
-    LDSCFG(doppler_tilem_kernel, lds);
-    hipLaunchKernelGGL(doppler_tilem_kernel, dim3(tileGridM, n_cpi), dim3(1024), lds, st, da);
-    nPartsUsed = tileGridM;
-    HIPCHK(hipGetLastError());
-  } else
-  if (h->dopTile && (int)n_cpi * tileGrid >= h->numCU / 2) {
-    const size_t lds = ((size_t)h->dopTile * DOPT_PITCH + 1024) * sizeof(cf);
-    if (h->dopTile == 16) LDSCFG(doppler_tile_kernel<16>, lds);
-    else LDSCFG(doppler_tile_kernel<8>, lds);
-    if (h->dopTile == 16) hipLaunchKernelGGL(doppler_tile_kernel<16>, dim3(tileGrid, n_cpi), dim3(1024), lds, st, da);
-    else hipLaunchKernelGGL(doppler_tile_kernel<8>, dim3(tileGrid, n_cpi), dim3(512), lds, st, da);
-    nPartsUsed = tileGrid;
-    HIPCHK(hipGetLastError());
-  } else if (h->dopR3 == 4) rc = launch_doppler_t<4>(h, da, n_cpi, st);
-  else if (h->dopR3 == 8) rc = launch_doppler_t<8>(h, da, n_cpi, st);
-  else if (h->dopR3 == 16) rc = launch_doppler_t<16>(h, da, n_cpi, st);
-  else {
-    hipLaunchKernelGGL(doppler_dft_kernel, dim3(h->dopTilesX, h->dopTilesY, n_cpi), dim3(64 * DOP_WAVES), 0, st, da);
-    HIPCHK(hipGetLastError());
+  const int which = pick_doppler(h, n_cpi);
+  switch (which) {
+  case BLAH2HIP_DOP_TILE8:
+  case BLAH2HIP_DOP_TILE16: {
+    const int ncol = which == BLAH2HIP_DOP_TILE16 ? 16 : 8;
+    const int grid = (int)((nDelay + ncol - 1) / ncol);
+    const size_t lds = ((size_t)ncol * DOPT_PITCH + 1024) * sizeof(cf);
+    if (ncol == 16) {
+      LDSCFG(doppler_tile_kernel<16>, lds);
+      hipLaunchKernelGGL(doppler_tile_kernel<16>, dim3(grid, n_cpi), dim3(1024), lds, st, da);
+    } else {
+      LDSCFG(doppler_tile_kernel<8>, lds);
+      hipLaunchKernelGGL(doppler_tile_kernel<8>, dim3(grid, n_cpi), dim3(512), lds, st, da);
+    }
+    nPartsUsed = grid;
+    break;
   }
-  if (rc) return rc;
+  case BLAH2HIP_DOP_TILEM: {
+    if (h->dopR3 == 8) {
+      const int grid = (int)((nDelay + DopM<8>::NCOL - 1) / DopM<8>::NCOL);
+      const size_t lds = (size_t)DopM<8>::LDS_ELEMS * sizeof(cf);
+      LDSCFG(doppler_tilem_kernel<8>, lds);
+      hipLaunchKernelGGL(doppler_tilem_kernel<8>, dim3(grid, n_cpi), dim3(1024), lds, st, da);
+      nPartsUsed = grid;
+    } else {
+      const int grid = (int)((nDelay + DopM<16>::NCOL - 1) / DopM<16>::NCOL);
+      const size_t lds = (size_t)DopM<16>::LDS_ELEMS * sizeof(cf);
+      LDSCFG(doppler_tilem_kernel<16>, lds);
+      hipLaunchKernelGGL(doppler_tilem_kernel<16>, dim3(grid, n_cpi), dim3(1024), lds, st, da);
+      nPartsUsed = grid;
+    }
+    break;
+  }
+  case BLAH2HIP_DOP_COLUMN:
+    if (h->dopR3 == 4) rc = launch_doppler_t<4>(h, da, n_cpi, st);
+    else if (h->dopR3 == 8) rc = launch_doppler_t<8>(h, da, n_cpi, st);
+    else rc = launch_doppler_t<16>(h, da, n_cpi, st);
+    if (rc) return rc;
+    nPartsUsed = h->dopGridX;
+    break;
+  default:
+    hipLaunchKernelGGL(doppler_dft_kernel, dim3(h->dopTilesX, h->dopTilesY, n_cpi), dim3(64 * DOP_WAVES), 0, st, da);
+    nPartsUsed = h->dopTilesX * h->dopTilesY;
+    break;
+  }
+  HIPCHK(hipGetLastError());
+  h->lastDoppler = which;
   if ((rc = toc(h, BLAH2HIP_K_DOPPLER, st))) return rc;
 
   {
@@ -786,17 +839,15 @@ int blah2hip_cfar1d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
     return fail(BLAH2HIP_ERR_INVALID, "nGuard/nTrain/minDelay outside int8 range");
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
-  // alpha = nCells*(pow(pfa,-1/nCells)-1)  (CfarDetector1D.cpp:76), same libm call
-  double alpha[256];
-  alpha[0] = std::nan("");
-  for (int n = 1; n <= 2 * n_train; n++) alpha[n] = n * (pow(pfa, -1.0 / n) - 1);
-  HIPCHK(hipMemcpyAsync(h->d_alpha, alpha, (2 * n_train + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+  const double *d_alpha = nullptr;
+  int rc;
+  if ((rc = alpha_table(h, pfa, (size_t)(2 * n_train), &d_alpha))) return rc;
   HIPCHK(hipMemsetAsync(d_count, 0, n_cpi * sizeof(uint32_t), st));
   CfarArgs a;
   a.map = d_map ? (const cf *)d_map : h->d_map;
   a.metrics = d_metrics ? d_metrics : h->d_metrics;
   a.doppler = h->d_doppler;
-  a.alpha = h->d_alpha;
+  a.alpha = d_alpha;
   a.hits = d_hits;
   a.count = d_count;
   a.nD = (int32_t)h->dims.n_doppler_bins;
@@ -805,7 +856,6 @@ int blah2hip_cfar1d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
   a.nGuard = n_guard; a.nTrain = n_train; a.minDelay = min_delay;
   a.minDoppler = min_doppler;
   a.cap = cap;
-  int rc;
   if ((rc = tic(h, BLAH2HIP_K_CFAR, st))) return rc;
   hipLaunchKernelGGL(cfar1d_kernel, dim3(a.nD, n_cpi), dim3(256), (size_t)a.nDelay * sizeof(double), st, a);
   HIPCHK(hipGetLastError());
@@ -854,6 +904,74 @@ int blah2hip_cfar1d_process(blah2hip_amb_t h, uint32_t cpi, double pfa, int32_t 
   return BLAH2HIP_OK;
 }
 
+// CfarDetector1D::process on a map that lives on the HOST (any Map<complex<double>>, not only one
+// the engine produced): uploads it, runs cfar1d_kernel, frees.  noise_power is Map::noisePower.
+int blah2hip_cfar1d_map(const float *map, uint32_t n_doppler, uint32_t n_delay, const int32_t *delay_axis,
+                        const double *doppler_axis, double noise_power, double pfa, int32_t n_guard,
+                        int32_t n_train, int32_t min_delay, double min_doppler, int device, double *delay,
+                        double *doppler, double *snr, uint32_t cap, uint32_t *count)
+{
+  if (!map || !delay_axis || !doppler_axis || !count) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (n_doppler == 0 || n_delay == 0) return fail(BLAH2HIP_ERR_INVALID, "empty map");
+  if (n_guard < 0 || n_guard > 127 || n_train < 0 || n_train > 127 || min_delay < -128 || min_delay > 127)
+    return fail(BLAH2HIP_ERR_INVALID, "nGuard/nTrain/minDelay outside int8 range");
+  if ((size_t)n_delay * sizeof(double) > 64 * 1024) return fail(BLAH2HIP_ERR_UNSUPPORTED, "more than 8192 delay bins");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(BLAH2HIP_ERR_NO_DEVICE, "no HIP device visible (the HIP path is the only path)");
+  if (device < 0 || device >= ndev) return fail(BLAH2HIP_ERR_INVALID, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  const size_t cells = (size_t)n_doppler * n_delay;
+  std::vector<double> alpha(2 * n_train + 1);
+  alpha[0] = std::nan("");
+  for (int n = 1; n <= 2 * n_train; n++) alpha[n] = n * (pow(pfa, -1.0 / n) - 1);
+  const double met[2] = {noise_power, 0.0};
+  char *pool = nullptr; // one allocation: map | hits | doppler | alpha | metrics | count
+  const size_t oMap = 0, oHits = oMap + cells * sizeof(cf), oDop = oHits + cells * sizeof(blah2hip_hit_t),
+               oAlpha = oDop + n_doppler * sizeof(double), oMet = oAlpha + alpha.size() * sizeof(double),
+               oCnt = oMet + 2 * sizeof(double), total = oCnt + sizeof(uint32_t);
+  HIPCHK(hipMalloc(&pool, total));
+  std::vector<blah2hip_hit_t> hits;
+  uint32_t n = 0;
+  auto run = [&]() -> int {
+    HIPCHK(hipMemcpy(pool + oMap, map, cells * sizeof(cf), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pool + oDop, doppler_axis, n_doppler * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pool + oAlpha, alpha.data(), alpha.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pool + oMet, met, sizeof met, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(pool + oCnt, 0, sizeof(uint32_t)));
+    CfarArgs a;
+    a.map = (const cf *)(pool + oMap);
+    a.metrics = (const double *)(pool + oMet);
+    a.doppler = (const double *)(pool + oDop);
+    a.alpha = (const double *)(pool + oAlpha);
+    a.hits = (blah2hip_hit_t *)(pool + oHits);
+    a.count = (uint32_t *)(pool + oCnt);
+    a.nD = (int32_t)n_doppler; a.nDelay = (int32_t)n_delay; a.delayMin = delay_axis[0];
+    a.nGuard = n_guard; a.nTrain = n_train; a.minDelay = min_delay; a.minDoppler = min_doppler;
+    a.cap = (uint32_t)cells;
+    hipLaunchKernelGGL(cfar1d_kernel, dim3(a.nD, 1), dim3(256), (size_t)a.nDelay * sizeof(double), 0, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(&n, pool + oCnt, sizeof(uint32_t), hipMemcpyDeviceToHost)); // synchronises with the null stream
+    hits.resize(n);
+    if (n) HIPCHK(hipMemcpy(hits.data(), pool + oHits, n * sizeof(blah2hip_hit_t), hipMemcpyDeviceToHost));
+    return BLAH2HIP_OK;
+  };
+  const int rc = run();
+  (void)hipFree(pool);
+  if (rc) return rc;
+  std::sort(hits.begin(), hits.end(), [](const blah2hip_hit_t &a, const blah2hip_hit_t &b) {
+    return a.row != b.row ? a.row < b.row : a.col < b.col;
+  });
+  *count = n;
+  if (n > cap) return fail(BLAH2HIP_ERR_CAPACITY, "detection capacity too small");
+  for (uint32_t i = 0; i < n; i++) {
+    if (delay) delay[i] = (double)(hits[i].col + delay_axis[0]); // CfarDetector1D.cpp:88
+    if (doppler) doppler[i] = doppler_axis[hits[i].row];         // :89
+    if (snr) snr[i] = hits[i].snr;                               // :90
+  }
+  return BLAH2HIP_OK;
+}
+
 // ---------------------------------------------------------------- 2-D CFAR --
 int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_metrics, uint32_t n_cpi,
                         double pfa, int32_t ngd, int32_t ntd, int32_t ngf, int32_t ntf, int32_t min_delay,
@@ -868,29 +986,16 @@ int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   const int nD = (int)h->dims.n_doppler_bins, nC = (int)h->dims.n_delay_bins;
-  const size_t satElems = (size_t)(nD + 1) * (nC + 1);
-  if (!h->d_sat) {
-    HIPCHK(hipMalloc(&h->d_sat, satElems * h->dims.max_batch * sizeof(double)));
-    HIPCHK(hipMemset(h->d_sat, 0, satElems * h->dims.max_batch * sizeof(double))); // zero borders
-  }
-  const size_t maxN = (size_t)(2 * (ngd + ntd) + 1) * (2 * (ngf + ntf) + 1);
-  if (h->alpha2Cap < maxN + 1) {
-    if (h->d_alpha2) HIPCHK(hipFree(h->d_alpha2));
-    h->d_alpha2 = nullptr;
-    HIPCHK(hipMalloc(&h->d_alpha2, (maxN + 1) * sizeof(double)));
-    h->alpha2Cap = maxN + 1;
-  }
-  std::vector<double> alpha(maxN + 1);
-  alpha[0] = std::nan("");
-  for (size_t n = 1; n <= maxN; n++) alpha[n] = (double)n * (pow(pfa, -1.0 / (double)n) - 1);
-  HIPCHK(hipMemcpyAsync(h->d_alpha2, alpha.data(), (maxN + 1) * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st)); // alpha[] is a stack-lifetime host buffer
+  int rc;
+  if ((rc = blah2hip_cfar2d_prepare(h, pfa, ngd, ntd, ngf, ntf))) return rc; // no-op once prepared
+  const double *d_alpha = nullptr;
+  if ((rc = alpha_table(h, pfa, (size_t)(2 * (ngd + ntd) + 1) * (2 * (ngf + ntf) + 1), &d_alpha))) return rc;
   HIPCHK(hipMemsetAsync(d_count, 0, n_cpi * sizeof(uint32_t), st));
   Cfar2dArgs a;
   a.map = d_map ? (const cf *)d_map : h->d_map;
   a.metrics = d_metrics ? d_metrics : h->d_metrics;
   a.doppler = h->d_doppler;
-  a.alpha = h->d_alpha2;
+  a.alpha = d_alpha;
   a.sat = h->d_sat;
   a.hits = d_hits;
   a.count = d_count;
@@ -898,14 +1003,38 @@ int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
   a.ngD = ngd; a.ntD = ntd; a.ngF = ngf; a.ntF = ntf; a.minDelay = min_delay;
   a.minDoppler = min_doppler;
   a.cap = cap;
-  int rc;
-  if ((rc = tic(h, BLAH2HIP_K_CFAR, st))) return rc;
+  if ((rc = tic(h, BLAH2HIP_K_SAT_ROWS, st))) return rc;
   hipLaunchKernelGGL(sat_rows_kernel, dim3(nD, n_cpi), dim3(256), 0, st, a);
+  if ((rc = toc(h, BLAH2HIP_K_SAT_ROWS, st))) return rc;
+  if ((rc = tic(h, BLAH2HIP_K_SAT_COLS, st))) return rc;
   hipLaunchKernelGGL(sat_cols_kernel, dim3((nC + 63) / 64, n_cpi), dim3(64), 0, st, a);
+  if ((rc = toc(h, BLAH2HIP_K_SAT_COLS, st))) return rc;
+  if ((rc = tic(h, BLAH2HIP_K_CFAR, st))) return rc;
   hipLaunchKernelGGL(cfar2d_kernel, dim3((nC + 255) / 256, nD, n_cpi), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
   if ((rc = toc(h, BLAH2HIP_K_CFAR, st))) return rc;
   return BLAH2HIP_OK;
+}
+
+int blah2hip_cfar1d_prepare(blah2hip_amb_t h, double pfa, int32_t n_train)
+{
+  if (!h) return fail(BLAH2HIP_ERR_INVALID, "NULL handle");
+  if (n_train < 0 || n_train > 127) return fail(BLAH2HIP_ERR_INVALID, "nTrain outside int8 range");
+  HIPCHK(hipSetDevice(h->device));
+  const double *d = nullptr;
+  return alpha_table(h, pfa, (size_t)(2 * n_train), &d);
+}
+
+int blah2hip_cfar2d_prepare(blah2hip_amb_t h, double pfa, int32_t ngd, int32_t ntd, int32_t ngf, int32_t ntf)
+{
+  if (!h) return fail(BLAH2HIP_ERR_INVALID, "NULL handle");
+  for (int32_t v : {ngd, ntd, ngf, ntf})
+    if (v < 0 || v > 127) return fail(BLAH2HIP_ERR_INVALID, "guard/train sizes outside [0, 127]");
+  HIPCHK(hipSetDevice(h->device));
+  int rc;
+  if ((rc = ensure_sat(h))) return rc;
+  const double *d = nullptr;
+  return alpha_table(h, pfa, (size_t)(2 * (ngd + ntd) + 1) * (2 * (ngf + ntf) + 1), &d);
 }
 
 int blah2hip_cfar2d_process(blah2hip_amb_t h, uint32_t cpi, double pfa, int32_t ngd, int32_t ntd,
@@ -948,7 +1077,7 @@ int blah2hip_cfar2d_process(blah2hip_amb_t h, uint32_t cpi, double pfa, int32_t 
 int blah2hip_amb_set_timing(blah2hip_amb_t h, int enable)
 {
   if (!h) return fail(BLAH2HIP_ERR_INVALID, "NULL handle");
-  h->timing = enable != 0;
+  h->timer.enabled = enable != 0;
   return BLAH2HIP_OK;
 }
 
@@ -957,18 +1086,7 @@ int blah2hip_amb_get_timing(blah2hip_amb_t h, double *ms_total, uint32_t *launch
   if (!h || !ms_total || !launches) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipDeviceSynchronize());
-  for (int k = 0; k < BLAH2HIP_K_COUNT; k++) {
-    double tot = 0.0;
-    for (auto &p : h->ev[k]) {
-      float ms = 0.f;
-      HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
-      tot += ms;
-      h->evPool.push_back(p);
-    }
-    ms_total[k] = tot;
-    launches[k] = (uint32_t)h->ev[k].size();
-    h->ev[k].clear();
-  }
+  HIPCHK(h->timer.collect(ms_total, launches));
   return BLAH2HIP_OK;
 }
 

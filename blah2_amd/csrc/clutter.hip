@@ -26,6 +26,7 @@
 
 #include "blah2hip.h"
 #include "fft_wg.hpp"
+#include "timing.hpp"
 
 #include <algorithm>
 #include <stdint.h>
@@ -412,6 +413,8 @@ struct blah2hip_clutter_s {
   int32_t *d_ok = nullptr;
   cf *d_stage = nullptr; // host entry points: x, y, y_out planes
   size_t stageElems = 0;
+  int32_t *lastOk = nullptr; // where the last process call wrote its flags
+  KernelTimer<BLAH2HIP_CK_COUNT> timer;
 };
 
 namespace {
@@ -443,12 +446,17 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   ca.x = x; ca.y = y; ca.cpiStride = stride; ca.N = h->N; ca.xs = xs;
   ca.nBins = h->nBins; ca.segLen = h->segLen; ca.nSeg = h->nSeg; ca.nJobs = nJobs;
   ca.tw = h->d_tw; ca.partial = h->d_partial; ca.scale = 1.0f / (float)h->F;
+  CHIP(h->timer.tic(BLAH2HIP_CK_CORR, st));
   hipLaunchKernelGGL(clutter_corr_kernel<R3>, dim3(nJobs, nCpi), dim3(W::T), lds, st, ca);
   CHIP(hipGetLastError());
+  CHIP(h->timer.toc(BLAH2HIP_CK_CORR, st));
 
   SolveArgs sa;
   sa.partial = h->d_partial; sa.rb = h->d_rb; sa.w = h->d_w; sa.ok = ok; sa.nBins = h->nBins; sa.nJobs = nJobs;
+  CHIP(h->timer.tic(BLAH2HIP_CK_REDUCE, st));
   hipLaunchKernelGGL(clutter_reduce_kernel, dim3((h->nBins + 255) / 256, 2, nCpi), dim3(256), 0, st, sa);
+  CHIP(h->timer.toc(BLAH2HIP_CK_REDUCE, st));
+  CHIP(h->timer.tic(BLAH2HIP_CK_SOLVE, st));
   const size_t sl = (size_t)4 * h->nBins * sizeof(dcx);
   // waves per CPI: more waves split the per-order LDS traffic, fewer keep the barriers cheap
   static const int swEnv = [] { const char *e = std::getenv("BLAH2HIP_SOLVE_WAVES"); return e ? std::atoi(e) : 0; }();
@@ -457,13 +465,17 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   else if (sw == 8) hipLaunchKernelGGL(clutter_solve_kernel<8>, dim3(nCpi), dim3(512), sl, st, sa);
   else hipLaunchKernelGGL(clutter_solve_kernel<4>, dim3(nCpi), dim3(256), sl, st, sa);
   CHIP(hipGetLastError());
+  CHIP(h->timer.toc(BLAH2HIP_CK_SOLVE, st));
 
   FirArgs fa;
   fa.x = x; fa.y = y; fa.yout = yout; fa.cpiStride = stride; fa.outStride = outStride; fa.N = h->N; fa.xs = xs;
   fa.nBins = h->nBins; fa.segLen = h->segLen; fa.nSeg = h->nSeg; fa.w = h->d_w; fa.ok = ok; fa.tw = h->d_tw;
   fa.scale = 1.0f / (float)h->F;
+  CHIP(h->timer.tic(BLAH2HIP_CK_FIR, st));
   hipLaunchKernelGGL(clutter_fir_kernel<R3>, dim3(firGrid, nCpi), dim3(W::T), lds, st, fa);
   CHIP(hipGetLastError());
+  CHIP(h->timer.toc(BLAH2HIP_CK_FIR, st));
+  h->lastOk = ok;
   return BLAH2HIP_OK;
 }
 
@@ -551,8 +563,51 @@ int blah2hip_clutter_destroy(blah2hip_clutter_t h)
   for (void *p : {(void *)h->d_tw, (void *)h->d_partial, (void *)h->d_rb, (void *)h->d_w, (void *)h->d_ok,
                   (void *)h->d_stage})
     if (p) (void)hipFree(p);
+  h->timer.destroy();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_clutter_get_dims(blah2hip_clutter_t h, uint32_t *n_bins, uint32_t *fft_len, uint32_t *seg_len)
+{
+  if (!h) CFAIL(BLAH2HIP_ERR_INVALID, "NULL handle");
+  if (n_bins) *n_bins = (uint32_t)h->nBins;
+  if (fft_len) *fft_len = (uint32_t)h->F;
+  if (seg_len) *seg_len = (uint32_t)h->segLen;
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_clutter_read_last(blah2hip_clutter_t h, uint32_t cpi, float *w, double *rb, int *ok)
+{
+  if (!h) CFAIL(BLAH2HIP_ERR_INVALID, "NULL handle");
+  if (cpi >= h->maxBatch) CFAIL(BLAH2HIP_ERR_INVALID, "cpi index out of range");
+  CHIP(hipSetDevice(h->device));
+  CHIP(hipDeviceSynchronize());
+  if (w) CHIP(hipMemcpy(w, h->d_w + (size_t)cpi * h->nBins, (size_t)h->nBins * sizeof(cf), hipMemcpyDeviceToHost));
+  if (rb) CHIP(hipMemcpy(rb, h->d_rb + (size_t)cpi * 2 * h->nBins, (size_t)2 * h->nBins * sizeof(dcx), hipMemcpyDeviceToHost));
+  if (ok) {
+    int32_t v = 0;
+    if (!h->lastOk) CFAIL(BLAH2HIP_ERR_INVALID, "no process call yet");
+    CHIP(hipMemcpy(&v, h->lastOk + cpi, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *ok = v;
+  }
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_clutter_set_timing(blah2hip_clutter_t h, int enable)
+{
+  if (!h) CFAIL(BLAH2HIP_ERR_INVALID, "NULL handle");
+  h->timer.enabled = enable != 0;
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_clutter_get_timing(blah2hip_clutter_t h, double *ms_total, uint32_t *launches)
+{
+  if (!h || !ms_total || !launches) CFAIL(BLAH2HIP_ERR_INVALID, "NULL argument");
+  CHIP(hipSetDevice(h->device));
+  CHIP(hipDeviceSynchronize());
+  CHIP(h->timer.collect(ms_total, launches));
   return BLAH2HIP_OK;
 }
 

@@ -174,21 +174,27 @@ template <int R3> struct WgFft {
     for (int u = 1; u < R3; u++) tw3[u - 1] = tw[(16 * r * u) & (F - 1)];
   }
 
+  template <class TW> B2_HD static void load_tw1(int t, const TW *tw, cf *tw1)
+  {
+#pragma unroll
+    for (int q = 1; q < 16; q++) tw1[q - 1] = tw[(t * q) & (F - 1)];
+  }
+  template <class TW> B2_HD static void load_tw3(int t, const TW *tw, cf *tw3)
+  {
+    const int r = t & 15;
+#pragma unroll
+    for (int u = 1; u < R3; u++) tw3[u - 1] = tw[(16 * r * u) & (F - 1)];
+  }
+
   // ---- forward -----------------------------------------------------------
   // v[k1] = in[t + T*k1] on entry
-  // M is an ablation mask for profiling builds: bit 0 = do the arithmetic,
-  // bit 1 = do the LDS traffic.  Production code uses the default (3).
-  template <int M = 3> B2_HD static void fwd_s1(int t, cf *v, const cf *tw1, cf *A)
+  B2_HD static void fwd_s1(int t, cf *v, const cf *tw1, cf *A)
   {
-    if (M & 1) {
-      dft16<-1>(v);
+    dft16<-1>(v);
 #pragma unroll
-      for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw1[q - 1]);
-    }
-    if (M & 2) {
+    for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw1[q - 1]);
 #pragma unroll
-      for (int q = 0; q < 16; q++) A[q * PA + t] = v[q];
-    }
+    for (int q = 0; q < 16; q++) A[q * PA + t] = v[q];
   }
   B2_HD static void fwd_s2_load(int t, cf *v, const cf *A)
   {
@@ -202,49 +208,41 @@ template <int R3> struct WgFft {
 #pragma unroll
     for (int r = 0; r < 16; r++) B[q * PB + u * SU + r] = v[r];
   }
-  template <int M = 3> B2_HD static void fwd_s2(int t, cf *v, const cf *A, cf *B)
+  B2_HD static void fwd_s2(int t, cf *v, const cf *A, cf *B)
   {
-    if (M & 2) fwd_s2_load(t, v, A);
-    if (M & 1) dft16<-1>(v);
-    if (M & 2) fwd_s2_store(t, v, B);
+    fwd_s2_load(t, v, A);
+    dft16<-1>(v);
+    fwd_s2_store(t, v, B);
   }
   // leaves X[q + 16*r + 256*s] in v[j*R3 + s], (16*q + r) = t + T*j
-  template <int M = 3> B2_HD static void fwd_s3(int t, cf *v, const cf *tw3, const cf *B)
+  B2_HD static void fwd_s3(int t, cf *v, const cf *tw3, const cf *B)
   {
     const int r = t & 15;
 #pragma unroll
     for (int j = 0; j < NP; j++) {
       const int q = (t >> 4) + R3 * j;
       cf *w = v + j * R3;
-      if (M & 2) {
 #pragma unroll
-        for (int u = 0; u < R3; u++) w[u] = B[q * PB + u * SU + r];
-      }
-      if (M & 1) {
+      for (int u = 0; u < R3; u++) w[u] = B[q * PB + u * SU + r];
 #pragma unroll
-        for (int u = 1; u < R3; u++) w[u] = cmul(w[u], tw3[u - 1]);
-        dftR<R3, -1>(w);
-      }
+      for (int u = 1; u < R3; u++) w[u] = cmul(w[u], tw3[u - 1]);
+      dftR<R3, -1>(w);
     }
   }
 
   // ---- inverse (unnormalised: returns F * ifft) ----------------------------
-  template <int M = 3> B2_HD static void inv_s1(int t, cf *v, const cf *tw3, cf *B)
+  B2_HD static void inv_s1(int t, cf *v, const cf *tw3, cf *B)
   {
     const int r = t & 15;
 #pragma unroll
     for (int j = 0; j < NP; j++) {
       const int q = (t >> 4) + R3 * j;
       cf *w = v + j * R3;
-      if (M & 1) {
-        dftR<R3, +1>(w);
+      dftR<R3, +1>(w);
 #pragma unroll
-        for (int a = 1; a < R3; a++) w[a] = cmulc(w[a], tw3[a - 1]);
-      }
-      if (M & 2) {
+      for (int a = 1; a < R3; a++) w[a] = cmulc(w[a], tw3[a - 1]);
 #pragma unroll
-        for (int a = 0; a < R3; a++) B[q * PB + a * SU + r] = w[a];
-      }
+      for (int a = 0; a < R3; a++) B[q * PB + a * SU + r] = w[a];
     }
   }
   B2_HD static void inv_s2_load(int t, cf *v, const cf *B)
@@ -259,24 +257,20 @@ template <int R3> struct WgFft {
 #pragma unroll
     for (int b = 0; b < 16; b++) A[q * PA + a + R3 * b] = v[b];
   }
-  template <int M = 3> B2_HD static void inv_s2(int t, cf *v, const cf *B, cf *A)
+  B2_HD static void inv_s2(int t, cf *v, const cf *B, cf *A)
   {
-    if (M & 2) inv_s2_load(t, v, B);
-    if (M & 1) dft16<+1>(v);
-    if (M & 2) inv_s2_store(t, v, A);
+    inv_s2_load(t, v, B);
+    dft16<+1>(v);
+    inv_s2_store(t, v, A);
   }
   // leaves z[t + T*c] in v[c]
-  template <int M = 3> B2_HD static void inv_s3(int t, cf *v, const cf *tw1, const cf *A)
+  B2_HD static void inv_s3(int t, cf *v, const cf *tw1, const cf *A)
   {
-    if (M & 2) {
 #pragma unroll
-      for (int q = 0; q < 16; q++) v[q] = A[q * PA + t];
-    }
-    if (M & 1) {
+    for (int q = 0; q < 16; q++) v[q] = A[q * PA + t];
 #pragma unroll
-      for (int q = 1; q < 16; q++) v[q] = cmulc(v[q], tw1[q - 1]);
-      dft16<+1>(v);
-    }
+    for (int q = 1; q < 16; q++) v[q] = cmulc(v[q], tw1[q - 1]);
+    dft16<+1>(v);
   }
 };
 

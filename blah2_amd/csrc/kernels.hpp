@@ -3,7 +3,7 @@
 //   range_kernel / range8_kernel   Hot loop A  Ambiguity.cpp:106-149  (segmented on-chip FFT correlation;
 //                                  16 / 8 points per thread)
 //   doppler_tile_kernel            Hot loop B  Ambiguity.cpp:152-169  nD <= 513, batched launches
-//   doppler_tilem_kernel                                              513 < nD <= 1025
+//   doppler_tilem_kernel                                              513 < nD <= 2049
 //   doppler_fft_kernel                                                nD <= 2049, one column per workgroup
 //   doppler_dft_kernel                                                direct fallback
 //                                  (all with the per-workgroup partial sums of Map::set_metrics)
@@ -36,6 +36,9 @@ namespace blah2 {
 // HBM traffic per pulse: 2*nCorr*8 B in (C32) or nCorr*8 B in (I16), nDelay*8 B out.
 // LDS: A and B exchange buffers, (16*PA + 16*PB)*8 B  (19 KB / 36 KB / 70 KB for
 // F = 1024 / 2048 / 4096).
+#ifndef RANGE8_WAVES_PER_SIMD
+#define RANGE8_WAVES_PER_SIMD 4
+#endif
 struct RangeArgs {
   RangePlan plan;
   const cf *tw;        // exp(-2 pi i k / F), k in [0, F)
@@ -70,12 +73,13 @@ __device__ __forceinline__ void bufload_seg(const In &in, const RangePlan &p, in
   for (int k = 0; k < E; k++) yv[k] = B::cvt(yr[k]);
 }
 
-// M / LD are profiling ablations (tools/gpu_ablate.py): M bit 0 = arithmetic, bit 1 = LDS
-// traffic, LD = global loads.  Production launches use <.., 3, true>.
-template <int R3, class In, bool ILV, int M = 3, bool LD = true, bool BL = false>
+// ILV: the x and y transforms advance together through their own exchange buffers
+// (+3..6 % for F <= 2048, neutral at 4096 where it costs registers; measured).
+template <int R3, class In>
 __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
 {
   using W = WgFft<R3>;
+  constexpr bool ILV = (R3 <= 8);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf *P = reinterpret_cast<cf *>(smem);
   cf *Q = P + W::A_ELEMS;
@@ -93,24 +97,12 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
     cf v[16], yv[16], acc[16];
     for (int s = 0; s < p.nSeg; s++) {
       // both channels' loads go out first: 32 requests in flight per thread
-      if (BL) {
-        bufload_seg<16 * R3, 16>(in, p, base, s, t, v, yv);
-      } else if (LD) {
-        load_seg_x<R3>(in, p, base, s, t, v);
-        load_seg_y<R3>(in, p, base, s, t, yv);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 16; k++) { v[k] = cmake((float)(t + k), (float)s); yv[k] = cmake((float)k, (float)(t - s)); }
-      }
-      if (!BL) {
-        mask_seg_x<R3>(p, s, t, v);
-        mask_seg_y<R3>(p, s, t, yv);
-      }
-      // The x and y transforms advance together, each through its own exchange
-      // buffer (P for x, Q for y, used first in the A layout and then in the B
-      // layout): every barrier interval holds two independent instruction
-      // streams, so LDS latency of one overlaps butterflies of the other.
+      bufload_seg<16 * R3, 16>(in, p, base, s, t, v, yv);
       if (ILV) {
+        // The x and y transforms advance together, each through its own exchange
+        // buffer (P for x, Q for y, used first in the A layout and then in the B
+        // layout): every barrier interval holds two independent instruction
+        // streams, so LDS latency of one overlaps butterflies of the other.
         W::fwd_s1(t, v, tw1, P);
         W::fwd_s1(t, yv, tw1, Q);
         __syncthreads();
@@ -126,16 +118,16 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
         W::fwd_s3(t, yv, tw3, Q); // yv = Y spectrum
       } else {
         // one transform at a time, P in the A layout and Q in the B layout
-        W::template fwd_s1<M>(t, v, tw1, P);
+        W::fwd_s1(t, v, tw1, P);
         __syncthreads();
-        W::template fwd_s2<M>(t, v, P, Q);
+        W::fwd_s2(t, v, P, Q);
         __syncthreads();
-        W::template fwd_s3<M>(t, v, tw3, Q);
-        W::template fwd_s1<M>(t, yv, tw1, P);
+        W::fwd_s3(t, v, tw3, Q);
+        W::fwd_s1(t, yv, tw1, P);
         __syncthreads();
-        W::template fwd_s2<M>(t, yv, P, Q);
+        W::fwd_s2(t, yv, P, Q);
         __syncthreads();
-        W::template fwd_s3<M>(t, yv, tw3, Q);
+        W::fwd_s3(t, yv, tw3, Q);
       }
       if (s == 0) {
 #pragma unroll
@@ -146,25 +138,26 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
       }
       __syncthreads(); // P/Q are rewritten by the next segment (or the inverse)
     }
-    W::template inv_s1<M>(t, acc, tw3, P);
+    W::inv_s1(t, acc, tw3, P);
     __syncthreads();
-    W::template inv_s2<M>(t, acc, P, Q);
+    W::inv_s2(t, acc, P, Q);
     __syncthreads();
-    W::template inv_s3<M>(t, acc, tw1, Q);
+    W::inv_s3(t, acc, tw1, Q);
     store_lags<R3>(a.out, p, cpi, i, t, acc);
     __syncthreads(); // Q is rewritten by the next pulse
   }
 }
 
 // --------------------------------------------------------------------------
-// Range kernel on the 8-points-per-thread transform (fft_wg8.hpp): identical
-// mathematics and interface, T = F/8 threads per pulse (4 waves for F = 2048),
-// ~half the registers per thread -> 4 waves per SIMD.  The x and y transforms of a
-// segment run one after the other and alternate their starting exchange buffer
-// (x: A,B,A  y: B,A,B), so a buffer is never rewritten before the barrier that
-// follows its last read: 3 barriers per transform and none in between.
-template <int R4, class In, bool BL = false>
-__global__ __launch_bounds__(64 * R4, 4) void range8_kernel(RangeArgs a, In in)
+// Range kernel on the 8-points-per-thread transform (fft_wg8.hpp), used for the
+// one-wave F = 1024 shape (measured 1.4x faster there than 16 points per thread;
+// equal or slower for F >= 2048): identical mathematics and interface, T = F/8
+// threads per pulse.  The x and y transforms of a segment run one after the other
+// and alternate their starting exchange buffer (x: A,B,A  y: B,A,B), so a buffer
+// is never rewritten before the barrier that follows its last read: 3 barriers
+// per transform and none in between.
+template <int R4, class In>
+__global__ __launch_bounds__(64 * R4, RANGE8_WAVES_PER_SIMD) void range8_kernel(RangeArgs a, In in)
 {
   using W = WgFft8<R4>;
   constexpr int T = W::T;
@@ -183,13 +176,7 @@ __global__ __launch_bounds__(64 * R4, 4) void range8_kernel(RangeArgs a, In in)
     cf acc[8];
     for (int s = 0; s < p.nSeg; s++) {
       cf v[8], yv[8];
-      if (BL) {
-        bufload_seg<T, 8>(in, p, base, s, t, v, yv);
-      } else {
-        load_seg_x_g<T, 8>(in, p, base, s, t, v);
-        load_seg_y_g<T, 8>(in, p, base, s, t, yv);
-        mask_seg_x_g<T, 8>(p, s, t, v);
-      }
+      bufload_seg<T, 8>(in, p, base, s, t, v, yv);
       W::fwd_s1(t, v, tw1, A);
       __syncthreads();
       W::fwd_s2_load(t, v, A);
@@ -200,7 +187,6 @@ __global__ __launch_bounds__(64 * R4, 4) void range8_kernel(RangeArgs a, In in)
       __syncthreads();
       W::fwd_s4(t, v, A); // v = X spectrum
 
-      if (!BL) mask_seg_y_g<T, 8>(p, s, t, yv);
       W::fwd_s1(t, yv, tw1, B);
       __syncthreads();
       W::fwd_s2_load(t, yv, B);
@@ -289,10 +275,7 @@ struct DopplerArgs {
   const cf *bf;     // fft kernel: kernel spectrum / M, [16][T]
   double *partSum;  // [nCpi][partsPerCpi]
   float *partMax;   // [nCpi][partsPerCpi]
-  int32_t nD, nDelay, nTiles, nGroups;
-  uint32_t *counter; // [nCpi] arrival tickets, zero between launches
-  double *metrics;   // [nCpi][2]
-  double cells;      // nD * nDelay
+  int32_t nD, nDelay, nTiles;
 };
 
 // 10*log10|z| = 5*log10(re^2+im^2) = 5*log10(2) * log2(re^2+im^2)
@@ -541,25 +524,42 @@ __global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a)
   }
 }
 
-// Tile variant for 513 < nD <= 1025 (M = 2048: a column is a 128-thread, two-wave
-// transform): 8 columns per 1024-thread workgroup, same phases as doppler_tile_kernel.
-// A column's exchange buffer is ONE region (stage 2 works inside rows of 8 consecutive
-// threads, i.e. inside a wave, so it runs in place); the stage boundaries are
-// workgroup barriers, all columns advance in lockstep.  155 KB of LDS: one workgroup
-// per CU, 4 waves per SIMD.
-constexpr int DOPM_R3 = 8;
-constexpr int DOPM_NCOL = 8;
-constexpr int DOPM_REGION = WgFft<DOPM_R3>::A_ELEMS; // 2176 complex values per column
-constexpr int DOPM_LDS_ELEMS = DOPM_NCOL * DOPM_REGION + WgFft<DOPM_R3>::F;
+// Tile variant for multi-wave columns: 513 < nD <= 1025 (M = 2048, R3 = 8: a column is a
+// 128-thread, two-wave transform, 8 columns per 1024-thread workgroup) and 1025 < nD <= 2049
+// (M = 4096, R3 = 16: 256 threads per column, 4 columns per workgroup).  Same phases as
+// doppler_tile_kernel.  A column's exchange buffer is ONE region (stage 2 works inside rows
+// of R3 consecutive threads, i.e. inside a wave, so it runs in place); the stage boundaries
+// are workgroup barriers, all columns advance in lockstep.  LDS: 8 x 17 KB + the kernel
+// spectrum (16 KB) = 155 KB, or 4 x 34 KB = 139 KB (R3 = 16 reads the kernel spectrum, which
+// every workgroup shares, from L2 instead): one workgroup per CU, 4 waves per SIMD.
+template <int R3> struct DopM {
+  using W = WgFft<R3>;
+  static constexpr int NCOL = 1024 / W::T;          // 8 or 4
+  static constexpr int SH = (NCOL == 8) ? 3 : 2;
+  static constexpr int REGION = W::A_ELEMS;         // complex values per column
+  static constexpr bool BF_LDS = (R3 == 8);
+  static constexpr int LDS_ELEMS = NCOL * REGION + (BF_LDS ? W::F : 0);
+  static constexpr int MAX_ND = 9 * W::T - (W::T - 1); // rows t + T*k, k < 9: 1025 / 2049
+};
 
+// hides a value's provenance from the optimiser, so that addresses derived from it are
+// recomputed where they are used instead of being kept live (and spilled) from their first use
+__device__ __forceinline__ int relaunder(int v)
+{
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+template <int R3>
 __global__ __launch_bounds__(1024) void doppler_tilem_kernel(DopplerArgs a)
 {
-  using W = WgFft<DOPM_R3>;
-  constexpr int T = W::T;   // 128 threads per column
-  constexpr int NCOL = DOPM_NCOL;
+  using D = DopM<R3>;
+  using W = WgFft<R3>;
+  constexpr int T = W::T;   // threads per column
+  constexpr int NCOL = D::NCOL;
   constexpr int NT = 1024;
-  constexpr int NR = 9;     // rows t + 128*k, k < 9, cover nD <= 1025 (+ padding)
-  constexpr int NRT = 9;    // tile cells per thread: nD * 8 / 1024 <= 8.01
+  constexpr int NR = 9;     // rows t + T*k, k < 9, cover nD <= MAX_ND
+  constexpr int NRT = 9;    // tile cells per thread: nD * NCOL / 1024 <= 8.01
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf *lds = reinterpret_cast<cf *>(smem);
   const int tid = threadIdx.x;
@@ -567,8 +567,8 @@ __global__ __launch_bounds__(1024) void doppler_tilem_kernel(DopplerArgs a)
   const int nD = a.nD;
   const int sub = blockIdx.x, cpi = blockIdx.y;
   const int col0 = sub * NCOL;
-  cf *region = lds + w * DOPM_REGION;
-  cf *bfL = lds + NCOL * DOPM_REGION;
+  cf *region = lds + w * D::REGION;
+  cf *bfL = lds + NCOL * D::REGION;
 
   // phase 1: coalesced tile read, all loads in flight before the first use
   const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, col0);
@@ -577,24 +577,33 @@ __global__ __launch_bounds__(1024) void doppler_tilem_kernel(DopplerArgs a)
 #pragma unroll
   for (int j = 0; j < NRT; j++) {
     const int idx = tid + NT * j;
-    const int c = idx & (NCOL - 1), row = idx >> 3;
+    const int c = idx & (NCOL - 1), row = idx >> D::SH;
     v[j] = Rt[idx < cells ? row * 16 + c : 0];
   }
   cf bfs[W::F / NT];
+  if (D::BF_LDS) {
 #pragma unroll
-  for (int j = 0; j < W::F / NT; j++) bfs[j] = a.bf[tid + NT * j];
+    for (int j = 0; j < W::F / NT; j++) bfs[j] = a.bf[tid + NT * j];
+  }
+  // R3 = 16 carries 15 stage-3 twiddles (7 for R3 = 8) and would spill at the 128 VGPRs a
+  // 1024-thread workgroup leaves: there each twiddle set and the chirp are fetched (L1/L2)
+  // right before the stage that uses them instead of being held across the whole transform
+  constexpr bool RELOAD = (R3 == 16);
   cf tw1[15], tw3[16], ch[NR];
-  W::load_twiddles(t, a.tw, tw1, tw3);
+  if (RELOAD) W::load_tw1(t, a.tw, tw1);
+  else W::load_twiddles(t, a.tw, tw1, tw3);
 #pragma unroll
   for (int k = 0; k < NR; k++) ch[k] = a.chirp[min(t + T * k, nD - 1)];
 #pragma unroll
   for (int j = 0; j < NRT; j++) {
     const int idx = tid + NT * j;
-    const int c = idx & (NCOL - 1), row = idx >> 3;
-    if (idx < cells) lds[c * DOPM_REGION + row] = v[j];
+    const int c = idx & (NCOL - 1), row = idx >> D::SH;
+    if (idx < cells) lds[c * D::REGION + row] = v[j];
   }
+  if (D::BF_LDS) {
 #pragma unroll
-  for (int j = 0; j < W::F / NT; j++) bfL[tid + NT * j] = bfs[j];
+    for (int j = 0; j < W::F / NT; j++) bfL[tid + NT * j] = bfs[j];
+  }
   __syncthreads();
 
   // phase 2: column -> registers (DC removal + chirp), transform, x kernel spectrum, inverse
@@ -615,9 +624,10 @@ __global__ __launch_bounds__(1024) void doppler_tilem_kernel(DopplerArgs a)
   dft16<-1>(v);
   W::fwd_s2_store(t, v, region);
   __syncthreads();
+  if (RELOAD) W::load_tw3(relaunder(t), a.tw, tw3);
   W::fwd_s3(t, v, tw3, region);
 #pragma unroll
-  for (int e = 0; e < 16; e++) v[e] = cmul(v[e], bfL[e * T + t]);
+  for (int e = 0; e < 16; e++) v[e] = cmul(v[e], D::BF_LDS ? bfL[e * T + t] : a.bf[e * T + t]);
   __syncthreads();
   W::inv_s1(t, v, tw3, region);
   __syncthreads();
@@ -625,10 +635,16 @@ __global__ __launch_bounds__(1024) void doppler_tilem_kernel(DopplerArgs a)
   dft16<+1>(v);
   W::inv_s2_store(t, v, region);
   __syncthreads();
+  if (RELOAD) W::load_tw1(relaunder(t), a.tw, tw1);
   W::inv_s3(t, v, tw1, region);
   __syncthreads();
 
   // phase 3: rotate rows by nD/2+1 and park the column back in its region
+  if (RELOAD) {
+    const int tl = relaunder(t);
+#pragma unroll
+    for (int k = 0; k < NR; k++) ch[k] = a.chirp[min(tl + T * k, nD - 1)];
+  }
 #pragma unroll
   for (int c = 0; c < NR; c++) {
     const int k = t + T * c;
@@ -648,9 +664,9 @@ __global__ __launch_bounds__(1024) void doppler_tilem_kernel(DopplerArgs a)
 #pragma unroll
   for (int j = 0; j < NRT; j++) {
     const int idx = tid + NT * j;
-    const int c = idx & (NCOL - 1), o = idx >> 3;
+    const int c = idx & (NCOL - 1), o = idx >> D::SH;
     const bool ok = idx < cells && c < ncol;
-    const cf d = lds[c * DOPM_REGION + min(o, nD - 1)];
+    const cf d = lds[c * D::REGION + min(o, nD - 1)];
     if (ok) mapb[(size_t)o * a.nDelay + c] = d;
     const float db = db_of(d);
     lsum += ok ? (double)db : 0.0;

@@ -55,12 +55,10 @@ struct InI16 {
   B2_HD cf ly(int64_t i) const { return cmake((float)iq[4 * i + 2], (float)iq[4 * i + 3]); }
 };
 
-// Loads are branch-free: the index is clamped into the pulse, all loads of a thread
-// issue back to back (so their HBM latencies overlap), and the segment / pulse masks
-// are applied afterwards with selects (mask_seg_*).  Clamped lanes re-read the last
-// sample of the pulse, an L1 hit.  (Skipping the sample groups beyond the needed
-// window with uniform branches was measured: -10 % -- the branches break up the
-// load burst -- although it removes 20 % of the L1 traffic.)
+// load_seg_* / mask_seg_* below DEFINE the segment windows (clamped index, then a
+// select).  The GPU kernels fetch the same windows with raw buffer loads whose
+// range check does the zero padding (bufload.hpp); these portable forms are what
+// tests/host/emulate_fft.cpp runs on the CPU to check the index algebra.
 #if defined(__clang__)
 // fp16 IQ storage with fp32 accumulate (BASELINE.json configs[4]): two planes of
 // (re, im) half pairs, 4 bytes per sample; every value is widened to fp32 on load
@@ -125,51 +123,7 @@ B2_HD void mask_seg_y(const RangePlan &p, int s, int t, cf *v)
 
 B2_HD int64_t rmap_index(int nDoppler, int nTiles, int cpi, int pulse, int lag);
 
-// ---- the same loaders / masks / store for a transform with E points per thread
-// and T threads (fft_wg8.hpp: E = 8) -------------------------------------------
-template <int T, int E, class In>
-B2_HD void load_seg_x_g(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, cf *v)
-{
-  const int s0 = s * p.segLen + t;
-#pragma unroll
-  for (int k = 0; k < E; k++) {
-    const int idx = s0 + T * k;
-    v[k] = in.lx(pulseBase + (idx < p.nCorr ? idx : p.nCorr - 1));
-  }
-}
-
-template <int T, int E> B2_HD void mask_seg_x_g(const RangePlan &p, int s, int t, cf *v)
-{
-  const int s0 = s * p.segLen;
-#pragma unroll
-  for (int k = 0; k < E; k++) {
-    const int m = t + T * k;
-    v[k] = ((m < p.segLen) && (s0 + m < p.nCorr)) ? v[k] : cmake(0.f, 0.f);
-  }
-}
-
-template <int T, int E, class In>
-B2_HD void load_seg_y_g(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, cf *v)
-{
-  const int s0 = s * p.segLen + p.delayMin + t;
-#pragma unroll
-  for (int k = 0; k < E; k++) {
-    const int idx = s0 + T * k;
-    const int cl = idx < 0 ? 0 : (idx < p.nCorr ? idx : p.nCorr - 1);
-    v[k] = in.ly(pulseBase + cl);
-  }
-}
-
-template <int T, int E> B2_HD void mask_seg_y_g(const RangePlan &p, int s, int t, cf *v)
-{
-  const int s0 = s * p.segLen + p.delayMin + t;
-#pragma unroll
-  for (int k = 0; k < E; k++) {
-    const int idx = s0 + T * k;
-    v[k] = (idx >= 0 && idx < p.nCorr) ? v[k] : cmake(0.f, 0.f);
-  }
-}
-
+// ---- lag store for a transform with E points per thread and T threads (fft_wg8.hpp: E = 8)
 template <int T, int E>
 B2_HD void store_lags_g(cf *out, const RangePlan &p, int cpi, int pulse, int t, const cf *v)
 {

@@ -57,17 +57,33 @@ template <class T> uint32_t Map<T>::doppler_hz_to_bin(double hz)
   return 0;
 }
 
+// A cheap fingerprint of the cells (every cell's bit pattern, FNV-1a style over 64-bit words):
+// tells whether `data` is still what the engine delivered.
+template <class T> uint64_t Map<T>::fingerprint() const
+{
+  uint64_t h = 1469598103934665603ull;
+  for (const auto &row : data) {
+    const uint64_t *w = reinterpret_cast<const uint64_t *>(row.data());
+    const size_t nw = row.size() * sizeof(T) / sizeof(uint64_t);
+    for (size_t i = 0; i < nw; i++) h = (h ^ w[i]) * 1099511628211ull;
+  }
+  return h;
+}
+
 // Map::set_metrics (reference Map.cpp:187-206): noisePower = mean(10 log10|z|),
 // maxPower = max(0, max 10 log10|z|) - noisePower.  For a map that came out of
-// the GPU engine the reduction was fused into the Doppler kernel and the
-// values are adopted from there; any other map is reduced here in fp64.
+// the GPU engine AND whose cells are untouched since, the reduction was fused into
+// the Doppler kernel and the values are adopted from there; any other map
+// (built by the caller, or modified after Ambiguity::process) is reduced here in
+// fp64 exactly like the reference.
 template <class T> void Map<T>::set_metrics()
 {
-  if (engineMetricsValid) {
+  if (engineMetricsValid && fingerprint() == engineFingerprint) {
     noisePower = engineNoise;
     maxPower = engineMax;
     return;
   }
+  engineMetricsValid = false;
   double sum = 0.0, peak = 0.0;
   for (uint32_t i = 0; i < nRows; i++)
     for (uint32_t j = 0; j < nCols; j++) {

@@ -26,6 +26,8 @@ private:
   uint32_t engineCpi = 0;
   double engineNoise = 0.0, engineMax = 0.0;
   bool engineMetricsValid = false;
+  uint64_t engineFingerprint = 0; // of `data` as the engine delivered it
+  uint64_t fingerprint() const;
 
 public:
   std::vector<std::vector<T>> data;
@@ -51,11 +53,14 @@ public:
   bool save(std::string json, std::string path);
 
   // ---- extensions used by the GPU classes --------------------------------
+  // called by Ambiguity::process after it has filled `data`
   void bind_engine(blah2hip_amb_s *h, uint32_t cpi, double noise, double peak)
   {
     engine = h; engineCpi = cpi; engineNoise = noise; engineMax = peak; engineMetricsValid = true;
+    engineFingerprint = fingerprint();
   }
-  blah2hip_amb_s *get_engine() const { return engine; }
+  // the engine whose device copy still equals `data` (nullptr once the caller has changed the cells)
+  blah2hip_amb_s *get_engine() const { return (engine && fingerprint() == engineFingerprint) ? engine : nullptr; }
   uint32_t get_engine_cpi() const { return engineCpi; }
 };
 

@@ -132,6 +132,31 @@ int main()
     CHECK(js.find("\"delay\":[-2.99,-2.69") != std::string::npos); // -10*c/fs/1000 = -2.9979 -> truncated
     std::printf("chain: %zu detections, noisePower %.3f maxPower %.3f, json %zu bytes\n", dl.size(),
                 map->noisePower, map->maxPower, js.size());
+
+    // Map::set_metrics is not sticky (reference Map.cpp:187-206 always reduces `data`): change the cells
+    // and the values follow; CfarDetector1D then runs on the caller's cells (uploaded), not on the
+    // engine's stale device copy.
+    const double noise0 = map->noisePower, max0 = map->maxPower;
+    const size_t nDet0 = det1->get_nDetections();
+    map->set_metrics();
+    CHECK(map->noisePower == noise0 && map->maxPower == max0); // untouched: adopted again
+    for (auto &row : map->data)
+      for (auto &v : row) v *= 10.0; // +10 dB on every cell
+    map->set_metrics();
+    CHECK(std::fabs(map->noisePower - (noise0 + 10.0)) < 1e-3);
+    CHECK(std::fabs(map->maxPower - max0) < 1e-3);
+    auto det10 = cfar.process(map); // scale-free detector: same cells fire, snr unchanged (both shift by 10 dB)
+    CHECK(det10->get_nDetections() == nDet0);
+    CHECK(det10->get_delay() == det1->get_delay() && det10->get_doppler() == det1->get_doppler());
+    // a map the caller builds from scratch: one strong cell on a flat floor
+    Map<std::complex<double>> own(5, 40);
+    for (int j = 0; j < 40; j++) own.delay.push_back(j - 2);
+    for (int i = 0; i < 5; i++) own.doppler.push_back(20.0 * (i - 2));
+    own.data[4][20] = {1000.0, 0.0};
+    own.set_metrics();
+    CHECK(std::fabs(own.noisePower - 30.0 / 200.0) < 1e-12 && std::fabs(own.maxPower - (30.0 - 0.15)) < 1e-12);
+    auto detOwn = CfarDetector1D(1e-3, 1, 4, 0, 15.0).process(&own);
+    CHECK(detOwn->get_nDetections() == 1 && detOwn->get_delay()[0] == 18.0 && detOwn->get_doppler()[0] == 40.0);
   }
   std::printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
   return failures ? 1 : 0;

@@ -82,7 +82,8 @@ inline bool write_double(std::string &out, double v, int maxDec = 2)
   if (v == 0.0) { out += std::signbit(v) ? "-0.0" : "0.0"; return true; }
   if (v < 0) { out.push_back('-'); v = -v; }
   char buf[64];
-  auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::scientific);
+  auto r = std::to_chars(buf, buf + sizeof buf - 1, v, std::chars_format::scientific);
+  *r.ptr = '\0'; // to_chars does not terminate; the exponent is parsed with atoi below
   // d[.ddd]e[+-]XX  ->  digit string + decimal exponent
   char digits[32];
   int len = 0, exp10 = 0;

@@ -179,6 +179,24 @@ class Ambiguity:
         """Enqueue the fp32 dB map Map::to_json prints (10*log10|M| - noisePower) for n_cpi maps."""
         check(self._L.blah2hip_amb_db_dev(self._h, d_map, d_metrics, n_cpi, d_db, stream))
 
+    # -- execution plan (engine-specific, not part of the reference surface) ----
+    def set_doppler_kernel(self, which):
+        """Force one of the Doppler kernels (``_lib.DOP_*`` or its name); 'auto' picks by launch size."""
+        if isinstance(which, str):
+            which = {v: k for k, v in _lib.DOPPLER_KERNEL_NAMES.items()}[which]
+        check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_DOPPLER_KERNEL, int(which)))
+
+    def set_range_grid(self, n):
+        check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_RANGE_GRID, int(n)))
+
+    def info(self, key):
+        v = C.c_int64(0)
+        check(self._L.blah2hip_amb_get_info(self._h, key, C.byref(v)))
+        return v.value
+
+    def last_doppler_kernel(self):
+        return _lib.DOPPLER_KERNEL_NAMES[self.info(_lib.INFO_LAST_DOPPLER_KERNEL)]
+
     # -- per-kernel timing -----------------------------------------------------
     def set_timing(self, enable=True):
         check(self._L.blah2hip_amb_set_timing(self._h, 1 if enable else 0))
@@ -214,6 +232,27 @@ class CfarDetector1D:
         k = n.value
         return Detection(d[:k].copy(), f[:k].copy(), s[:k].copy())
 
+    def process_dev(self, amb, n_cpi, d_hits, cap, d_count, d_map=None, d_metrics=None, stream=0):
+        """Enqueue the detector for n_cpi device-resident maps (None = the engine's internal buffers of the
+        last process_dev): hit records into d_hits [n_cpi][cap], counts into d_count [n_cpi]."""
+        check(amb._L.blah2hip_cfar1d_dev(amb._h, d_map, d_metrics, n_cpi, self.pfa, self.nGuard, self.nTrain,
+                                         self.minDelay, self.minDoppler, d_hits, cap, d_count, stream))
+
+
+def hits_to_detection(amb, hits, count, cap):
+    """One CPI's device hit records (``blah2hip_hit_t``: int32 row, int32 col, double snr; arbitrary
+    order) -> :class:`Detection` in the reference's row-major emission order
+    (CfarDetector1D.cpp:36-92: delay = col + delay[0], doppler = doppler[row])."""
+    if count > cap:
+        raise Blah2HipError(_lib.ERR_CAPACITY, f"{count} detections, capacity {cap}")
+    h = np.asarray(hits[:count])
+    order = np.lexsort((h["col"], h["row"]))
+    h = h[order]
+    return Detection(h["col"].astype(np.float64) + float(amb.delay[0]), amb.doppler[h["row"]], h["snr"].astype(np.float64))
+
+
+HIT_DTYPE = np.dtype([("row", np.int32), ("col", np.int32), ("snr", np.float64)])
+
 
 class CfarDetector2D:
     """2-D cell-averaging CFAR (BASELINE.json configs[2]).  Not a reference class:
@@ -235,6 +274,10 @@ class CfarDetector2D:
                                              self.minDoppler, _ptr(d), _ptr(f), _ptr(s), cap, C.byref(n)))
         k = n.value
         return Detection(d[:k].copy(), f[:k].copy(), s[:k].copy())
+
+    def process_dev(self, amb, n_cpi, d_hits, cap, d_count, d_map=None, d_metrics=None, stream=0):
+        check(amb._L.blah2hip_cfar2d_dev(amb._h, d_map, d_metrics, n_cpi, self.pfa, *self.p, self.minDelay,
+                                         self.minDoppler, d_hits, cap, d_count, stream))
 
 
 class Centroid:
@@ -289,6 +332,9 @@ class WienerHopf:
         check(L.blah2hip_clutter_create(delayMin, delayMax, nSamples, device, max_batch, C.byref(h)))
         self._h, self._L = h, L
         self.nSamples = nSamples
+        nb, fl, sl = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(L.blah2hip_clutter_get_dims(h, C.byref(nb), C.byref(fl), C.byref(sl)))
+        self.nBins, self.fft_len, self.seg_len = nb.value, fl.value, sl.value
 
     def close(self):
         if getattr(self, "_h", None):
@@ -304,6 +350,9 @@ class WienerHopf:
     def process(self, x, y):
         x = np.ascontiguousarray(x)
         y = np.ascontiguousarray(y)
+        if x.shape[0] != self.nSamples or y.shape[0] != self.nSamples:
+            # the reference sizes its plans for nSamples (WienerHopf.cpp:7-56) and reads exactly that many
+            raise ValueError(f"WienerHopf.process needs {self.nSamples} samples per channel, got {x.shape[0]} and {y.shape[0]}")
         ok = C.c_int(0)
         if x.dtype == np.complex64 and y.dtype == np.complex64:
             out = np.empty(self.nSamples, dtype=np.complex64)
@@ -318,6 +367,24 @@ class WienerHopf:
     def process_dev(self, d_x, d_y, n_cpi, cpi_stride, d_y_out, d_ok=None, stream=0):
         """Enqueue on ``stream``: device complex64 planes, output may alias d_y."""
         check(self._L.blah2hip_clutter_process_dev(self._h, d_x, d_y, n_cpi, cpi_stride, d_y_out, d_ok, stream))
+
+    def read_last(self, cpi=0):
+        """(ok, w, r, b) of CPI ``cpi`` of the last call: the nBins filter taps (complex64) and the fp64
+        correlations r, b of the normal equations A w = b, A[i][j] = r[i-j] (diagnostics)."""
+        w = np.empty(self.nBins, dtype=np.complex64)
+        rb = np.empty(2 * self.nBins, dtype=np.complex128)
+        ok = C.c_int(0)
+        check(self._L.blah2hip_clutter_read_last(self._h, cpi, _ptr(w), _ptr(rb), C.byref(ok)))
+        return bool(ok.value), w, rb[:self.nBins].copy(), rb[self.nBins:].copy()
+
+    def set_timing(self, enable=True):
+        check(self._L.blah2hip_clutter_set_timing(self._h, 1 if enable else 0))
+
+    def get_timing(self):
+        ms = np.zeros(_lib.CK_COUNT, dtype=np.float64)
+        cnt = np.zeros(_lib.CK_COUNT, dtype=np.uint32)
+        check(self._L.blah2hip_clutter_get_timing(self._h, _ptr(ms), _ptr(cnt)))
+        return {name: (float(ms[k]), int(cnt[k])) for k, name in _lib.CLUTTER_KERNEL_NAMES.items()}
 
 
 class SpectrumAnalyser:

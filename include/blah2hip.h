@@ -27,7 +27,11 @@
  *     own stream and return when the results are in the output buffers.
  *   - "dev" entry points take device pointers that are already resident in HBM
  *     and a hipStream_t (as void*); they only enqueue work and never
- *     synchronise.  This is the chain the benchmark times.
+ *     synchronise.  This is the chain the benchmark times.  Everything a dev
+ *     call needs is allocated at *_create; the two exceptions are named where
+ *     they occur (blah2hip_cfar1d_prepare / blah2hip_cfar2d_prepare: a threshold
+ *     table per parameter tuple and the 2-D detector's summed-area table, built
+ *     by the first call that needs them or ahead of time by *_prepare).
  *   - a handle is not re-entrant: one thread at a time, like the reference's
  *     objects (all three process() calls run on blah2.cpp's single t2 thread).
  *   - maps are complex fp32, interleaved (re,im), row-major [doppler][delay],
@@ -105,10 +109,38 @@ int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_mi
 int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler_min, int32_t doppler_max,
                            uint32_t fs, uint32_t n, int round_hamming, uint32_t n_doppler_bins,
                            int device, uint32_t max_batch, blah2hip_amb_t *out);
+/* Geometry limits of the on-chip transforms (BLAH2HIP_ERR_UNSUPPORTED beyond them; the
+ * reference's own limit is the uint16 narrowing of Ambiguity.h:80-89):
+ *   - n_delay_bins <= 4081 (range transform F <= 4096 with at least 16 samples per segment);
+ *   - the lag window must not reach the lags the reference's nfft-point CIRCULAR correlation
+ *     aliases: max(|delay_min|, |delay_max|) <= nfft - n_corr (Ambiguity.cpp:132-146 reads
+ *     index nfft + d for d < 0; beyond that bound the reference returns the opposite-sign
+ *     lag, this engine would return 0);
+ *   - Doppler lengths above 2049 run on the direct-DFT kernel (correct, slow). */
 int blah2hip_amb_destroy(blah2hip_amb_t h);
 int blah2hip_amb_get_dims(blah2hip_amb_t h, blah2hip_amb_dims_t *dims);
 /* Map::delay (bins, length n_delay_bins) and Map::doppler (Hz, length n_doppler_bins) */
 int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
+
+/* Execution plan, per handle.  Options take effect on the next process call. */
+#define BLAH2HIP_OPT_DOPPLER_KERNEL 1 /* BLAH2HIP_DOP_*; AUTO picks by launch size */
+#define BLAH2HIP_OPT_RANGE_GRID 2     /* workgroups of the range kernel; 0 = residency default */
+#define BLAH2HIP_DOP_AUTO 0
+#define BLAH2HIP_DOP_TILE8 1   /* nD <= 513: 8-column tiles, one wave per column */
+#define BLAH2HIP_DOP_TILE16 2  /* nD <= 513: 16-column tiles */
+#define BLAH2HIP_DOP_TILEM 3   /* 513 < nD <= 2049: multi-wave columns, 8 or 4 per workgroup */
+#define BLAH2HIP_DOP_COLUMN 4  /* nD <= 2049: one column per workgroup (small launches) */
+#define BLAH2HIP_DOP_DIRECT 5  /* any nD: direct DFT */
+#define BLAH2HIP_RANGE_E16 1   /* 16 points per thread (F = 2048, 4096) */
+#define BLAH2HIP_RANGE_E8 2    /* 8 points per thread (F = 1024) */
+/* BLAH2HIP_ERR_UNSUPPORTED when the kernel does not cover the handle's Doppler length */
+int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value);
+#define BLAH2HIP_INFO_LAST_DOPPLER_KERNEL 1 /* BLAH2HIP_DOP_* the last process call launched (0 = none yet) */
+#define BLAH2HIP_INFO_LAST_RANGE_KERNEL 2   /* BLAH2HIP_RANGE_* */
+#define BLAH2HIP_INFO_DOPPLER_FFT_LEN 3     /* chirp-z transform length M (0 = direct DFT only) */
+#define BLAH2HIP_INFO_RANGE_GRID 4
+#define BLAH2HIP_INFO_NUM_CU 5
+int blah2hip_amb_get_info(blah2hip_amb_t h, int key, int64_t *value);
 
 /* Ambiguity::process + Map::set_metrics on host buffers (blah2.cpp:278-279).
  * x = reference, y = surveillance, n complex samples each (n >= n_used, only
@@ -147,12 +179,24 @@ int blah2hip_cfar1d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
                         uint32_t n_cpi, double pfa, int32_t n_guard, int32_t n_train,
                         int32_t min_delay, double min_doppler, blah2hip_hit_t *d_hits,
                         uint32_t cap, uint32_t *d_count, void *stream);
+/* Builds the threshold table alpha[n] = n (pfa^(-1/n) - 1) for this (pfa, n_train) ahead of
+ * time (one blocking upload).  blah2hip_cfar1d_dev does it on the first call with a new
+ * tuple and only enqueues afterwards. */
+int blah2hip_cfar1d_prepare(blah2hip_amb_t h, double pfa, int32_t n_train);
 /* host: runs the detector on CPI `cpi` of the handle's internal map and
  * returns Detection's three vectors (delay bins, Doppler Hz, snr) in the
  * reference's emission order (row-major, CfarDetector1D.cpp:36-92). */
 int blah2hip_cfar1d_process(blah2hip_amb_t h, uint32_t cpi, double pfa, int32_t n_guard,
                             int32_t n_train, int32_t min_delay, double min_doppler, double *delay,
                             double *doppler, double *snr, uint32_t cap, uint32_t *count);
+
+/* The same detector on a map held by the HOST (any Map<complex<double>>, e.g. one the caller
+ * modified or built itself): complex fp32 cells [n_doppler][n_delay], Map::delay (bins),
+ * Map::doppler (Hz) and Map::noisePower.  Uploads, runs the GPU kernel on `device`, frees. */
+int blah2hip_cfar1d_map(const float *map, uint32_t n_doppler, uint32_t n_delay, const int32_t *delay_axis,
+                        const double *doppler_axis, double noise_power, double pfa, int32_t n_guard,
+                        int32_t n_train, int32_t min_delay, double min_doppler, int device, double *delay,
+                        double *doppler, double *snr, uint32_t cap, uint32_t *count);
 
 /* 2-D cell-averaging CFAR (BASELINE.json configs[2]; NOT in the reference, which
  * only has the 1-D detector).  Extension defined in SURVEY.md section 8g: training
@@ -165,6 +209,10 @@ int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
                         int32_t n_guard_doppler, int32_t n_train_doppler, int32_t min_delay,
                         double min_doppler, blah2hip_hit_t *d_hits, uint32_t cap, uint32_t *d_count,
                         void *stream);
+/* Allocates the summed-area table ([max_batch][nD+1][nDelay+1] doubles) and builds the
+ * threshold table for this parameter tuple; blah2hip_cfar2d_dev calls it implicitly. */
+int blah2hip_cfar2d_prepare(blah2hip_amb_t h, double pfa, int32_t n_guard_delay, int32_t n_train_delay,
+                            int32_t n_guard_doppler, int32_t n_train_doppler);
 int blah2hip_cfar2d_process(blah2hip_amb_t h, uint32_t cpi, double pfa, int32_t n_guard_delay,
                             int32_t n_train_delay, int32_t n_guard_doppler, int32_t n_train_doppler,
                             int32_t min_delay, double min_doppler, double *delay, double *doppler,
@@ -205,6 +253,14 @@ int blah2hip_clutter_process_c32(blah2hip_clutter_t h, const float *x, const flo
 int blah2hip_clutter_process_dev(blah2hip_clutter_t h, const void *d_x, const void *d_y,
                                  uint32_t n_cpi, uint64_t cpi_stride, void *d_y_out, int32_t *d_ok,
                                  void *stream);
+/* Derived sizes: nBins = delayMax - delayMin taps (WienerHopf.cpp:12), on-chip transform
+ * length and samples per overlap-save block. */
+int blah2hip_clutter_get_dims(blah2hip_clutter_t h, uint32_t *n_bins, uint32_t *fft_len, uint32_t *seg_len);
+/* Copies CPI `cpi` of the last process call's filter to the host (synchronises): the nBins
+ * taps w (complex fp32, interleaved), the fp64 correlations the normal equations were built
+ * from, r then b (2*nBins complex fp64, interleaved), and the ok flag.  Any output may be NULL.
+ * For diagnostics (residual of A w = b) and tests. */
+int blah2hip_clutter_read_last(blah2hip_clutter_t h, uint32_t cpi, float *w, double *rb, int *ok);
 
 /* ---- SpectrumAnalyser (SpectrumAnalyser.h:53-62, called blah2.cpp:264) ----
  * decimation = uint32(n/bandwidth), nSpectrum = n/decimation, nfft = nSpectrum*decimation
@@ -229,13 +285,24 @@ int blah2hip_spectrum_process_dev(blah2hip_spectrum_t h, int fmt, const void *d_
 #define BLAH2HIP_K_RANGE 0
 #define BLAH2HIP_K_DOPPLER 1
 #define BLAH2HIP_K_METRICS 2
-#define BLAH2HIP_K_CFAR 3
+#define BLAH2HIP_K_CFAR 3     /* cfar1d_kernel or cfar2d_kernel */
+#define BLAH2HIP_K_SAT_ROWS 4 /* 2-D CFAR: row prefix sums */
+#define BLAH2HIP_K_SAT_COLS 5 /* 2-D CFAR: column prefix sums */
+#define BLAH2HIP_K_ROTATE 6   /* Doppler-centre shift (asymmetric limits only) */
 #define BLAH2HIP_K_COUNT 8
 /* enable != 0: every dev call brackets each kernel with hipEvents */
 int blah2hip_amb_set_timing(blah2hip_amb_t h, int enable);
 /* synchronises the recorded events; ms_total[k] = summed duration of kernel k
  * over launches[k] launches since the last reset; then resets */
 int blah2hip_amb_get_timing(blah2hip_amb_t h, double *ms_total, uint32_t *launches);
+/* the same for the clutter filter's kernels */
+#define BLAH2HIP_CK_CORR 0
+#define BLAH2HIP_CK_REDUCE 1
+#define BLAH2HIP_CK_SOLVE 2
+#define BLAH2HIP_CK_FIR 3
+#define BLAH2HIP_CK_COUNT 4
+int blah2hip_clutter_set_timing(blah2hip_clutter_t h, int enable);
+int blah2hip_clutter_get_timing(blah2hip_clutter_t h, double *ms_total, uint32_t *launches);
 
 #ifdef __cplusplus
 }

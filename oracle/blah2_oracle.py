@@ -109,11 +109,13 @@ def ambiguity_dims(delay_min, delay_max, doppler_min, doppler_max, fs, n, round_
 
 
 # --------------------------------------------------------------------------
-def ambiguity_process(dims: AmbiguityDims, x, y):
+def ambiguity_process(dims: AmbiguityDims, x, y, workers=None):
     """``Ambiguity::process`` (Ambiguity.cpp:92-172).
 
     x = reference, y = surveillance, complex, at least n_corr*n_doppler_bins
     samples.  Returns the complex128 map [n_doppler_bins, n_delay_bins].
+    ``workers``: pocketfft threads over the batch of pulses (the reference plans FFTW
+    with 4 threads, blah2.cpp:115-120); results do not depend on it.
     """
     x = np.asarray(x, dtype=np.complex128)
     y = np.asarray(y, dtype=np.complex128)
@@ -125,14 +127,15 @@ def ambiguity_process(dims: AmbiguityDims, x, y):
     X = x[:used].reshape(nD, nC)
     Y = y[:used].reshape(nD, nC)
     # :108-129 zero-pad each pulse to nfft, Y*conj(X)/nfft, unnormalised backward FFT
-    FX = _fft.fft(X, n=nfft, axis=1)
-    FY = _fft.fft(Y, n=nfft, axis=1)
-    Z = _fft.ifft(FY * np.conj(FX), axis=1)  # = backward(FY*conj(FX)/nfft)
+    kw = {"workers": workers} if workers else {}
+    FX = _fft.fft(X, n=nfft, axis=1, **kw)
+    FY = _fft.fft(Y, n=nfft, axis=1, **kw)
+    Z = _fft.ifft(FY * np.conj(FX), axis=1, **kw)  # = backward(FY*conj(FX)/nfft)
     # :132-146 nets to R[i][j] = z[(delayMin + j) mod nfft]
     lag = (dims.delay_min + np.arange(dims.n_delay_bins)) % nfft
     R = Z[:, lag]
     # :152-169 forward FFT over pulses, out[j] = D[(j + nD//2 + 1) % nD]
-    D = _fft.fft(R, axis=0)
+    D = _fft.fft(R, axis=0, **kw)
     sel = (np.arange(nD) + nD // 2 + 1) % nD
     return D[sel, :]
 
@@ -338,11 +341,12 @@ def spectrum_process(x, n, bandwidth):
 
 
 # --------------------------------------------------------------------------
-def wiener_hopf(x, y, delay_min, delay_max):
+def wiener_hopf(x, y, delay_min, delay_max, return_filter=False):
     """``WienerHopf::process`` (src/process/clutter/WienerHopf.cpp:58-163).
 
     Returns (ok, y_filtered).  x is not modified.  ``nBins = delayMax-delayMin``
-    (no +1, :12).
+    (no +1, :12).  With ``return_filter`` also the taps w, the matrix's first
+    column r (A[i][j] = r[i-j]) and the right-hand side b of A w = b.
     """
     import scipy.linalg as sla
 
@@ -370,13 +374,29 @@ def wiener_hopf(x, y, delay_min, delay_max):
     try:
         U = sla.cholesky(A, lower=False)
     except np.linalg.LinAlgError:
-        return False, y.copy()
+        return (False, y.copy(), None, r, b) if return_filter else (False, y.copy())
     t = sla.solve_triangular(U.conj().T, b, lower=True)
     w = sla.solve_triangular(U, t, lower=False)
     # :125-160  y - (w * xs)[0:N]  (linear convolution; the FFT length is immaterial)
     L = n_bins + n + 1
     filt = _fft.ifft(_fft.fft(xs, n=L) * _fft.fft(w, n=L))[:n]
+    if return_filter:
+        return True, y - filt, w, r, b
     return True, y - filt
+
+
+def toeplitz_residual(r, w, b):
+    """||A w - b|| / ||b|| for the Hermitian Toeplitz A[i][j] = r[i-j] (r[-k] = conj r[k]) of
+    WienerHopf.cpp:85-97, evaluated with an FFT product in fp64."""
+    r = np.asarray(r, dtype=np.complex128)
+    w = np.asarray(w, dtype=np.complex128)
+    n = r.shape[0]
+    L = 1 << int(np.ceil(np.log2(2 * n)))
+    c = np.zeros(L, dtype=np.complex128)
+    c[:n] = r
+    c[L - n + 1:] = np.conj(r[1:][::-1])
+    Aw = _fft.ifft(_fft.fft(c) * _fft.fft(w, n=L))[:n]
+    return float(np.linalg.norm(Aw - b) / np.linalg.norm(b))
 
 
 # --------------------------------------------------------------------------

@@ -123,13 +123,14 @@ def test_every_transform_length(b2, fft_len, monkeypatch):
     assert_map_close(m.data, g["map"])
 
 
-def test_direct_doppler_fallback(b2, monkeypatch):
+def test_direct_doppler_fallback(b2):
     # nDoppler > 2049 falls back to a direct DFT kernel; force it on a small case
-    monkeypatch.setenv("BLAH2HIP_DOPPLER_DIRECT", "1")
     g = load_golden("medium")
     fs, n, dmin, dmax, fmin, fmax, rh = (int(v) for v in g["params"])
     amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, bool(rh))
+    amb.set_doppler_kernel("direct")
     m = amb.process(g["x"], g["y"])
+    assert amb.last_doppler_kernel() == "direct"
     assert_map_close(m.data, g["map"])
     assert abs(m.noisePower - g["metrics"][0]) <= DB_TOL
 

@@ -71,6 +71,28 @@ def test_unsupported_geometries_fail_loudly(b2):
         b2.Ambiguity(5, 100, -10, 10, 1_000_000, 1_000_000, True)
     with pytest.raises(b2.Blah2HipError):
         b2.Ambiguity(-10, 100, 10, -10, 1_000_000, 1_000_000, True)
+    # short pulses: 2049 pulses of 488 samples, nfft = 1000.  Lags beyond nfft - nCorr = 512 alias in the
+    # reference's circular correlation (Ambiguity.cpp:132-146) onto the opposite-sign lags; refused
+    with pytest.raises(b2.Blah2HipError) as e:
+        b2.Ambiguity(-10, 600, -2048, 2048, 2_000_000, 1_000_000, True)
+    assert e.value.code == -3 and "alias" in str(e.value)
+
+
+def test_lags_longer_than_a_pulse_are_zero_like_the_reference(b2):
+    # same geometry with delayMax = 500 <= nfft - nCorr: lags 488..500 exceed the pulse length and are
+    # zero (up to rounding) in the reference (zero padding to nfft) and here
+    # (the reference's values there are fp64 rounding noise ~1e-13 of the peak, so Map::set_metrics' mean
+    # of the dB values is not comparable for such a geometry: the map is what is checked)
+    args = (-10, 500, -2048, 2048, 2_000_000, 1_000_000, True)
+    x, y = O.synth_iq(args[5], seed=11, fs=args[4], targets=((20, 600.0, 0.1),))
+    amb = b2.Ambiguity(*args)
+    assert (amb.get_n_doppler_bins(), amb.get_n_corr(), amb.get_nfft()) == (2049, 488, 1000)
+    m = amb.process(x, y)
+    ref = O.ambiguity_process(O.ambiguity_dims(*args), x, y)
+    peak = np.abs(ref).max()
+    assert np.abs(m.data.astype(np.complex128) - ref).max() / peak <= 1e-5
+    beyond = amb.delay >= 488
+    assert beyond.sum() == 13 and np.abs(ref[:, beyond]).max() / peak < 1e-9 and np.abs(m.data[:, beyond]).max() / peak < 1e-5
 
 
 def test_zero_cells_poison_the_mean_like_the_reference(b2):

@@ -1,0 +1,129 @@
+"""GPU parity for the kernels bench.py actually times.
+
+The benchmark runs the device-resident chain on BATCHES of CPIs; the launch-size
+rule of the engine then selects kernels that a single-CPI call never reaches
+(doppler_tile_kernel<8> at nD = 513, the range kernel's grid-stride path with
+cpi > 0, the multi-wave tile kernel at nD = 1025 / 2049).  Every test here
+asserts WHICH Doppler kernel ran (blah2hip_amb_get_info) and compares every CPI
+of the batch with the fp64 oracle (Ambiguity.cpp:92-172, Map.cpp:187-206) at the
+gates of tests/test_ambiguity_gpu.py:
+    max|dM| / max|M| <= 1e-5, cell-wise <= 1e-4 above the mean level, metrics within 1e-3 dB.
+"""
+import numpy as np
+import pytest
+
+from oracle import blah2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+PEAK_TOL, CELL_TOL, DB_TOL = 1e-5, 1e-4, 1e-3
+
+
+@pytest.fixture(scope="module")
+def b2(built_lib):
+    import blah2_amd
+    assert blah2_amd.device_count() > 0
+    return blah2_amd
+
+
+def assert_cpi(got, met, ref, tag, cell_tol=CELL_TOL):
+    got = got.astype(np.complex128)
+    peak = np.max(np.abs(ref))
+    err = np.abs(got - ref)
+    assert err.max() / peak <= PEAK_TOL, f"{tag}: peak-relative error {err.max() / peak:.3e}"
+    strong = np.abs(ref) > np.mean(np.abs(ref))
+    rel = np.max(err[strong] / np.abs(ref[strong]))
+    assert rel <= cell_tol, f"{tag}: element-wise relative error {rel:.3e}"
+    noise, mx = O.map_metrics(ref)
+    assert abs(met[0] - noise) <= DB_TOL and abs(met[1] - mx) <= DB_TOL, f"{tag}: metrics {met} vs {(noise, mx)}"
+
+
+def run_batch(b2, geom, B, kernel, seeds, fmt="c32", expect=None, cell_tol=CELL_TOL, targets=((37, -63.0, 0.05),)):
+    """B distinct CPIs through blah2hip_amb_process_dev in ONE call; every CPI against the oracle."""
+    import torch
+    dmin, dmax, fmin, fmax, fs, n = geom
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, max_batch=B)
+    if kernel != "auto":
+        amb.set_doppler_kernel(kernel)
+    xs, ys = zip(*(O.synth_iq(n, seed=s, fs=fs, targets=targets) for s in seeds))
+    nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
+    out = torch.zeros((B, nD, nC), dtype=torch.complex64, device="cuda")
+    met = torch.zeros((B, 2), dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    if fmt == "c32":
+        x = torch.from_numpy(np.stack(xs).astype(np.complex64)).cuda()
+        y = torch.from_numpy(np.stack(ys).astype(np.complex64)).cuda()
+        amb.process_dev(b2.FMT_C32, x.data_ptr(), y.data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
+    else:
+        iq = np.stack([np.stack([x_.real, x_.imag, y_.real, y_.imag], axis=-1) for x_, y_ in zip(xs, ys)]).astype(np.int16)
+        d = torch.from_numpy(iq).cuda()
+        amb.process_dev(b2.FMT_I16, d.data_ptr(), 0, B, n, out.data_ptr(), met.data_ptr(), st)
+    torch.cuda.synchronize()
+    ran = amb.last_doppler_kernel()
+    assert ran == (expect or kernel), f"Doppler kernel that ran: {ran}"
+    o, m = out.cpu().numpy(), met.cpu().numpy()
+    d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
+    assert (d.n_doppler_bins, d.n_delay_bins) == (nD, nC)
+    for c in range(B):
+        assert_cpi(o[c], m[c], O.ambiguity_process(d, xs[c], ys[c]), f"cpi {c} of {B} [{ran}]", cell_tol)
+    return amb
+
+
+CFG2 = (-10, 400, -256, 256, 2_000_000, 2_000_000)
+
+
+@pytest.mark.parametrize("B", [3, 8])
+def test_cfg2_batched_takes_the_tile_kernel(b2, B):
+    """BASELINE configs[1] in batches: B*52 half-tiles >= numCU/2 -> doppler_tile_kernel<8> at
+    nD = 513 (all nine row groups, the k = 8 tail row, the row rotation by 257), and the range
+    kernel's grid-stride loop reaches pulses of cpi > 0."""
+    amb = run_batch(b2, CFG2, B, "auto", seeds=range(40, 40 + B), expect="tile8")
+    assert (amb.get_n_doppler_bins(), amb.get_n_delay_bins(), amb.dims.fft_len) == (513, 411, 2048)
+    from blah2_amd import _lib
+    assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_E16
+
+
+def test_cfg2_batched_int16_wire_format(b2):
+    run_batch(b2, CFG2, 3, "auto", seeds=(50, 51, 52), fmt="i16", expect="tile8")
+
+
+@pytest.mark.parametrize("kernel", ["tile8", "tile16", "column", "direct"])
+def test_cfg2_every_doppler_kernel(b2, kernel):
+    """The same two CPIs through each Doppler kernel that covers nD = 513, forced."""
+    run_batch(b2, CFG2, 2, kernel, seeds=(60, 61))
+
+
+# Doppler lengths either side of each tile kernel's row grouping (64 rows per register at one wave
+# per column), ragged delay counts (last tile partly empty: 411 = 51*8+3, 300 = 18*16+12), B = 2.
+@pytest.mark.parametrize("fmax,n,nD", [(32, 130_000, 65), (255, 1_022_000, 511), (256, 1_026_000, 513)])
+@pytest.mark.parametrize("kernel", ["tile8", "tile16"])
+def test_tile_kernels_row_groups_and_ragged_tiles(b2, fmax, n, nD, kernel):
+    geom = (-7, 292, -fmax, fmax, n, n)  # fs = n: 1 s CPI, 1 Hz Doppler resolution, nCorr = 2000
+    amb = run_batch(b2, geom, 2, kernel, seeds=(70 + nD, 71 + nD), targets=((37, -13.0, 0.05),))
+    assert amb.get_n_doppler_bins() == nD and amb.get_n_delay_bins() == 300
+
+
+@pytest.mark.parametrize("fmax,n,nD", [(257, 1_030_000, 515), (512, 2_050_000, 1025)])
+def test_two_wave_tile_kernel(b2, fmax, n, nD):
+    """513 < nD <= 1025 -> doppler_tilem_kernel<8> (two-wave columns, 8 per workgroup)."""
+    geom = (-7, 292, -fmax, fmax, n, n)
+    amb = run_batch(b2, geom, 2, "tilem", seeds=(80 + nD, 81 + nD), targets=((37, -13.0, 0.05),))
+    assert amb.get_n_doppler_bins() == nD
+    from blah2_amd import _lib
+    assert amb.info(_lib.INFO_DOPPLER_FFT_LEN) == 2048
+
+
+@pytest.mark.parametrize("fmax,n,nD", [(513, 2_054_000, 1027), (1024, 4_098_000, 2049)])
+def test_four_wave_tile_kernel(b2, fmax, n, nD):
+    """1025 < nD <= 2049 -> doppler_tilem_kernel<16> (four-wave columns, 4 per workgroup)."""
+    geom = (-7, 292, -fmax, fmax, n, n)
+    amb = run_batch(b2, geom, 2, "tilem", seeds=(90 + nD, 91 + nD), targets=((37, -13.0, 0.05),), cell_tol=2e-4)
+    assert amb.get_n_doppler_bins() == nD
+    from blah2_amd import _lib
+    assert amb.info(_lib.INFO_DOPPLER_FFT_LEN) == 4096
+
+
+def test_auto_rule_small_launch_keeps_the_column_kernel(b2):
+    amb = run_batch(b2, CFG2, 1, "auto", seeds=(99,), expect="column")
+    with pytest.raises(b2.Blah2HipError):  # nD = 513 is outside the multi-wave tile kernel's plan (M = 1024)
+        amb.set_doppler_kernel("tilem")

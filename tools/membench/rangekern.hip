@@ -1,5 +1,5 @@
 // The library's range kernel launched bare (no Doppler/metrics kernels around it, no
-// Python): production variant and the ablated ones, same buffers as rangepat.hip.
+// Python), same buffers as rangepat.hip.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I../../include -I../../blah2_amd/csrc rangekern.hip -o rangekern
 #include "kernels.hpp"
 #include <cstdio>
@@ -48,18 +48,12 @@ int main()
   a.tw = tw; a.out = out; a.cpiStride = 2000000; a.nPulses = nCpi * nD;
   InC32 in{x, y};
   const size_t lds = (size_t)(WgFft<8>::A_ELEMS + WgFft<8>::B_ELEMS) * sizeof(cf);
-  for (int pass = 0; pass < 2; pass++) {
-    const int grid = 1024;
-    run("production  <8,C32,ILV,3,LD,BL>", range_kernel<8, InC32, true, 3, true, true>, a, in, nCpi, grid, lds);
-    run("old loads   <8,C32,ILV,3,LD>", range_kernel<8, InC32, true, 3, true, false>, a, in, nCpi, grid, lds);
-    run("non-ILV     <8,C32,-,3,LD>", range_kernel<8, InC32, false, 3, true, false>, a, in, nCpi, grid, lds);
-    run("loads only  <8,C32,-,0,LD>", range_kernel<8, InC32, false, 0, true, false>, a, in, nCpi, grid, lds);
-    run("loads only, buffer loads <8,C32,-,0,LD,BL>", range_kernel<8, InC32, false, 0, true, true>, a, in, nCpi, grid, lds);
-    run("arith+LDS   <8,C32,-,3,noLD>", range_kernel<8, InC32, false, 3, false, false>, a, in, nCpi, grid, lds);
-    run("empty       <8,C32,-,0,noLD>", range_kernel<8, InC32, false, 0, false, false>, a, in, nCpi, grid, lds);
-  }
-  // the loads-only kernel without its LDS allocation (occupancy no longer LDS-limited)
-  run("loads only, 0 LDS", range_kernel<8, InC32, false, 0, true, false>, a, in, nCpi, 1024, 0);
-  run("loads only, 0 LDS", range_kernel<8, InC32, false, 0, true, false>, a, in, nCpi, 2048, 0);
+  // the shipped kernel at several grid sizes (1024 = LDS-limited residency, 4 workgroups per CU).
+  // The ablated variants this tool used to time (arithmetic / LDS / loads switched off one by one;
+  // results in DESIGN.md section 4) were template parameters of the product kernel in round 1 and
+  // were removed from it; rangepat.hip still times the bare load/store pattern.
+  for (int pass = 0; pass < 2; pass++)
+    for (int grid : {512, 768, 1024, 2048})
+      run("range_kernel<8, InC32>", range_kernel<8, InC32>, a, in, nCpi, grid, lds);
   return 0;
 }
