@@ -22,6 +22,7 @@ CK_CORR, CK_REDUCE, CK_SOLVE, CK_FIR, CK_COUNT = 0, 1, 2, 3, 4
 CLUTTER_KERNEL_NAMES = {CK_CORR: "clutter_corr", CK_REDUCE: "clutter_reduce", CK_SOLVE: "clutter_solve",
                         CK_FIR: "clutter_fir"}
 OPT_DOPPLER_KERNEL, OPT_RANGE_GRID = 1, 2
+CLUTTER_OPT_SOLVE_K = 1
 DOP_AUTO, DOP_TILE8, DOP_TILE16, DOP_TILEM, DOP_COLUMN, DOP_DIRECT = 0, 1, 2, 3, 4, 5
 DOPPLER_KERNEL_NAMES = {DOP_AUTO: "auto", DOP_TILE8: "tile8", DOP_TILE16: "tile16", DOP_TILEM: "tilem",
                         DOP_COLUMN: "column", DOP_DIRECT: "direct"}
@@ -83,6 +84,7 @@ SYMBOLS = {
     "blah2hip_clutter_process_c64": (C.c_int, [_vp, _vp, _vp, _u32, _vp, C.POINTER(C.c_int)]),
     "blah2hip_clutter_process_c32": (C.c_int, [_vp, _vp, _vp, _u32, _vp, C.POINTER(C.c_int)]),
     "blah2hip_clutter_process_dev": (C.c_int, [_vp, _vp, _vp, _u32, C.c_uint64, _vp, _vp, _vp]),
+    "blah2hip_clutter_set_option": (C.c_int, [_vp, C.c_int, C.c_int64]),
     "blah2hip_clutter_get_dims": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "blah2hip_clutter_read_last": (C.c_int, [_vp, _u32, _vp, _vp, C.POINTER(C.c_int)]),
     "blah2hip_clutter_set_timing": (C.c_int, [_vp, C.c_int]),

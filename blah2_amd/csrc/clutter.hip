@@ -13,9 +13,10 @@
 //   * r and b are nBins lags of a circular correlation -> the same segmented
 //     on-chip FFT correlation as the range kernel (clutter_corr_kernel),
 //     partial sums per workgroup, reduced in fp64;
-//   * A is Hermitian Toeplitz -> Levinson recursion in fp64, O(nBins^2), one
-//     workgroup (clutter_solve_kernel).  The reference's chol() fails exactly
-//     when A is not positive definite; Levinson detects the same condition
+//   * A is Hermitian Toeplitz -> Levinson recursion in fp64, O(nBins^2), with Schur
+//     residual recursions in place of its inner products (clutter_solve_kernel: one
+//     workgroup per CPI, one barrier per order).  The reference's chol() fails exactly
+//     when A is not positive definite; the recursion detects the same condition
 //     (a prediction-error factor 1-|e|^2 <= 0 or r[0] <= 0) -> ok = 0;
 //   * the FIR is an overlap-save convolution on the on-chip FFT
 //     (clutter_fir_kernel), one pass over x and y.
@@ -148,7 +149,7 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_ker
   finish(accB, 1);
 }
 
-// ---- reduction of the partials (fp64), then the Levinson solve ----------------
+// ---- reduction of the partials (fp64), then the Toeplitz solve -----------------
 struct SolveArgs {
   const cf *partial; // [nCpi][2][nJobs][nBins]
   dcx *rb;           // [nCpi][2][nBins]: r then b, fp64
@@ -177,115 +178,111 @@ __global__ __launch_bounds__(256) void clutter_reduce_kernel(SolveArgs a)
   a.rb[((size_t)cpi * 2 + mode) * a.nBins + k] = {(sx[0] + sx[1]) + (sx[2] + sx[3]), (sy[0] + sy[1]) + (sy[2] + sy[3])};
 }
 
-__device__ __forceinline__ dcx dmul(dcx a, dcx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ dcx dconj(dcx a) { return {a.x, -a.y}; }
-
-// Sum of a double over the 64 lanes of a wave, result uniform.  Row-wise
-// inclusive scan with DPP row_shr (full-rate VALU, no LDS crossbar), then the
-// four row totals are combined through v_readlane.
-template <int CTRL> __device__ __forceinline__ double dpp_shr_add(double v)
+// Hermitian Toeplitz solve A w = b, A[i][j] = r[i-j], by the Levinson recursion with its inner
+// products replaced by Schur-type residual recursions, so that one order is a purely ELEMENT-WISE
+// update of length n with two scalars broadcast -- no reduction, one workgroup barrier per order.
+//
+// Levinson (the round-1 kernel): forward vector f (T_m f = e_1), backward vector conj(rev f), solution
+// x; per order m it needs ef = sum_i r[m-i] f[i] and ex = sum_i r[m-i] x[i]: two dot products, i.e. a
+// wave reduction, an LDS exchange of partials and a second barrier per order (3.1 ms for 2047 orders).
+// Apply T to the (zero-extended) vectors instead and carry the results along:
+//     a_m[j] = (T f_m)[j],  c_m[j] = (T conj(rev f_m))[j],  g_m[j] = b[j] - (T x_m)[j]        (j >= m)
+// then ef = a_m[m] and b[m] - ex = g_m[m] are simply the LEADING ELEMENTS, and with D = 1 - |ef|^2
+//     a_{m+1}[j] = (a_m[j]   - ef       c_m[j-1]) / D        f_{m+1}[i]      = (f_m[i]         - ef       conj f_m[m-i]) / D
+//     c_{m+1}[j] = (c_m[j-1] - conj(ef) a_m[j]  ) / D        conj f_{m+1}[m-i] = (conj f_m[m-i] - conj(ef) f_m[i]      ) / D
+//     g_{m+1}[j] = g_m[j] - d c_{m+1}[j]                     x_{m+1}[i]      = x_m[i] + d conj f_{m+1}[m-i]
+// The two columns are THE SAME update (u, v) -> ((u - ef v)/D, (v - conj(ef) u)/D), acc += d v' on
+// different operands: index j > m carries (u, v, acc) = (a[j], c[j-1], -g[j]), index j <= m carries
+// (f[j], conj f[m-j], x[j]).  An index changes role once, at m = j, where a[m] and g[m] are consumed as
+// the scalars and f[m] = x[m] = 0 start.  Thread t owns the indices t + NT k (u and acc in registers);
+// v comes from a neighbour (c[j-1]) or the mirror index (f[m-j]) through an LDS array holding c[j] for
+// j > m and f[j] for j <= m, double-buffered so that one barrier per order suffices.
+// The matrix is positive definite iff r[0] > 0 and every D > 0 -- the condition under which the
+// reference's chol() succeeds (WienerHopf.cpp:111) -- else ok = 0.  fp64 throughout.
+__device__ __forceinline__ dcx dsub_mul(dcx u, dcx e, dcx v) // u - e*v
 {
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-  return v + __hiloint2double(hi2, lo2);
+  return {u.x - (e.x * v.x - e.y * v.y), u.y - (e.x * v.y + e.y * v.x)};
 }
-__device__ __forceinline__ double wave_sum(double v)
+__device__ __forceinline__ dcx dadd_mul(dcx u, dcx e, dcx v) // u + e*v
 {
-  v = dpp_shr_add<0x111>(v); // row_shr:1
-  v = dpp_shr_add<0x112>(v); // row_shr:2
-  v = dpp_shr_add<0x114>(v); // row_shr:4
-  v = dpp_shr_add<0x118>(v); // row_shr:8  -> lanes 15,31,47,63 hold their row's total
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  double tot = 0.0;
-#pragma unroll
-  for (int l = 15; l < 64; l += 16)
-    tot += __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
-  return tot;
+  return {u.x + (e.x * v.x - e.y * v.y), u.y + (e.x * v.y + e.y * v.x)};
 }
 
-// Levinson recursion for the Hermitian Toeplitz system A w = b, A[i][j] = r[i-j]:
-//   f = forward vector (T_m f = e_1), x = running solution; per order m
-//     ef = sum_i r[m-i] f[i],  ex = sum_i r[m-i] x[i]
-//     f <- (f - ef * conj(rev f)) / (1 - |ef|^2)      (f[m] = 0 before)
-//     x <- x + (b[m] - ex) * conj(rev f)
-// The matrix is positive definite iff r[0] > 0 and every 1 - |ef|^2 > 0 -- the
-// condition under which the reference's chol() succeeds (WienerHopf.cpp:111).
-// One workgroup of 4 waves per CPI.  The recursion is a chain of nBins dependent
-// steps, so what matters is the latency of a step: a single wave (the first version)
-// needs no barriers but streams ~6m 16-byte LDS accesses per step through one wave's
-// LDS issue rate (505 us for nBins = 410, 7.7 ms for 2047); four waves split that
-// traffic for the price of two workgroup barriers per step.  All four vectors live in
-// LDS.  (A fully unrolled variant with clamped unconditional LDS reads was measured
-// slower: it always touches every element, while the average order is n/2.)
-template <int SOLVE_WAVES>
-__global__ __launch_bounds__(64 * SOLVE_WAVES) void clutter_solve_kernel(SolveArgs a)
+// component-wise select (a struct-valued ?: makes hipcc index a scratch copy of both operands)
+__device__ __forceinline__ dcx dsel(bool c, dcx a, dcx b) { return {c ? a.x : b.x, c ? a.y : b.y}; }
+
+template <int K>
+__global__ __launch_bounds__(1024) void clutter_solve_kernel(SolveArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double red[2][SOLVE_WAVES][4];
   const int n = a.nBins;
-  dcx *f = reinterpret_cast<dcx *>(smem);
-  dcx *xv = f + n;
-  dcx *r = xv + n;
-  dcx *b = r + n;
+  dcx *cur = reinterpret_cast<dcx *>(smem);
+  dcx *nxt = cur + n;
+  dcx *scal = nxt + n; // [parity][ef, d]
   const int cpi = blockIdx.x;
-  const int t = threadIdx.x, wv = t >> 6;
-  constexpr int NT = 64 * SOLVE_WAVES;
+  const int t = threadIdx.x, NT = blockDim.x;
   const dcx *rg = a.rb + (size_t)cpi * 2 * n;
-  for (int k = t; k < n; k += NT) {
-    r[k] = rg[k];
-    b[k] = rg[n + k];
-    f[k] = {0.0, 0.0};
-    xv[k] = {0.0, 0.0};
-  }
-  __syncthreads();
-  const double r0 = r[0].x;
+  const double r0 = rg[0].x;
   bool ok = (r0 > 0.0) && isfinite(r0);
-  if (ok && t == 0) {
-    f[0] = {1.0 / r0, 0.0};
-    xv[0] = {b[0].x / r0, b[0].y / r0};
+  const double inv0 = ok ? 1.0 / r0 : 0.0;
+  const dcx x0 = {rg[n].x * inv0, rg[n].y * inv0}; // x_1[0] = b[0] / r[0]
+  dcx U[K], Acc[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int j = t + NT * k;
+    U[k] = {0.0, 0.0};
+    Acc[k] = {0.0, 0.0};
+    if (j < n) {
+      const dcx rj = rg[j], bj = rg[n + j];
+      if (j == 0) {
+        U[k] = {inv0, 0.0}; // f_1[0]
+        Acc[k] = x0;
+      } else {
+        U[k] = {rj.x * inv0, rj.y * inv0};                  // a_1[j] = r[j] / r[0]  (= c_1[j])
+        const dcx g = dsub_mul(bj, rj, x0);                  // g_1[j] = b[j] - r[j] x_1[0]
+        Acc[k] = {-g.x, -g.y};
+      }
+      cur[j] = U[k];
+      if (j == 1) { scal[2] = U[k]; scal[3] = {-Acc[k].x, -Acc[k].y}; } // ef, d of order 1 (parity 1)
+    }
   }
   __syncthreads();
-  // Two barriers per order: (A) partial dot products -> wave sums -> LDS, (B) every pair
-  // (i, m-i) is updated by one thread, which holds the old f[i], f[m-i] and therefore also
-  // the NEW f[m-i], f[i] that the solution update x[i] += d*conj(f_new[m-i]) needs.
   for (int m = 1; m < n && ok; m++) {
-    double efx = 0.0, efy = 0.0, exx = 0.0, exy = 0.0;
-    for (int i = t; i < m; i += NT) {
-      const dcx rr = r[m - i];
-      const dcx p1 = dmul(rr, f[i]), p2 = dmul(rr, xv[i]);
-      efx += p1.x; efy += p1.y;
-      exx += p2.x; exy += p2.y;
-    }
-    efx = wave_sum(efx); efy = wave_sum(efy); exx = wave_sum(exx); exy = wave_sum(exy);
-    double (*rd)[4] = red[m & 1];
-    if ((t & 63) == 0) { rd[wv][0] = efx; rd[wv][1] = efy; rd[wv][2] = exx; rd[wv][3] = exy; }
-    __syncthreads();
-    dcx ef = {0.0, 0.0}, ex = {0.0, 0.0};
+    const dcx ef = scal[(m & 1) * 2], d = scal[(m & 1) * 2 + 1];
+    const double D = 1.0 - (ef.x * ef.x + ef.y * ef.y);
+    if (!(D > 0.0) || !isfinite(D)) { ok = false; break; } // uniform: every thread reads the same scalars
+    const double inv = 1.0 / D;
+    const dcx efc = {ef.x, -ef.y};
 #pragma unroll
-    for (int w = 0; w < SOLVE_WAVES; w++) { ef.x += rd[w][0]; ef.y += rd[w][1]; ex.x += rd[w][2]; ex.y += rd[w][3]; }
-    const double denom = 1.0 - (ef.x * ef.x + ef.y * ef.y);
-    if (!(denom > 0.0) || !isfinite(denom)) { ok = false; break; } // uniform: every thread sees the same sums
-    const double inv = 1.0 / denom;
-    const dcx d = {b[m].x - ex.x, b[m].y - ex.y};
-    for (int i = t; 2 * i <= m; i += NT) {
-      const int j = m - i;
-      const dcx fi = f[i], fj = (j < m) ? f[j] : dcx{0.0, 0.0}; // f[m] = 0 before the update
-      const dcx ti = dmul(ef, dconj(fj)), tj = dmul(ef, dconj(fi));
-      const dcx ni = {(fi.x - ti.x) * inv, (fi.y - ti.y) * inv};
-      const dcx nj = {(fj.x - tj.x) * inv, (fj.y - tj.y) * inv};
-      const dcx pi = dmul(d, dconj(nj)), pj = dmul(d, dconj(ni));
-      const dcx xi = xv[i], xj = xv[j];
-      f[i] = ni;
-      xv[i] = {xi.x + pi.x, xi.y + pi.y};
-      if (j != i) {
-        f[j] = nj;
-        xv[j] = {xj.x + pj.x, xj.y + pj.y};
+    for (int k = 0; k < K; k++) {
+      const int j = t + NT * k;
+      if (j < n) {
+        const bool hi = j > m;
+        const dcx s = cur[hi ? j - 1 : m - j];
+        const dcx zero = {0.0, 0.0};
+        const dcx v = dsel(hi, s, dsel(j == 0, zero, dcx{s.x, -s.y})); // c[j-1], or conj f[m-j] (f[m] = 0)
+        const dcx u = dsel(j == m, zero, U[k]);
+        const dcx acc = dsel(j == m, zero, Acc[k]);
+        dcx up = dsub_mul(u, ef, v), vp = dsub_mul(v, efc, u);
+        up = {up.x * inv, up.y * inv};
+        vp = {vp.x * inv, vp.y * inv};
+        U[k] = up;
+        Acc[k] = dadd_mul(acc, d, vp);
+        nxt[j] = dsel(hi, vp, up);
+        if (j == m + 1) {
+          scal[((m + 1) & 1) * 2] = up;
+          scal[((m + 1) & 1) * 2 + 1] = {-Acc[k].x, -Acc[k].y};
+        }
       }
     }
     __syncthreads();
+    dcx *tmp = cur; cur = nxt; nxt = tmp;
   }
-  for (int k = t; k < n; k += NT) a.w[(size_t)cpi * n + k] = ok ? cmake((float)xv[k].x, (float)xv[k].y) : cmake(0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int j = t + NT * k;
+    if (j < n) a.w[(size_t)cpi * n + j] = ok ? cmake((float)Acc[k].x, (float)Acc[k].y) : cmake(0.f, 0.f);
+  }
   if (t == 0) a.ok[cpi] = ok ? 1 : 0;
 }
 
@@ -413,6 +410,7 @@ struct blah2hip_clutter_s {
   int32_t *d_ok = nullptr;
   cf *d_stage = nullptr; // host entry points: x, y, y_out planes
   size_t stageElems = 0;
+  int solveK = 0;            // indices per thread of the Toeplitz solve (0 = by size)
   int32_t *lastOk = nullptr; // where the last process call wrote its flags
   KernelTimer<BLAH2HIP_CK_COUNT> timer;
 };
@@ -427,9 +425,9 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   // once per (device, kernel), see capi.hip
   CHIP(blah2hip_ensure_lds_((const void *)clutter_corr_kernel<R3>, (int)lds));
   CHIP(blah2hip_ensure_lds_((const void *)clutter_fir_kernel<R3>, (int)lds));
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<1>, 160 * 1024 - 2048));
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<2>, 160 * 1024 - 2048));
   CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<4>, 160 * 1024 - 2048));
-  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<8>, 160 * 1024 - 2048));
-  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<16>, 160 * 1024 - 2048));
   XsMap xs;
   xs.N = h->N;
   xs.thresh = h->delayMin > 0 ? (uint32_t)h->delayMin : 0u;
@@ -457,13 +455,13 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   hipLaunchKernelGGL(clutter_reduce_kernel, dim3((h->nBins + 255) / 256, 2, nCpi), dim3(256), 0, st, sa);
   CHIP(h->timer.toc(BLAH2HIP_CK_REDUCE, st));
   CHIP(h->timer.tic(BLAH2HIP_CK_SOLVE, st));
-  const size_t sl = (size_t)4 * h->nBins * sizeof(dcx);
-  // waves per CPI: more waves split the per-order LDS traffic, fewer keep the barriers cheap
-  static const int swEnv = [] { const char *e = std::getenv("BLAH2HIP_SOLVE_WAVES"); return e ? std::atoi(e) : 0; }();
-  const int sw = swEnv ? swEnv : (h->nBins > 1024 ? 8 : 4); // measured: 410 orders 408 / 481 / 743 us, 2047 orders 3128 / 3023 / 4507 us with 4 / 8 / 16 waves
-  if (sw == 16) hipLaunchKernelGGL(clutter_solve_kernel<16>, dim3(nCpi), dim3(1024), sl, st, sa);
-  else if (sw == 8) hipLaunchKernelGGL(clutter_solve_kernel<8>, dim3(nCpi), dim3(512), sl, st, sa);
-  else hipLaunchKernelGGL(clutter_solve_kernel<4>, dim3(nCpi), dim3(256), sl, st, sa);
+  // indices per thread: 2 up to 2048 taps (a 1024-thread workgroup), 4 above; at least one wave
+  const size_t sl = ((size_t)2 * h->nBins + 4) * sizeof(dcx);
+  const int kper = h->solveK ? h->solveK : (h->nBins > 2048 ? 4 : 2);
+  const int nt = std::min(1024, 64 * ((h->nBins + 64 * kper - 1) / (64 * kper)));
+  if (kper == 1) hipLaunchKernelGGL(clutter_solve_kernel<1>, dim3(nCpi), dim3(nt), sl, st, sa);
+  else if (kper == 2) hipLaunchKernelGGL(clutter_solve_kernel<2>, dim3(nCpi), dim3(nt), sl, st, sa);
+  else hipLaunchKernelGGL(clutter_solve_kernel<4>, dim3(nCpi), dim3(nt), sl, st, sa);
   CHIP(hipGetLastError());
   CHIP(h->timer.toc(BLAH2HIP_CK_SOLVE, st));
 
@@ -515,8 +513,8 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
     if (cost < best) { best = cost; bestR3 = r3; }
   }
   if (!bestR3) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip transform lengths (<= 4096)");
-  // the solve keeps four fp64 vectors of nBins in LDS
-  if ((size_t)4 * nBins * sizeof(dcx) > 160 * 1024 - 2048)
+  // the solve keeps two fp64 vectors of nBins in LDS and 4 indices per thread at most
+  if (((size_t)2 * nBins + 4) * sizeof(dcx) > 160 * 1024 - 2048 || nBins > 4096)
     CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip Toeplitz solve");
   auto *h = new blah2hip_clutter_s;
   // everything that can fail runs inside `build`; a partially built handle is torn down by destroy()
@@ -593,6 +591,19 @@ int blah2hip_clutter_read_last(blah2hip_clutter_t h, uint32_t cpi, float *w, dou
     *ok = v;
   }
   return BLAH2HIP_OK;
+}
+
+int blah2hip_clutter_set_option(blah2hip_clutter_t h, int option, int64_t value)
+{
+  if (!h) CFAIL(BLAH2HIP_ERR_INVALID, "NULL handle");
+  switch (option) {
+  case BLAH2HIP_CLUTTER_OPT_SOLVE_K:
+    if (value != 0 && value != 1 && value != 2 && value != 4) CFAIL(BLAH2HIP_ERR_INVALID, "indices per thread: 0 (auto), 1, 2 or 4");
+    if (value && (int64_t)h->nBins > 1024 * value) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins needs more indices per thread");
+    h->solveK = (int)value;
+    return BLAH2HIP_OK;
+  default: CFAIL(BLAH2HIP_ERR_INVALID, "unknown option");
+  }
 }
 
 int blah2hip_clutter_set_timing(blah2hip_clutter_t h, int enable)

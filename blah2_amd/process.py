@@ -368,6 +368,9 @@ class WienerHopf:
         """Enqueue on ``stream``: device complex64 planes, output may alias d_y."""
         check(self._L.blah2hip_clutter_process_dev(self._h, d_x, d_y, n_cpi, cpi_stride, d_y_out, d_ok, stream))
 
+    def set_solve_indices_per_thread(self, k):
+        check(self._L.blah2hip_clutter_set_option(self._h, _lib.CLUTTER_OPT_SOLVE_K, int(k)))
+
     def read_last(self, cpi=0):
         """(ok, w, r, b) of CPI ``cpi`` of the last call: the nBins filter taps (complex64) and the fp64
         correlations r, b of the normal equations A w = b, A[i][j] = r[i-j] (diagnostics)."""

@@ -253,6 +253,10 @@ int blah2hip_clutter_process_c32(blah2hip_clutter_t h, const float *x, const flo
 int blah2hip_clutter_process_dev(blah2hip_clutter_t h, const void *d_x, const void *d_y,
                                  uint32_t n_cpi, uint64_t cpi_stride, void *d_y_out, int32_t *d_ok,
                                  void *stream);
+/* Execution plan of the filter.  SOLVE_K: indices of the Toeplitz recursion per thread (0 = by
+ * size: 2 up to 2048 taps, 4 above; the workgroup has ceil(nBins / K) threads rounded up to a wave). */
+#define BLAH2HIP_CLUTTER_OPT_SOLVE_K 1
+int blah2hip_clutter_set_option(blah2hip_clutter_t h, int option, int64_t value);
 /* Derived sizes: nBins = delayMax - delayMin taps (WienerHopf.cpp:12), on-chip transform
  * length and samples per overlap-save block. */
 int blah2hip_clutter_get_dims(blah2hip_clutter_t h, uint32_t *n_bins, uint32_t *fft_len, uint32_t *seg_len);

@@ -25,6 +25,14 @@ template <class V> __device__ void rd(const V *in, float *out)
 }
 __global__ void cal_read8(const f2 *in, float *out) { rd(in, out); }
 __global__ void cal_read16(const f4 *in, float *out) { rd(in, out); }
+// the first 64 bytes of every 128-byte line, 8 bytes per lane (the 8-column Doppler tile read)
+__global__ void cal_read_half(const f2 *in, float *out)
+{
+  const size_t n = BYTES / sizeof(f2) / 2; // elements read
+  float acc = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += in[(i >> 3) * 16 + (i & 7)].x;
+  if (acc == 12345.678f) out[0] = acc;
+}
 __global__ void cal_write8(f2 *o)
 {
   const size_t n = BYTES / sizeof(f2);
@@ -52,6 +60,7 @@ int main()
   for (int rep = 0; rep < 3; rep++) {
     cal_read8<<<grid, T>>>((const f2 *)buf, out);
     cal_read16<<<grid, T>>>((const f4 *)buf, out);
+    cal_read_half<<<grid, T>>>((const f2 *)buf, out);
     cal_write8<<<grid, T>>>((f2 *)buf);
     cal_write_seg<32><<<grid, T>>>((char *)buf);
     cal_write_seg<64><<<grid, T>>>((char *)buf);
@@ -59,7 +68,7 @@ int main()
   }
   hipDeviceSynchronize();
   const double rows = (double)(BYTES / 3288);
-  std::printf("known bytes per dispatch: read8 %.0f read16 %.0f write8 %.0f seg32 %.0f seg64 %.0f seg128 %.0f (%s)\n", (double)BYTES,
+  std::printf("known bytes per dispatch: read_half 536870912 (of 1 GiB of lines touched) read8 %.0f read16 %.0f write8 %.0f seg32 %.0f seg64 %.0f seg128 %.0f (%s)\n", (double)BYTES,
               (double)BYTES, (double)BYTES, 32 * rows, 64 * rows, 128 * rows, hipGetErrorString(hipGetLastError()));
   return 0;
 }
