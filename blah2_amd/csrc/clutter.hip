@@ -180,23 +180,25 @@ __global__ __launch_bounds__(256) void clutter_reduce_kernel(SolveArgs a)
 
 // Hermitian Toeplitz solve A w = b, A[i][j] = r[i-j], by the Levinson recursion with its inner
 // products replaced by Schur-type residual recursions, so that one order is a purely ELEMENT-WISE
-// update of length n with two scalars broadcast -- no reduction, one workgroup barrier per order.
+// update of length n with a few scalars broadcast -- no reduction, one workgroup barrier per order.
 //
 // Levinson (the round-1 kernel): forward vector f (T_m f = e_1), backward vector conj(rev f), solution
 // x; per order m it needs ef = sum_i r[m-i] f[i] and ex = sum_i r[m-i] x[i]: two dot products, i.e. a
 // wave reduction, an LDS exchange of partials and a second barrier per order (3.1 ms for 2047 orders).
 // Apply T to the (zero-extended) vectors instead and carry the results along:
 //     a_m[j] = (T f_m)[j],  c_m[j] = (T conj(rev f_m))[j],  g_m[j] = b[j] - (T x_m)[j]        (j >= m)
-// then ef = a_m[m] and b[m] - ex = g_m[m] are simply the LEADING ELEMENTS, and with D = 1 - |ef|^2
-//     a_{m+1}[j] = (a_m[j]   - ef       c_m[j-1]) / D        f_{m+1}[i]      = (f_m[i]         - ef       conj f_m[m-i]) / D
+// then ef = a_m[m] and d = b[m] - ex = g_m[m] are simply the LEADING ELEMENTS, and with D = 1 - |ef|^2
+//     a_{m+1}[j] = (a_m[j]   - ef       c_m[j-1]) / D        f_{m+1}[i]        = (f_m[i]         - ef       conj f_m[m-i]) / D
 //     c_{m+1}[j] = (c_m[j-1] - conj(ef) a_m[j]  ) / D        conj f_{m+1}[m-i] = (conj f_m[m-i] - conj(ef) f_m[i]      ) / D
-//     g_{m+1}[j] = g_m[j] - d c_{m+1}[j]                     x_{m+1}[i]      = x_m[i] + d conj f_{m+1}[m-i]
-// The two columns are THE SAME update (u, v) -> ((u - ef v)/D, (v - conj(ef) u)/D), acc += d v' on
-// different operands: index j > m carries (u, v, acc) = (a[j], c[j-1], -g[j]), index j <= m carries
-// (f[j], conj f[m-j], x[j]).  An index changes role once, at m = j, where a[m] and g[m] are consumed as
-// the scalars and f[m] = x[m] = 0 start.  Thread t owns the indices t + NT k (u and acc in registers);
-// v comes from a neighbour (c[j-1]) or the mirror index (f[m-j]) through an LDS array holding c[j] for
-// j > m and f[j] for j <= m, double-buffered so that one barrier per order suffices.
+//     g_{m+1}[j] = g_m[j] - d c_{m+1}[j]                     x_{m+1}[i]        = x_m[i] + d conj f_{m+1}[m-i]
+// The left column is carried UNNORMALISED, A = s a, C = s c with s_{m+1} = s_m D (the prediction-error
+// power relative to r[0]), which removes its divisions: A' = A - ef C[j-1], C' = C[j-1] - conj(ef) A,
+// ef = A_m[m] / s_m and g' = g - (d / s_{m+1}) C'.  One reciprocal per order (1/D; 1/s follows by a
+// product), computed by the one thread that owns index m+1 while the others run to the barrier.
+// Index j > m carries (A[j], -g[j]) in registers and C[j] in LDS; index j <= m carries (f[j], x[j]) in
+// registers and f[j] in LDS (the mirror index m-j is another thread's).  An index changes role once, at
+// m = j, where A[m] and g[m] have been consumed as the scalars and f[m] = x[m] = 0 start.  Thread t
+// owns the indices t + NT k.  The LDS array is double-buffered: one barrier per order.
 // The matrix is positive definite iff r[0] > 0 and every D > 0 -- the condition under which the
 // reference's chol() succeeds (WienerHopf.cpp:111) -- else ok = 0.  fp64 throughout.
 __device__ __forceinline__ dcx dsub_mul(dcx u, dcx e, dcx v) // u - e*v
@@ -207,18 +209,49 @@ __device__ __forceinline__ dcx dadd_mul(dcx u, dcx e, dcx v) // u + e*v
 {
   return {u.x + (e.x * v.x - e.y * v.y), u.y + (e.x * v.y + e.y * v.x)};
 }
+// 1/d for d in (0, 1]: hardware estimate + two Newton steps (5 dependent instructions instead of the
+// ~10 of the IEEE-exact division sequence; this reciprocal sits on the critical path of every order)
+__device__ __forceinline__ double fast_rcp(double d)
+{
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
 
-// component-wise select (a struct-valued ?: makes hipcc index a scratch copy of both operands)
-__device__ __forceinline__ dcx dsel(bool c, dcx a, dcx b) { return {c ? a.x : b.x, c ? a.y : b.y}; }
+// scalars of one order, published by the owner of index m through LDS
+struct SolveScal {
+  dcx ef;     // reflection coefficient a_m[m]
+  dcx d;      // g_m[m]
+  dcx dt;     // d / s_{m+1}
+  double D;   // 1 - |ef|^2
+  double inv; // 1 / D
+  double rsn; // 1 / s_{m+1}
+  double pad;
+};
+__device__ __forceinline__ SolveScal solve_scalars(dcx Am, dcx gm, double rs) // rs = 1 / s_m
+{
+  SolveScal q;
+  q.ef = {Am.x * rs, Am.y * rs};
+  q.D = 1.0 - (q.ef.x * q.ef.x + q.ef.y * q.ef.y);
+  q.inv = fast_rcp(q.D > 0.0 ? q.D : 1.0); // D <= 0 ends the recursion (ok = 0): any finite value will do
+  q.rsn = rs * q.inv;
+  q.d = gm;
+  q.dt = {gm.x * q.rsn, gm.y * q.rsn};
+  q.pad = 0.0;
+  return q;
+}
 
 template <int K>
 __global__ __launch_bounds__(1024) void clutter_solve_kernel(SolveArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n = a.nBins;
+  // two buffers of n + 1 entries (entry n stays zero: "f[m]" as seen by index 0), then the scalars
   dcx *cur = reinterpret_cast<dcx *>(smem);
-  dcx *nxt = cur + n;
-  dcx *scal = nxt + n; // [parity][ef, d]
+  dcx *nxt = cur + (n + 1);
+  SolveScal *scal = reinterpret_cast<SolveScal *>(nxt + (n + 1)); // [parity]
   const int cpi = blockIdx.x;
   const int t = threadIdx.x, NT = blockDim.x;
   const dcx *rg = a.rb + (size_t)cpi * 2 * n;
@@ -238,40 +271,50 @@ __global__ __launch_bounds__(1024) void clutter_solve_kernel(SolveArgs a)
         U[k] = {inv0, 0.0}; // f_1[0]
         Acc[k] = x0;
       } else {
-        U[k] = {rj.x * inv0, rj.y * inv0};                  // a_1[j] = r[j] / r[0]  (= c_1[j])
-        const dcx g = dsub_mul(bj, rj, x0);                  // g_1[j] = b[j] - r[j] x_1[0]
+        U[k] = {rj.x * inv0, rj.y * inv0};  // A_1[j] = a_1[j] = r[j] / r[0]  (= C_1[j], s_1 = 1)
+        const dcx g = dsub_mul(bj, rj, x0); // g_1[j] = b[j] - r[j] x_1[0]
         Acc[k] = {-g.x, -g.y};
       }
       cur[j] = U[k];
-      if (j == 1) { scal[2] = U[k]; scal[3] = {-Acc[k].x, -Acc[k].y}; } // ef, d of order 1 (parity 1)
+      if (j == 1) {
+        scal[1] = solve_scalars(U[k], {-Acc[k].x, -Acc[k].y}, 1.0);
+        U[k] = {0.0, 0.0};   // becomes f[1] = 0, x[1] = 0 at order 1
+        Acc[k] = {0.0, 0.0};
+      }
     }
   }
+  if (t == 0) { cur[n] = {0.0, 0.0}; nxt[n] = {0.0, 0.0}; }
   __syncthreads();
   for (int m = 1; m < n && ok; m++) {
-    const dcx ef = scal[(m & 1) * 2], d = scal[(m & 1) * 2 + 1];
-    const double D = 1.0 - (ef.x * ef.x + ef.y * ef.y);
-    if (!(D > 0.0) || !isfinite(D)) { ok = false; break; } // uniform: every thread reads the same scalars
-    const double inv = 1.0 / D;
-    const dcx efc = {ef.x, -ef.y};
+    const SolveScal q = scal[m & 1];
+    if (!(q.D > 0.0) || !isfinite(q.D)) { ok = false; break; } // uniform: every thread reads the same scalars
+    const dcx efc = {q.ef.x, -q.ef.y};
 #pragma unroll
     for (int k = 0; k < K; k++) {
       const int j = t + NT * k;
       if (j < n) {
-        const bool hi = j > m;
-        const dcx s = cur[hi ? j - 1 : m - j];
-        const dcx zero = {0.0, 0.0};
-        const dcx v = dsel(hi, s, dsel(j == 0, zero, dcx{s.x, -s.y})); // c[j-1], or conj f[m-j] (f[m] = 0)
-        const dcx u = dsel(j == m, zero, U[k]);
-        const dcx acc = dsel(j == m, zero, Acc[k]);
-        dcx up = dsub_mul(u, ef, v), vp = dsub_mul(v, efc, u);
-        up = {up.x * inv, up.y * inv};
-        vp = {vp.x * inv, vp.y * inv};
-        U[k] = up;
-        Acc[k] = dadd_mul(acc, d, vp);
-        nxt[j] = dsel(hi, vp, up);
-        if (j == m + 1) {
-          scal[((m + 1) & 1) * 2] = up;
-          scal[((m + 1) & 1) * 2 + 1] = {-Acc[k].x, -Acc[k].y};
+        if (j > m) {
+          const dcx c1 = cur[j - 1];
+          const dcx An = dsub_mul(U[k], q.ef, c1);
+          const dcx Cn = dsub_mul(c1, efc, U[k]);
+          const dcx Gn = dadd_mul(Acc[k], q.dt, Cn);
+          nxt[j] = Cn;
+          U[k] = An;
+          Acc[k] = Gn;
+          if (j == m + 1) { // the next order's scalars; this index turns into f[m+1] = 0, x[m+1] = 0
+            scal[(m + 1) & 1] = solve_scalars(An, {-Gn.x, -Gn.y}, q.rsn);
+            U[k] = {0.0, 0.0};
+            Acc[k] = {0.0, 0.0};
+          }
+        } else {
+          const dcx s = cur[j == 0 ? n : m - j]; // f[m - j]; f[m] = 0
+          const dcx v = {s.x, -s.y};
+          dcx up = dsub_mul(U[k], q.ef, v), vp = dsub_mul(v, efc, U[k]);
+          up = {up.x * q.inv, up.y * q.inv};
+          vp = {vp.x * q.inv, vp.y * q.inv};
+          nxt[j] = up;
+          U[k] = up;
+          Acc[k] = dadd_mul(Acc[k], q.d, vp);
         }
       }
     }
@@ -455,9 +498,10 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   hipLaunchKernelGGL(clutter_reduce_kernel, dim3((h->nBins + 255) / 256, 2, nCpi), dim3(256), 0, st, sa);
   CHIP(h->timer.toc(BLAH2HIP_CK_REDUCE, st));
   CHIP(h->timer.tic(BLAH2HIP_CK_SOLVE, st));
-  // indices per thread: 2 up to 2048 taps (a 1024-thread workgroup), 4 above; at least one wave
-  const size_t sl = ((size_t)2 * h->nBins + 4) * sizeof(dcx);
-  const int kper = h->solveK ? h->solveK : (h->nBins > 2048 ? 4 : 2);
+  // one index per thread up to 1024 taps (measured: more, smaller threads win while the recursion is
+  // latency-bound), 2 up to 2048, 4 above
+  const size_t sl = ((size_t)2 * (h->nBins + 1)) * sizeof(dcx) + 2 * sizeof(SolveScal);
+  const int kper = h->solveK ? h->solveK : (h->nBins > 2048 ? 4 : (h->nBins > 1024 ? 2 : 1));
   const int nt = std::min(1024, 64 * ((h->nBins + 64 * kper - 1) / (64 * kper)));
   if (kper == 1) hipLaunchKernelGGL(clutter_solve_kernel<1>, dim3(nCpi), dim3(nt), sl, st, sa);
   else if (kper == 2) hipLaunchKernelGGL(clutter_solve_kernel<2>, dim3(nCpi), dim3(nt), sl, st, sa);
@@ -514,7 +558,7 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
   }
   if (!bestR3) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip transform lengths (<= 4096)");
   // the solve keeps two fp64 vectors of nBins in LDS and 4 indices per thread at most
-  if (((size_t)2 * nBins + 4) * sizeof(dcx) > 160 * 1024 - 2048 || nBins > 4096)
+  if (((size_t)2 * nBins + 16) * sizeof(dcx) > 160 * 1024 - 2048 || nBins > 4096)
     CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip Toeplitz solve");
   auto *h = new blah2hip_clutter_s;
   // everything that can fail runs inside `build`; a partially built handle is torn down by destroy()

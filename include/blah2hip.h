@@ -254,7 +254,7 @@ int blah2hip_clutter_process_dev(blah2hip_clutter_t h, const void *d_x, const vo
                                  uint32_t n_cpi, uint64_t cpi_stride, void *d_y_out, int32_t *d_ok,
                                  void *stream);
 /* Execution plan of the filter.  SOLVE_K: indices of the Toeplitz recursion per thread (0 = by
- * size: 2 up to 2048 taps, 4 above; the workgroup has ceil(nBins / K) threads rounded up to a wave). */
+ * size: 1 up to 1024 taps, 2 up to 2048, 4 above; the workgroup has ceil(nBins / K) threads rounded up to a wave). */
 #define BLAH2HIP_CLUTTER_OPT_SOLVE_K 1
 int blah2hip_clutter_set_option(blah2hip_clutter_t h, int option, int64_t value);
 /* Derived sizes: nBins = delayMax - delayMin taps (WienerHopf.cpp:12), on-chip transform
