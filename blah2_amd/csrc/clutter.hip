@@ -191,23 +191,28 @@ __global__ __launch_bounds__(256) void clutter_reduce_kernel(SolveArgs a)
 //     a_{m+1}[j] = (a_m[j]   - ef       c_m[j-1]) / D        f_{m+1}[i]        = (f_m[i]         - ef       conj f_m[m-i]) / D
 //     c_{m+1}[j] = (c_m[j-1] - conj(ef) a_m[j]  ) / D        conj f_{m+1}[m-i] = (conj f_m[m-i] - conj(ef) f_m[i]      ) / D
 //     g_{m+1}[j] = g_m[j] - d c_{m+1}[j]                     x_{m+1}[i]        = x_m[i] + d conj f_{m+1}[m-i]
-// The left column is carried UNNORMALISED, A = s a, C = s c with s_{m+1} = s_m D (the prediction-error
-// power relative to r[0]), which removes its divisions: A' = A - ef C[j-1], C' = C[j-1] - conj(ef) A,
-// ef = A_m[m] / s_m and g' = g - (d / s_{m+1}) C'.  One reciprocal per order (1/D; 1/s follows by a
-// product), computed by the one thread that owns index m+1 while the others run to the barrier.
-// Index j > m carries (A[j], -g[j]) in registers and C[j] in LDS; index j <= m carries (f[j], x[j]) in
-// registers and f[j] in LDS (the mirror index m-j is another thread's).  An index changes role once, at
-// m = j, where A[m] and g[m] have been consumed as the scalars and f[m] = x[m] = 0 start.  Thread t
-// owns the indices t + NT k.  The LDS array is double-buffered: one barrier per order.
+// Both columns are carried UNNORMALISED -- A = s a, C = s c, F = s f with s_{m+1} = s_m D, the
+// prediction-error power relative to r[0] -- which removes every per-element division and makes the two
+// columns literally the same update,
+//     (u, v) -> (u - ef v, v - conj(ef) u),      acc += dt v',      ef = A_m[m] / s_m,  dt = d / s_{m+1},
+// on different operands: index j > m carries (A[j], C[j-1], -g[j]), index j <= m carries
+// (F[j], conj F[m-j], x[j]).  An index changes role once, at m = j, where A[m] and g[m] have been
+// consumed as the scalars and F[m] = x[m] = 0 start.  Thread t owns the indices t + NT k (u and acc in
+// registers); v comes from a neighbour (C[j-1]) or the mirror index (F[m-j]) through an LDS array that
+// holds C[j] for j > m and F[j] for j <= m, double-buffered so that one barrier per order suffices.
+// The critical path of an order is short: the owner of index m+1 forms ef' = A'[m+1] / s_{m+1} as soon
+// as its own update is done -- 1/s_{m+1} = (1/s_m)(1/D) needs only THIS order's ef, so every thread
+// computes it (one reciprocal) while the LDS operands are in flight -- and publishes (ef', 1/s_{m+1},
+// d') for the next order.
 // The matrix is positive definite iff r[0] > 0 and every D > 0 -- the condition under which the
 // reference's chol() succeeds (WienerHopf.cpp:111) -- else ok = 0.  fp64 throughout.
-__device__ __forceinline__ dcx dsub_mul(dcx u, dcx e, dcx v) // u - e*v
+__device__ __forceinline__ dcx dsub_mul(dcx u, dcx e, dcx v) // u - e*v, two dependent fmas per component
 {
-  return {u.x - (e.x * v.x - e.y * v.y), u.y - (e.x * v.y + e.y * v.x)};
+  return {__builtin_fma(e.y, v.y, __builtin_fma(-e.x, v.x, u.x)), __builtin_fma(-e.y, v.x, __builtin_fma(-e.x, v.y, u.y))};
 }
 __device__ __forceinline__ dcx dadd_mul(dcx u, dcx e, dcx v) // u + e*v
 {
-  return {u.x + (e.x * v.x - e.y * v.y), u.y + (e.x * v.y + e.y * v.x)};
+  return {__builtin_fma(-e.y, v.y, __builtin_fma(e.x, v.x, u.x)), __builtin_fma(e.y, v.x, __builtin_fma(e.x, v.y, u.y))};
 }
 // 1/d for d in (0, 1]: hardware estimate + two Newton steps (5 dependent instructions instead of the
 // ~10 of the IEEE-exact division sequence; this reciprocal sits on the critical path of every order)
@@ -220,35 +225,20 @@ __device__ __forceinline__ double fast_rcp(double d)
   return __builtin_fma(r, e, r);
 }
 
-// scalars of one order, published by the owner of index m through LDS
+// scalars of one order, published through LDS by the owner of index m at the end of order m-1
 struct SolveScal {
-  dcx ef;     // reflection coefficient a_m[m]
-  dcx d;      // g_m[m]
-  dcx dt;     // d / s_{m+1}
-  double D;   // 1 - |ef|^2
-  double inv; // 1 / D
-  double rsn; // 1 / s_{m+1}
+  dcx ef;    // reflection coefficient a_m[m] = A_m[m] / s_m
+  dcx d;     // g_m[m]
+  double rs; // 1 / s_m
   double pad;
 };
-__device__ __forceinline__ SolveScal solve_scalars(dcx Am, dcx gm, double rs) // rs = 1 / s_m
-{
-  SolveScal q;
-  q.ef = {Am.x * rs, Am.y * rs};
-  q.D = 1.0 - (q.ef.x * q.ef.x + q.ef.y * q.ef.y);
-  q.inv = fast_rcp(q.D > 0.0 ? q.D : 1.0); // D <= 0 ends the recursion (ok = 0): any finite value will do
-  q.rsn = rs * q.inv;
-  q.d = gm;
-  q.dt = {gm.x * q.rsn, gm.y * q.rsn};
-  q.pad = 0.0;
-  return q;
-}
 
 template <int K>
 __global__ __launch_bounds__(1024) void clutter_solve_kernel(SolveArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n = a.nBins;
-  // two buffers of n + 1 entries (entry n stays zero: "f[m]" as seen by index 0), then the scalars
+  // two buffers of n + 1 entries (entry n stays zero: "F[m]" as seen by index 0), then the scalars
   dcx *cur = reinterpret_cast<dcx *>(smem);
   dcx *nxt = cur + (n + 1);
   SolveScal *scal = reinterpret_cast<SolveScal *>(nxt + (n + 1)); // [parity]
@@ -268,17 +258,17 @@ __global__ __launch_bounds__(1024) void clutter_solve_kernel(SolveArgs a)
     if (j < n) {
       const dcx rj = rg[j], bj = rg[n + j];
       if (j == 0) {
-        U[k] = {inv0, 0.0}; // f_1[0]
+        U[k] = {inv0, 0.0}; // F_1[0] = f_1[0] (s_1 = 1)
         Acc[k] = x0;
       } else {
-        U[k] = {rj.x * inv0, rj.y * inv0};  // A_1[j] = a_1[j] = r[j] / r[0]  (= C_1[j], s_1 = 1)
+        U[k] = {rj.x * inv0, rj.y * inv0};  // A_1[j] = r[j] / r[0]  (= C_1[j])
         const dcx g = dsub_mul(bj, rj, x0); // g_1[j] = b[j] - r[j] x_1[0]
         Acc[k] = {-g.x, -g.y};
       }
       cur[j] = U[k];
       if (j == 1) {
-        scal[1] = solve_scalars(U[k], {-Acc[k].x, -Acc[k].y}, 1.0);
-        U[k] = {0.0, 0.0};   // becomes f[1] = 0, x[1] = 0 at order 1
+        scal[1] = SolveScal{U[k], {-Acc[k].x, -Acc[k].y}, 1.0, 0.0};
+        U[k] = {0.0, 0.0};   // becomes F[1] = 0, x[1] = 0 at order 1
         Acc[k] = {0.0, 0.0};
       }
     }
@@ -287,35 +277,33 @@ __global__ __launch_bounds__(1024) void clutter_solve_kernel(SolveArgs a)
   __syncthreads();
   for (int m = 1; m < n && ok; m++) {
     const SolveScal q = scal[m & 1];
-    if (!(q.D > 0.0) || !isfinite(q.D)) { ok = false; break; } // uniform: every thread reads the same scalars
+    // operands first: they are in flight while the scalars below are formed
+    dcx v[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int j = t + NT * k;
+      const int src = (j > m) ? j - 1 : (j == 0 ? n : m - j); // C[j-1], or F[m-j] (F[m] = 0 lives in entry n)
+      const dcx s = cur[min(src, n)];
+      v[k] = {s.x, (j > m) ? s.y : -s.y};
+    }
+    const double D = __builtin_fma(-q.ef.y, q.ef.y, __builtin_fma(-q.ef.x, q.ef.x, 1.0));
+    if (!(D > 0.0) || !isfinite(D)) { ok = false; break; } // uniform: every thread reads the same scalars
+    const double rsn = q.rs * fast_rcp(D); // 1 / s_{m+1}
+    const dcx dt = {q.d.x * rsn, q.d.y * rsn};
     const dcx efc = {q.ef.x, -q.ef.y};
 #pragma unroll
     for (int k = 0; k < K; k++) {
       const int j = t + NT * k;
       if (j < n) {
-        if (j > m) {
-          const dcx c1 = cur[j - 1];
-          const dcx An = dsub_mul(U[k], q.ef, c1);
-          const dcx Cn = dsub_mul(c1, efc, U[k]);
-          const dcx Gn = dadd_mul(Acc[k], q.dt, Cn);
-          nxt[j] = Cn;
-          U[k] = An;
-          Acc[k] = Gn;
-          if (j == m + 1) { // the next order's scalars; this index turns into f[m+1] = 0, x[m+1] = 0
-            scal[(m + 1) & 1] = solve_scalars(An, {-Gn.x, -Gn.y}, q.rsn);
-            U[k] = {0.0, 0.0};
-            Acc[k] = {0.0, 0.0};
-          }
-        } else {
-          const dcx s = cur[j == 0 ? n : m - j]; // f[m - j]; f[m] = 0
-          const dcx v = {s.x, -s.y};
-          dcx up = dsub_mul(U[k], q.ef, v), vp = dsub_mul(v, efc, U[k]);
-          up = {up.x * q.inv, up.y * q.inv};
-          vp = {vp.x * q.inv, vp.y * q.inv};
-          nxt[j] = up;
-          U[k] = up;
-          Acc[k] = dadd_mul(Acc[k], q.d, vp);
-        }
+        const dcx un = dsub_mul(U[k], q.ef, v[k]);
+        const dcx vn = dsub_mul(v[k], efc, U[k]);
+        const dcx an = dadd_mul(Acc[k], dt, vn);
+        const bool hi = j > m;
+        nxt[j] = {hi ? vn.x : un.x, hi ? vn.y : un.y};
+        const bool owner = (j == m + 1); // this index turns into F[m+1] = 0, x[m+1] = 0 for the next order
+        if (owner) scal[(m + 1) & 1] = SolveScal{{un.x * rsn, un.y * rsn}, {-an.x, -an.y}, rsn, 0.0};
+        U[k] = {owner ? 0.0 : un.x, owner ? 0.0 : un.y};
+        Acc[k] = {owner ? 0.0 : an.x, owner ? 0.0 : an.y};
       }
     }
     __syncthreads();
