@@ -1,27 +1,40 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun) from the repo root:
 #   gpurun --timeout 1500 -- 'bash tools/profile_round.sh'
-# then, back in the container:  python tools/summarize_prof.py r01
-# Leaves under gpurun_out/: bench logs, rocprofv3 kernel-trace stats and the
-# separate PMC passes (never combined with a trace domain) for the bench command.
+# then, back in the container:  python tools/summarize_prof.py r02
+# For each profiled bench command (tag -> arguments below) leaves under gpurun_out/prof/<tag>/:
+# the rocprofv3 --kernel-trace --stats run and the separate PMC passes (never combined with a
+# trace domain other than --kernel-trace), plus the plain bench logs.
 set -u
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
-BATCH=${BATCH:-128}
 mkdir -p $OUT/prof
 cd /tmp && export TMPDIR=/tmp
-B="python $REPO/bench.py --steps 20 --warmup 5 --batch $BATCH --no-cpu-baseline"
-echo "{\"config\": \"cfg2\", \"batch\": $BATCH, \"fmt\": \"c32\"}" > $OUT/prof/bench_config.json
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof/trace -o bench --output-format csv -- $B > $OUT/prof/trace.log 2>&1
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES"; do
-  tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
-  timeout 300 rocprofv3 --kernel-trace --pmc $pass -d $OUT/prof/pmc_$tag -o bench --output-format csv -- $B > $OUT/prof/pmc_$tag.log 2>&1 || echo "pmc pass $pass failed"
-done
+profile() { # tag, json description, bench args...
+  local tag=$1; local desc=$2; shift 2
+  local B="python $REPO/bench.py $* --no-cpu-baseline --no-parity"
+  mkdir -p $OUT/prof/$tag
+  echo "$desc" > $OUT/prof/$tag/bench_config.json
+  timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof/$tag/trace -o bench --output-format csv -- $B > $OUT/prof/$tag/trace.log 2>&1
+  for pass in "FETCH_SIZE" "WRITE_SIZE" ${PMC_EXTRA:+"SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE"}; do
+    local ptag=$(echo $pass | tr ' ' '_' | cut -c1-40)
+    timeout 400 rocprofv3 --kernel-trace --pmc $pass -d $OUT/prof/$tag/pmc_$ptag -o bench --output-format csv -- $B > $OUT/prof/$tag/pmc_$ptag.log 2>&1 || echo "pmc pass $pass failed ($tag)"
+  done
+}
+PMC_EXTRA=1 profile amb '{"config": "cfg2", "batch": 128, "fmt": "c32", "chain": "amb"}' --steps 20 --warmup 5
+PMC_EXTRA= profile full '{"config": "cfg2", "batch": 64, "fmt": "c32", "chain": "full"}' --chain full --batch 64 --steps 10 --warmup 3
+PMC_EXTRA= profile cfg3_full '{"config": "cfg3", "batch": 32, "fmt": "c32", "chain": "full"}' --config cfg3 --chain full --batch 32 --steps 5 --warmup 2
+PMC_EXTRA= profile cfg5 '{"config": "cfg5", "batch": 4, "fmt": "f16", "chain": "amb"}' --config cfg5 --fmt f16 --steps 10 --warmup 2
+mkdir -p $OUT/cal
+timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/cal/fetch -o cal --output-format csv -- $REPO/tools/membench/pmccal > $OUT/cal/fetch.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/cal/write -o cal --output-format csv -- $REPO/tools/membench/pmccal > $OUT/cal/write.log 2>&1
 cd $REPO
-python bench.py > $OUT/bench_r1.log 2>&1
-python bench.py --batch 1 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_r1_b1.log 2>&1
-python bench.py --fmt i16 --no-cpu-baseline > $OUT/bench_r1_i16.log 2>&1
-python bench.py --chain full --batch 64 --no-cpu-baseline > $OUT/bench_r1_full.log 2>&1
-python bench.py --config cfg3 --batch 8 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_r1_cfg3.log 2>&1
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_r1_torchrun.log 2>&1
-tail -n 1 $OUT/bench_r1*.log
+python bench.py > $OUT/bench_r2.log 2>&1
+python bench.py --batch 1 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_r2_b1.log 2>&1
+python bench.py --fmt i16 --no-cpu-baseline > $OUT/bench_r2_i16.log 2>&1
+python bench.py --chain full --batch 64 --no-cpu-baseline > $OUT/bench_r2_full.log 2>&1
+python bench.py --config cfg3 --batch 8 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_r2_cfg3.log 2>&1
+python bench.py --config cfg3 --chain full --batch 32 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_r2_cfg3_full.log 2>&1
+python bench.py --config cfg5 --fmt f16 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_r2_cfg5.log 2>&1
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_r2_torchrun.log 2>&1
+tail -qn 1 $OUT/bench_r2*.log | cut -c1-200

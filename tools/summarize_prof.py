@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
-"""Condenses rocprofv3 output under gpurun_out/prof into the tracked summaries
-under profiles/ (per round):
+"""Condenses rocprofv3 output under gpurun_out/prof/<tag>/ (tools/profile_round.sh) into the tracked
+summaries under profiles/ (per round):
 
-    python tools/summarize_prof.py r01
+    python tools/summarize_prof.py r02
 
-  profiles/<round>_kernel_stats.csv   rocprofv3 --kernel-trace --stats (our kernels)
-  profiles/<round>_pmc.csv            per-kernel averages of every PMC pass found
-  profiles/<round>_traffic.json       HBM bytes per launch for bench.py's roofline.traffic
+  profiles/<round>_<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats (our kernels)
+  profiles/<round>_<tag>_pmc.csv            per-kernel averages of every PMC pass found
+  profiles/<round>_<tag>_traffic.json       HBM bytes per launch for bench.py's roofline.traffic
+  profiles/<round>_pmc_calibration.json     FETCH_SIZE / WRITE_SIZE against known byte counts (pmccal)
 
-HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE
-and WRITE_SIZE are in KiB, collected in separate --pmc passes; on gfx950
-FETCH_SIZE counts 64 B per 128-B request, so it is doubled; WRITE_SIZE is taken
-as reported (uncalibrated).
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are
+in KiB, collected in separate --pmc passes; on gfx950 FETCH_SIZE counts 64 B per 128-B request, so it
+is doubled.  tools/membench/pmccal.hip calibrates both on this engine's access patterns: the x2 holds
+for 8 and 16 B/lane streaming reads; WRITE_SIZE is exact for whole lines and counts 32-byte sectors
+for partial-line row segments (a 64-byte segment at an arbitrary 8-byte phase touches 2.75 sectors).
 """
 import collections
 import csv
@@ -24,23 +26,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 
+KERNELS = ("range8_kernel", "range_kernel", "doppler_tilem_kernel", "doppler_tile_kernel", "doppler_fft_kernel",
+           "doppler_dft_kernel", "metrics_kernel", "cfar1d_kernel", "cfar2d_kernel", "sat_rows_kernel", "sat_cols_kernel",
+           "rotate_kernel", "clutter_corr_kernel", "clutter_fir_kernel", "clutter_solve_kernel", "clutter_reduce_kernel",
+           "db_map_kernel", "cal_")
+
 
 def short(name):
-    for k in ("range_kernel", "doppler_tile_kernel", "doppler_fft_kernel", "doppler_dft_kernel", "metrics_kernel",
-              "cfar1d_kernel", "cfar2d_kernel", "sat_rows_kernel", "sat_cols_kernel", "rotate_kernel",
-              "clutter_corr_kernel", "clutter_fir_kernel", "clutter_solve_kernel", "clutter_reduce_kernel"):
+    for k in KERNELS:
         if k in name:
-            return k
+            return k if k != "cal_" else name.split("(")[0].replace("void ", "")
     return None
 
 
-def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    os.makedirs(DST, exist_ok=True)
-    stats = os.path.join(SRC, "trace", "bench_kernel_stats.csv")
+def summarize(src, tag, prefix):
+    stats = os.path.join(src, "trace", "bench_kernel_stats.csv")
     if os.path.exists(stats):
         rows = [r for r in csv.DictReader(open(stats)) if short(r["Name"])]
-        with open(os.path.join(DST, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        with open(os.path.join(DST, f"{prefix}_kernel_stats.csv"), "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct_of_all_gpu_time", "min_ns", "max_ns", "stddev_ns"])
             for r in rows:
@@ -48,7 +51,7 @@ def main():
                             r["MinNs"], r["MaxNs"], r["StdDev"]])
     agg = collections.defaultdict(list)
     meta = {}
-    for path in sorted(glob.glob(os.path.join(SRC, "*", "bench_counter_collection.csv"))):
+    for path in sorted(glob.glob(os.path.join(src, "*", "*_counter_collection.csv"))):
         for r in csv.DictReader(open(path)):
             k = short(r["Kernel_Name"])
             if not k:
@@ -56,14 +59,16 @@ def main():
             agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
             meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["Scratch_Size"],
                        r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"])
-    with open(os.path.join(DST, f"{tag}_pmc.csv"), "w", newline="") as f:
+    if not agg:
+        return None
+    with open(os.path.join(DST, f"{prefix}_pmc.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch", "grid", "wg", "lds_bytes", "scratch",
                     "vgpr", "agpr", "sgpr"])
         for (k, c), v in sorted(agg.items()):
             w.writerow([k, c, len(v), f"{sum(v)/len(v):.6g}", *meta[k]])
     traffic = {}
-    for k in {k for k, _ in agg}:
+    for k in sorted({k for k, _ in agg}):
         fs = agg.get((k, "FETCH_SIZE"))
         ws = agg.get((k, "WRITE_SIZE"))
         if fs and ws:
@@ -71,13 +76,47 @@ def main():
             write = 1024.0 * sum(ws) / len(ws)
             traffic[k] = {"fetch_bytes": fetch, "write_bytes": write, "hbm_bytes": fetch + write,
                           "note": "FETCH_SIZE KiB x2 (gfx950 64B-per-128B-request correction) + WRITE_SIZE KiB"}
-    cfgp = os.path.join(SRC, "bench_config.json")
+    cfgp = os.path.join(src, "bench_config.json")
     out = {"round": tag, "kernels": traffic}
     if os.path.exists(cfgp):
         out["bench_config"] = json.load(open(cfgp))
-    json.dump(out, open(os.path.join(DST, f"{tag}_traffic.json"), "w"), indent=1)
-    print(open(os.path.join(DST, f"{tag}_kernel_stats.csv")).read() if os.path.exists(stats) else "no stats")
-    print(json.dumps(traffic, indent=1))
+    json.dump(out, open(os.path.join(DST, f"{prefix}_traffic.json"), "w"), indent=1)
+    return traffic
+
+
+def calibration(tag):
+    src = os.path.join(ROOT, "gpurun_out", "cal")
+    known = {"cal_read8": 2 ** 30, "cal_read16": 2 ** 30, "cal_read_half": 2 ** 29, "cal_write8": 2 ** 30,
+             "cal_write_seg<32>": 32 * (2 ** 30 // 3288), "cal_write_seg<64>": 64 * (2 ** 30 // 3288),
+             "cal_write_seg<128>": 128 * (2 ** 30 // 3288)}
+    res = {}
+    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        path = os.path.join(src, kind, "cal_counter_collection.csv")
+        if not os.path.exists(path):
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            if k in known and ((kind == "fetch") == ("read" in k)):
+                raw = 1024.0 * sum(v) / len(v)
+                res[k] = {"counter": counter, "known_bytes": known[k], "reported_bytes_raw_KiB_x1024": raw,
+                          "reported_over_known": raw / known[k]}
+    if res:
+        json.dump({"round": tag, "tool": "tools/membench/pmccal.hip", "patterns": res}, open(os.path.join(DST, f"{tag}_pmc_calibration.json"), "w"), indent=1)
+    return res
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    os.makedirs(DST, exist_ok=True)
+    for sub in sorted(os.listdir(SRC)) if os.path.isdir(SRC) else []:
+        src = os.path.join(SRC, sub)
+        if os.path.isdir(os.path.join(src, "trace")) or glob.glob(os.path.join(src, "pmc_*")):
+            t = summarize(src, tag, f"{tag}_{sub}")
+            print(sub, json.dumps(t, indent=1) if t else "no counters")
+    print(json.dumps(calibration(tag), indent=1))
 
 
 if __name__ == "__main__":
