@@ -63,6 +63,28 @@ __device__ __forceinline__ uint32_t xs_index(uint32_t i, const XsMap &m)
 // n < 2N -> n mod N
 __device__ __forceinline__ uint32_t wrapN(uint32_t n, uint32_t N) { return n >= N ? n - N : n; }
 
+// XCD-aware walk over the segments of a CPI.  Neighbouring segments read overlapping windows (F samples
+// for segLen = F - nBins + 1 new ones: 2x at nBins = F/2), and workgroups are dispatched round-robin
+// over the 8 XCDs, each with its own L2: with the natural map (workgroup b takes segments b, b + G, ...)
+// the two readers of a shared half-window sit on different XCDs and both fetch it from HBM (measured,
+// profiles/r02_cfg3_full: 10.3 GB fetched for 5.1 GB of input).  Here every XCD owns one contiguous
+// eighth of the segments, and in each round its G/8 workgroups take G/8 CONSECUTIVE segments, so the
+// overlaps are served by that XCD's L2.  gridDim.x must be a multiple of 8.
+struct SegWalk {
+  int base, step, first, count; // segments base + first + k*step, while first + k*step < count
+};
+__device__ __forceinline__ SegWalk seg_walk(int nSeg)
+{
+  const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3, gx = gridDim.x >> 3;
+  const int s8 = (nSeg + 7) >> 3;
+  SegWalk w;
+  w.base = xcd * s8;
+  w.step = gx;
+  w.first = l;
+  w.count = min(s8, nSeg - w.base); // may be <= 0 for the last XCDs of a short CPI
+  return w;
+}
+
 struct CorrArgs {
   const cf *x, *y;
   int64_t cpiStride;
@@ -94,7 +116,9 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_ker
   cf accR[16], accB[16];
 #pragma unroll
   for (int e = 0; e < 16; e++) { accR[e] = cmake(0.f, 0.f); accB[e] = cmake(0.f, 0.f); }
-  for (int g = blockIdx.x; g < a.nSeg; g += a.nJobs) {
+  const SegWalk sw = seg_walk(a.nSeg);
+  for (int r = sw.first; r < sw.count; r += sw.step) {
+    const int g = sw.base + r;
     const uint32_t n0 = (uint32_t)g * (uint32_t)a.segLen;
     // all 32 loads of the segment first (the y window is consumed last)
     cf v[16], wv[16], yw[16];
@@ -365,7 +389,9 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_fir_kern
 
   const int hist = a.nBins - 1; // samples of history in front of each block
   const int N = (int)a.N;       // < 2^31 - 8192 (checked at create): 32-bit sample indices throughout
-  for (int g = blockIdx.x; g < a.nSeg; g += gridDim.x) {
+  const SegWalk sw = seg_walk(a.nSeg);
+  for (int r = sw.first; r < sw.count; r += sw.step) {
+    const int g = sw.base + r;
     const int n0 = g * a.segLen;
     cf v[16], yv[16];
 #pragma unroll
@@ -469,8 +495,10 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   // the taps -- per-workgroup costs that a long walk over segments amortises.  Two
   // resident generations' worth keeps the tail short.
   const int slots = 4 * h->numCU; // residency of these kernels: 4 workgroups per CU (LDS)
-  const int nJobs = std::max(1, std::min(h->nJobs, (2 * slots + (int)nCpi - 1) / (int)nCpi));
-  const int firGrid = std::max(1, std::min(h->firGrid, (2 * slots + (int)nCpi - 1) / (int)nCpi));
+  // (multiples of 8: the segment walk is XCD-aware, see seg_walk)
+  auto up8 = [](int v) { return std::max(8, (v + 7) & ~7); };
+  const int nJobs = std::min(h->nJobs, up8((2 * slots + (int)nCpi - 1) / (int)nCpi));
+  const int firGrid = std::min(h->firGrid, up8((2 * slots + (int)nCpi - 1) / (int)nCpi));
   CorrArgs ca;
   ca.x = x; ca.y = y; ca.cpiStride = stride; ca.N = h->N; ca.xs = xs;
   ca.nBins = h->nBins; ca.segLen = h->segLen; ca.nSeg = h->nSeg; ca.nJobs = nJobs;
@@ -560,8 +588,9 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
   hipDeviceProp_t prop;
   CHIP(hipGetDeviceProperties(&prop, device));
   h->numCU = prop.multiProcessorCount;
-  h->nJobs = std::min(h->nSeg, 2 * prop.multiProcessorCount); // partial correlations per CPI (x2 modes in one workgroup)
-  h->firGrid = std::min(h->nSeg, 8 * prop.multiProcessorCount);
+  auto up8 = [](int v) { return std::max(8, (v + 7) & ~7); };
+  h->nJobs = up8(std::min(h->nSeg, 2 * prop.multiProcessorCount)); // partial correlations per CPI (x2 modes in one workgroup)
+  h->firGrid = up8(std::min(h->nSeg, 8 * prop.multiProcessorCount));
   CHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   std::vector<cf> tw(h->F);
   for (int k = 0; k < h->F; k++) {

@@ -32,6 +32,10 @@ KERNELS = ("range8_kernel", "range_kernel", "doppler_tilem_kernel", "doppler_til
            "db_map_kernel", "cal_")
 
 
+# kernels whose global reads are 64-byte (or shorter) pieces of 128-byte lines
+HALF_LINE_READERS = ("doppler_tile_kernel", "doppler_tilem_kernel")
+
+
 def short(name):
     for k in KERNELS:
         if k in name:
@@ -72,10 +76,14 @@ def summarize(src, tag, prefix):
         fs = agg.get((k, "FETCH_SIZE"))
         ws = agg.get((k, "WRITE_SIZE"))
         if fs and ws:
-            fetch = 2.0 * 1024.0 * sum(fs) / len(fs)
+            # FETCH_SIZE counts 64 B per request: a whole-line (128 B) request is under-counted by 2, a
+            # half-line request (the 8-column Doppler tile reads 64 of every 128 B) is counted exactly
+            # (profiles/*_pmc_calibration.json: cal_read8/16 -> 0.5, cal_read_half -> 1.0)
+            factor = 1.0 if k in HALF_LINE_READERS else 2.0
+            fetch = factor * 1024.0 * sum(fs) / len(fs)
             write = 1024.0 * sum(ws) / len(ws)
-            traffic[k] = {"fetch_bytes": fetch, "write_bytes": write, "hbm_bytes": fetch + write,
-                          "note": "FETCH_SIZE KiB x2 (gfx950 64B-per-128B-request correction) + WRITE_SIZE KiB"}
+            traffic[k] = {"fetch_bytes": fetch, "write_bytes": write, "hbm_bytes": fetch + write, "fetch_factor": factor,
+                          "note": f"FETCH_SIZE KiB x{factor:g} (64 B counted per request) + WRITE_SIZE KiB (32-byte sectors)"}
     cfgp = os.path.join(src, "bench_config.json")
     out = {"round": tag, "kernels": traffic}
     if os.path.exists(cfgp):
