@@ -40,6 +40,7 @@ CONFIGS = {
     "cfg2": ((-10, 400, -256, 256, 2_000_000, 2_000_000), "BASELINE configs[1]: 2 MS/s, 1 s CPI, +-256 Hz"),
     "test": ((-10, 300, -300, 300, 2_000_000, 1_000_000), "TestAmbiguity.cpp geometry: 2 MS/s, 0.5 s CPI, +-300 Hz"),
     "small": ((-10, 100, -100, 100, 1_000_000, 100_000), "tests/golden `medium` geometry: 1 MS/s, 0.1 s CPI, +-100 Hz (F = 1024 range kernel)"),
+    "yml": ((-10, 400, -200, 200, 2_000_000, 1_500_000), "config/config.yml defaults: 2 MS/s, 0.75 s CPI, +-200 Hz"),
     "cfg3": ((-24, 2023, -512, 512, 10_000_000, 10_000_000), "BASELINE configs[2]: 10 MS/s, 1 s CPI, +-512 Hz"),
     "cfg5": ((-10, 400, -512, 512, 20_000_000, 40_000_000), "BASELINE configs[4]: 20 MS/s, 2 s CPI, +-512 Hz"),  # use --fmt f16
 }

@@ -166,9 +166,9 @@ bool choose_plan(blah2hip_amb_s *h)
     if (lmax < 16) continue;
     const int nSeg = (nCorr + lmax - 1) / lmax;
     const int segLen = (nCorr + nSeg - 1) / nSeg;
-    // measured on MI355X (tools/gpu_diag.py): at equal butterfly count the one-wave
-    // F = 1024 transform is ~8 % slower per point than the multi-wave ones
-    const double cost = (2.0 * nSeg + 1.0) * F * std::log2((double)F) * (r3 == 4 ? 1.05 : 1.0);
+    // measured on MI355X (round 2, forced lengths at three geometries): at equal butterfly count the
+    // F = 1024 kernel is ~3 % slower than the F = 2048 one
+    const double cost = (2.0 * nSeg + 1.0) * F * std::log2((double)F) * (r3 == 4 ? 1.03 : 1.0);
     if (cost < best) {
       best = cost;
       found = true;
@@ -281,6 +281,12 @@ template <int R4, class In> int launch_range8_t(blah2hip_amb_s *h, const RangeAr
 
 // F = 1024: 8 points per thread (one-wave transforms: 10.5 vs 14.3 us/CPI at cfg 2 with 16 points per
 // thread); F = 2048 / 4096: 16 points per thread (10.0 vs 10.3 us/CPI; equal at 4096).  Measured, round 1.
+// F = 1024: 8 points per thread with stage 4 across lanes (4 waves per SIMD); F = 2048 / 4096: 16 points
+// per thread.  Measured in round 2 (range kernel, us per launch): F = 1024 (tests/golden `medium`
+// geometry x 1024 CPIs) 362 with the lane form, 446 with the LDS form of stage 4 it replaced;
+// F = 2048 (cfg 2 x 128): 16-point 1192, 8-point lane form 1363-1372 (4 or 3 waves per SIMD); F = 4096
+// (cfg 3 x 8): 568 vs 707.  The 8-point transform executes 26 % more VALU instructions per point
+// (radix 8-8-8-4 twiddles + the lane butterflies) and the kernel follows that count, not its occupancy.
 template <class In> int launch_range(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
 {
   switch (h->r3) {
@@ -320,6 +326,27 @@ int host_tail(blah2hip_amb_s *h, float *map_out, double *metrics)
   if (metrics) HIPCHK(hipMemcpyAsync(metrics, h->d_metrics, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return BLAH2HIP_OK;
+}
+
+// Workgroups of the range kernel that fit a CU (LDS and registers): the grid of a launch is capped
+// there and the kernel walks the pulses with a grid stride.
+void set_range_residency(blah2hip_amb_s *h)
+{
+  const bool e8 = h->r3 == 4;
+  size_t lds;
+  int waves, wavesPerCU;
+  if (e8) {
+    lds = (size_t)2 * WgFft8<2>::BUF_ELEMS * sizeof(cf);
+    waves = h->r3 / 2;  // F/8 threads
+    wavesPerCU = 4 * RANGE8_WAVES_PER_SIMD; // the kernel's register cap: 4 waves per SIMD at <= 128 VGPRs
+  } else {
+    lds = (size_t)(h->r3 == 8 ? WgFft<8>::A_ELEMS + WgFft<8>::B_ELEMS : WgFft<16>::A_ELEMS + WgFft<16>::B_ELEMS) * sizeof(cf);
+    waves = h->r3 / 4;  // F/16 threads
+    wavesPerCU = 8;     // 230-247 VGPRs: 2 waves per SIMD
+  }
+  h->rangeLds = lds;
+  const int perCU = std::max(1, std::min((int)((160 * 1024) / lds), wavesPerCU / std::max(1, waves)));
+  h->rangeGridCap = h->rangeGridDefault = perCU * h->numCU;
 }
 
 // Which Doppler kernel a launch of n_cpi CPIs runs.  The tile kernels (coalesced tile
@@ -465,18 +492,7 @@ int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler
 
   const uint32_t nD = h->dims.n_doppler_bins, nDelay = h->dims.n_delay_bins;
   const int F = h->dims.fft_len;
-  // range kernel residency: LDS-limited
-  {
-    const size_t lds = (h->r3 == 4 ? (size_t)(WgFft<4>::A_ELEMS + WgFft<4>::B_ELEMS)
-                        : h->r3 == 8 ? (size_t)(WgFft<8>::A_ELEMS + WgFft<8>::B_ELEMS)
-                                     : (size_t)(WgFft<16>::A_ELEMS + WgFft<16>::B_ELEMS)) * sizeof(cf);
-    h->rangeLds = lds;
-    int perCU = (int)((160 * 1024) / lds);
-    const int wavesPerWg = (16 * h->r3) / 64;
-    perCU = std::min(perCU, 32 / wavesPerWg);
-    perCU = std::max(perCU, 1);
-    h->rangeGridCap = h->rangeGridDefault = perCU * h->numCU;
-  }
+  set_range_residency(h);
 
   std::vector<cf> tw(F);
   for (int k = 0; k < F; k++) tw[k] = root_of_unity(k, F);

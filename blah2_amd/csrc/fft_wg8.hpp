@@ -7,6 +7,15 @@
 // HBM latencies are hidden by other waves (profiles/r01_pmc.csv: at 2 waves per
 // SIMD a wave issued a VALU instruction every ~8 cycles, ideal 4).
 //
+// Stage 4 has two forms.  The LDS form (fwd_s3_store + fwd_s4 / inv_s4 + inv_s3_load) is a third
+// exchange through E3.  The lane form (fwd_s3_lanes / inv_s4_lanes, device only) keeps the data where
+// stage 3 left it: the R4 inputs of a stage-4 DFT sit in R4 CONSECUTIVE LANES (t3 = t mod R4), so the
+// DFT runs across lanes with DPP moves (quad_perm for lane^1 and lane^2, row_half_mirror + a quad
+// reversal for lane^4) as a decimation-in-frequency butterfly network with per-lane signs and
+// twiddles -- two LDS exchanges and two barriers per transform instead of three.  The spectrum then
+// stays in thread (q1,q2,t3), register q3, at frequency index q4 = bitrev(t3); X and Y share the
+// layout and the inverse mirrors it, so nothing else changes.
+//
 // Index algebra, T2 = T/8 = 8*R4:
 //   n = t + T*k1,            t  = t2 + T2*k2,        t2 = t3 + R4*k3
 //   m = q1 + 8*q2 + 64*q3 + 512*q4
@@ -155,6 +164,77 @@ template <int R4> struct WgFft8 {
     for (int q = 1; q < 8; q++) v[q] = cmulc(E[q * P1 + t], tw1[q - 1]);
     dft8<+1>(v);
   }
+
+#if defined(__HIPCC__)
+  // ---- stage 4 across lanes ------------------------------------------------------
+  // per-lane constants of the butterfly network: sgn[b] = -1 on lanes whose bit b is set, and the
+  // twiddle a lane applies after (forward) / before (inverse) the level on bit b > 0:
+  // W_{2^(b+1)}^(lane mod 2^b) on lanes with bit b set, 1 elsewhere.  `tw` is exp(-2 pi i k/F).
+  struct LaneConst {
+    float sgn[3];
+    cf w[3]; // w[b] for b = 1, 2 (w[0] unused)
+  };
+  template <class TW> __device__ static LaneConst lane_constants(int t, const TW *tw)
+  {
+    LaneConst c;
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      const bool set = (t >> b) & 1;
+      c.sgn[b] = set ? -1.f : 1.f;
+      const int e = (t & ((1 << b) - 1)) * (F >> (b + 1)); // W_{2^(b+1)}^k = W_F^(k F / 2^(b+1))
+      c.w[b] = (b > 0 && set) ? tw[e & (F - 1)] : cmake(1.f, 0.f);
+    }
+    return c;
+  }
+  template <int MASK> __device__ __forceinline__ static float lane_xor(float v)
+  {
+    const int i = __builtin_bit_cast(int, v);
+    int r;
+    if (MASK == 1) r = __builtin_amdgcn_mov_dpp(i, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+    else if (MASK == 2) r = __builtin_amdgcn_mov_dpp(i, 0x4E, 0xf, 0xf, true); // quad_perm [2,3,0,1]
+    else {                                                                      // lane ^ 4
+      r = __builtin_amdgcn_mov_dpp(i, 0x141, 0xf, 0xf, true);                   // row_half_mirror: l -> 7 - l
+      r = __builtin_amdgcn_mov_dpp(r, 0x1B, 0xf, 0xf, true);                    // quad_perm [3,2,1,0]: -> l ^ 4
+    }
+    return __builtin_bit_cast(float, r);
+  }
+  template <int B> __device__ __forceinline__ static cf lane_bfly(cf z, const LaneConst &c)
+  {
+    // lanes with bit B clear: z + partner; set: partner - z
+    return cmake(__builtin_fmaf(z.x, c.sgn[B], lane_xor<(1 << B)>(z.x)), __builtin_fmaf(z.y, c.sgn[B], lane_xor<(1 << B)>(z.y)));
+  }
+  // forward: stage-3 DFT in registers, then the R4-point DFT across the lanes t3 = t mod R4
+  __device__ static void fwd_s3_lanes(int t, cf *v, const cf *tw3, const LaneConst &c, const cf *E)
+  {
+    fwd_s3_load(t, v, E);
+    dft8<-1>(v);
+#pragma unroll
+    for (int q = 1; q < 8; q++) v[q] = cmul(v[q], tw3[q - 1]);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      cf z = v[q];
+      if (R4 == 8) { z = lane_bfly<2>(z, c); z = cmul(z, c.w[2]); }
+      if (R4 >= 4) { z = lane_bfly<1>(z, c); z = cmul(z, c.w[1]); }
+      z = lane_bfly<0>(z, c);
+      v[q] = z;
+    }
+  }
+  // inverse (unnormalised): the mirror image, ends where inv_s3_load would have left v
+  __device__ static void inv_s4_lanes(int t, cf *v, const cf *tw3, const LaneConst &c)
+  {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      cf z = v[q];
+      z = lane_bfly<0>(z, c);
+      if (R4 >= 4) { z = cmulc(z, c.w[1]); z = lane_bfly<1>(z, c); }
+      if (R4 == 8) { z = cmulc(z, c.w[2]); z = lane_bfly<2>(z, c); }
+      v[q] = z;
+    }
+#pragma unroll
+    for (int q = 1; q < 8; q++) v[q] = cmulc(v[q], tw3[q - 1]);
+    dft8<+1>(v);
+  }
+#endif
 
 private:
   template <int SIGN> B2_HD static void small_dft(cf *w)

@@ -149,13 +149,15 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
 }
 
 // --------------------------------------------------------------------------
-// Range kernel on the 8-points-per-thread transform (fft_wg8.hpp), used for the
-// one-wave F = 1024 shape (measured 1.4x faster there than 16 points per thread;
-// equal or slower for F >= 2048): identical mathematics and interface, T = F/8
-// threads per pulse.  The x and y transforms of a segment run one after the other
-// and alternate their starting exchange buffer (x: A,B,A  y: B,A,B), so a buffer
-// is never rewritten before the barrier that follows its last read: 3 barriers
-// per transform and none in between.
+// Range kernel on the 8-points-per-thread transform (fft_wg8.hpp): identical mathematics and
+// interface, T = F/8 threads per pulse, half the registers per thread (4 waves per SIMD).  Stage 4 of
+// the transform runs across lanes (fwd_s3_lanes / inv_s4_lanes), so a transform has two LDS exchanges
+// and two barriers.  Buffer schedule (A = E1 layout, B = E2 layout, every transform the same):
+//   forward  s1 -> A | barrier | s2: A -> B | barrier | s3 + s4: B -> registers
+//   inverse  s4 + s3: registers -> A | barrier | s2: A -> B | barrier | s1: B -> registers
+// A buffer is rewritten only after a barrier that follows its last read: A's readers (s2 loads) finish
+// before the barrier between s2 and s3, B's readers (s3 loads) before the next transform's first
+// barrier, and the inverse's last loads (from B) precede the next pulse's first barrier.
 template <int R4, class In>
 __global__ __launch_bounds__(64 * R4, RANGE8_WAVES_PER_SIMD) void range8_kernel(RangeArgs a, In in)
 {
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(64 * R4, RANGE8_WAVES_PER_SIMD) void range8_kernel(
   const int t = threadIdx.x;
   cf tw1[7], tw2[7], tw3[7];
   W::load_twiddles(t, a.tw, tw1, tw2, tw3);
+  const typename W::LaneConst lc = W::lane_constants(t, a.tw);
 
   const RangePlan p = a.plan;
   for (int pulse = blockIdx.x; pulse < a.nPulses; pulse += gridDim.x) {
@@ -182,20 +185,14 @@ __global__ __launch_bounds__(64 * R4, RANGE8_WAVES_PER_SIMD) void range8_kernel(
       W::fwd_s2_load(t, v, A);
       W::fwd_s2_store(t, v, tw2, B);
       __syncthreads();
-      W::fwd_s3_load(t, v, B);
-      W::fwd_s3_store(t, v, tw3, A);
-      __syncthreads();
-      W::fwd_s4(t, v, A); // v = X spectrum
+      W::fwd_s3_lanes(t, v, tw3, lc, B); // v = X spectrum
 
-      W::fwd_s1(t, yv, tw1, B);
+      W::fwd_s1(t, yv, tw1, A);
       __syncthreads();
-      W::fwd_s2_load(t, yv, B);
-      W::fwd_s2_store(t, yv, tw2, A);
+      W::fwd_s2_load(t, yv, A);
+      W::fwd_s2_store(t, yv, tw2, B);
       __syncthreads();
-      W::fwd_s3_load(t, yv, A);
-      W::fwd_s3_store(t, yv, tw3, B);
-      __syncthreads();
-      W::fwd_s4(t, yv, B); // yv = Y spectrum
+      W::fwd_s3_lanes(t, yv, tw3, lc, B); // yv = Y spectrum
       if (s == 0) {
 #pragma unroll
         for (int e = 0; e < 8; e++) acc[e] = cmulc(yv[e], v[e]);
@@ -204,17 +201,14 @@ __global__ __launch_bounds__(64 * R4, RANGE8_WAVES_PER_SIMD) void range8_kernel(
         for (int e = 0; e < 8; e++) acc[e] = cmacc(acc[e], yv[e], v[e]);
       }
     }
-    W::inv_s4(t, acc, A);
+    W::inv_s4_lanes(t, acc, tw3, lc);
+    W::inv_s3_store(t, acc, A);
     __syncthreads();
-    W::inv_s3_load(t, acc, tw3, A);
-    W::inv_s3_store(t, acc, B);
+    W::inv_s2_load(t, acc, tw2, A);
+    W::inv_s2_store(t, acc, B);
     __syncthreads();
-    W::inv_s2_load(t, acc, tw2, B);
-    W::inv_s2_store(t, acc, A);
-    __syncthreads();
-    W::inv_s1(t, acc, tw1, A);
+    W::inv_s1(t, acc, tw1, B);
     store_lags_g<T, 8>(a.out, p, cpi, i, t, acc);
-    __syncthreads(); // A is rewritten by the next pulse's first stage
   }
 }
 

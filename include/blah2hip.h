@@ -132,7 +132,7 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 #define BLAH2HIP_DOP_COLUMN 4  /* nD <= 2049: one column per workgroup (small launches) */
 #define BLAH2HIP_DOP_DIRECT 5  /* any nD: direct DFT */
 #define BLAH2HIP_RANGE_E16 1   /* 16 points per thread (F = 2048, 4096) */
-#define BLAH2HIP_RANGE_E8 2    /* 8 points per thread (F = 1024) */
+#define BLAH2HIP_RANGE_E8 2    /* 8 points per thread, last stage across lanes (F = 1024) */
 /* BLAH2HIP_ERR_UNSUPPORTED when the kernel does not cover the handle's Doppler length */
 int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value);
 #define BLAH2HIP_INFO_LAST_DOPPLER_KERNEL 1 /* BLAH2HIP_DOP_* the last process call launched (0 = none yet) */

@@ -127,3 +127,24 @@ def test_auto_rule_small_launch_keeps_the_column_kernel(b2):
     amb = run_batch(b2, CFG2, 1, "auto", seeds=(99,), expect="column")
     with pytest.raises(b2.Blah2HipError):  # nD = 513 is outside the multi-wave tile kernel's plan (M = 1024)
         amb.set_doppler_kernel("tilem")
+
+
+@pytest.mark.parametrize("geom,fft_len,kernel", [(CFG2, 2048, "e16"), ((-24, 2023, -64, 64, 1_260_000, 1_260_000), 4096, "e16"),
+                                                  ((-10, 100, -100, 100, 1_000_000, 100_000), 1024, "e8")])
+def test_range_kernel_of_every_transform_length_batched(b2, geom, fft_len, kernel):
+    """F = 1024 -> the 8-point-per-thread kernel whose last transform stage runs across lanes (DPP),
+    F = 2048 / 4096 -> the 16-point one; two distinct CPIs per launch."""
+    from blah2_amd import _lib
+    amb = run_batch(b2, geom, 2, "auto", seeds=(5, 6), expect=_expected_doppler(b2, geom),
+                    targets=((37, -13.0, 0.05),), cell_tol=2e-4)
+    assert amb.dims.fft_len == fft_len
+    assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == (_lib.RANGE_E8 if kernel == "e8" else _lib.RANGE_E16)
+
+
+def _expected_doppler(b2, geom):
+    # what the launch-size rule picks for two CPIs of this geometry (asserted inside run_batch)
+    dmin, dmax, fmin, fmax, fs, n = geom
+    d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
+    if d.n_doppler_bins <= 513:
+        return "tile8" if 2 * -(-d.n_delay_bins // 8) >= 128 else "column"
+    return "tilem" if 2 * -(-d.n_delay_bins // 8) >= 128 else "column"
