@@ -49,9 +49,10 @@ namespace blah2 {
 // v_pk_mul_f32, v_pk_fma_f32: two lanes' worth of fp32 per instruction, VOP3P): a complex add is one
 // instruction, a complex multiply two, and the swaps and sign flips of x(-i), conj() and
 // multiply-accumulate are the instructions' op_sel / neg_lo / neg_hi operand modifiers, i.e. free.
-// A 2048-point transform drops from 545 to ~290 VALU instructions per thread; a packed instruction
-// issues in 4 cycles against ~3 for a scalar one (MI355X: scalar v_fma_f32 reaches 103 TF, the
-// 157 TF peak is v_pk_fma_f32), and the kernels are bound by that issue rate.
+// A 2048-point transform drops from 545 to ~290 VALU instructions per thread and the range kernel from
+// 230 to 190 VGPRs.  It is NOT faster per flop: a packed instruction occupies a wave for twice as long
+// as a scalar one (measured: the range kernel's time is unchanged, the register-starved correlation
+// kernel gains 16 %), so what it buys is registers and instruction-cache footprint.
 // The instructions are written as inline asm: left to the compiler (SLP vectoriser, or a float2
 // vector type -- both tried in round 1) the packed forms came with a v_mov per repacked operand and
 // register-tuple pressure that cost more than they saved; the library is still built with
