@@ -478,6 +478,7 @@ def main(argv=None):
             res["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)
     if dist is not None:
+        dist.barrier()  # rank 0 has been checking parity: every rank leaves the group together
         dist.destroy_process_group()
     if parity is not None and not parity["pass"]:
         raise SystemExit("bench.py: parity gate violated: " + json.dumps(parity))
