@@ -1,7 +1,7 @@
 // HIP kernels of the blah2 cross-ambiguity engine (gfx950 / MI355X only).
 //
 //   range_kernel / range8_kernel   Hot loop A  Ambiguity.cpp:106-149  (segmented on-chip FFT correlation;
-//                                  16 / 8 points per thread)
+//                                  16 points per thread for F = 2048 / 4096, 8 for F = 1024)
 //   doppler_tile_kernel            Hot loop B  Ambiguity.cpp:152-169  nD <= 513, batched launches
 //   doppler_tilem_kernel                                              513 < nD <= 2049
 //   doppler_fft_kernel                                                nD <= 2049, one column per workgroup
@@ -785,12 +785,6 @@ __global__ void metrics_kernel(const double *partSum, const float *partMax, int 
 }
 
 // --------------------------------------------------------------------------
-// CfarDetector1D::process (CfarDetector1D.cpp:23-100): cell-averaging CFAR
-// along delay for each Doppler row with |doppler| >= minDoppler.  One
-// workgroup per row; |z|^2 of the row is staged in LDS as fp64 and the window
-// sum runs in the reference's index order (leading cells need k > 0, trailing
-// k >= 0, :61,:68).  alpha[n] = n*(pfa^(-1/n)-1) is tabulated on the host with
-// the same libm pow the reference calls (:76).  Hits are appended through a
 // Map::to_json's cell values (Map.cpp:115-185): db[i] = 10*log10|z| - noisePower as fp32,
 // half the bytes of the complex map for a front-end that only plots.
 __global__ __launch_bounds__(256) void db_map_kernel(const cf *map, const double *metrics, float *db, uint32_t cells)
@@ -802,6 +796,13 @@ __global__ __launch_bounds__(256) void db_map_kernel(const cf *map, const double
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += gridDim.x * blockDim.x) o[i] = db_of(z[i]) - noise;
 }
 
+// --------------------------------------------------------------------------
+// CfarDetector1D::process (CfarDetector1D.cpp:23-100): cell-averaging CFAR
+// along delay for each Doppler row with |doppler| >= minDoppler.  One
+// workgroup per row; |z|^2 of the row is staged in LDS as fp64 and the window
+// sum runs in the reference's index order (leading cells need k > 0, trailing
+// k >= 0, :61,:68).  alpha[n] = n*(pfa^(-1/n)-1) is tabulated on the host with
+// the same libm pow the reference calls (:76).  Hits are appended through a
 // per-CPI atomic counter; the host API sorts them into row-major order.
 struct CfarArgs {
   const cf *map;         // [nCpi][nD][nDelay]
