@@ -197,7 +197,8 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=0,
                     help="CPIs per step (per GPU); default 128 for the 2 MS/s configs (4 GB of IQ per step: a pulse is "
                          "the scheduling unit of the range kernel and 128 x 513 pulses leave a 1.5 %% tail on 1024 "
-                         "resident workgroups, 32 x 513 leave 6 %%), 8 for cfg3 (64 with --chain full)")
+                         "resident workgroups, 32 x 513 leave 6 %%); 32 for cfg3 (64 with --chain full), 8 for cfg5 -- "
+                         "measured: cfg3 93.9 / 88.8 / 84.7 us/CPI at 8 / 16 / 32, cfg5 142.8 / 138.4 / 138.8 at 4 / 8 / 16")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--fmt", default="c32", choices=["c32", "i16", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -238,7 +239,7 @@ def main(argv=None):
 
     cfg, cfg_desc = CONFIGS[a.config]
     dmin, dmax, fmin, fmax, fs, n = cfg
-    B = a.batch if a.batch > 0 else ({"cfg3": 64 if a.chain == "full" else 8, "cfg5": 4, "small": 1024}.get(a.config, 128))
+    B = a.batch if a.batch > 0 else ({"cfg3": 64 if a.chain == "full" else 32, "cfg5": 8, "small": 1024}.get(a.config, 128))
     NS = max(1, a.streams) if a.chain == "amb" else 1
     ambs = [blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B, n_doppler_bins=a.n_doppler)
             for _ in range(NS)]
