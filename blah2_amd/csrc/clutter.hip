@@ -34,6 +34,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -155,6 +156,143 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_ker
     __syncthreads();
   }
   // two explicit calls (a runtime-selected register array would be demoted to scratch)
+  auto finish = [&](cf *acc, int mode) {
+    W::inv_s1(t, acc, tw3, P);
+    __syncthreads();
+    W::inv_s2(t, acc, P, Q);
+    __syncthreads();
+    W::inv_s3(t, acc, tw1, Q);
+    cf *dst = a.partial + (((size_t)cpi * 2 + mode) * a.nJobs + blockIdx.x) * a.nBins;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const int k = t + T * c;
+      if (k < a.nBins) dst[k] = cmake(acc[c].x * a.scale, acc[c].y * a.scale);
+    }
+    __syncthreads();
+  };
+  finish(accR, 0);
+  finish(accB, 1);
+}
+
+// Half-window form of the same correlations, for filters with many taps (nBins - 1 <= F/2): cut the
+// CPI into segments of exactly L = F/2 samples; with X_g, Y_g the transforms of the zero-padded
+// segments, the window [segment g, segment g+1] has the spectrum X_g + (-1)^m X_{g+1} (a shift by F/2
+// samples is the sign of the frequency index), so -- grouping every pair (n, n+k) by the segment that
+// holds its LATER sample --
+//     r = sum_g X_g conj(X_g + (-1)^m X_{g-1}),      b = sum_g Y_g conj(X_g + (-1)^m X_{g-1}):
+// TWO transforms per L samples instead of three per F - nBins + 1, every sample read once, and only
+// the previous segment's X to keep (the register budget of the windowed form).  A workgroup walks a
+// contiguous run of segments (one extra transform for the segment in front of its run).  The
+// sequence is treated as zero-extended to a whole number of segments; what that leaves out of the
+// CIRCULAR correlations over N -- the pairs whose later sample wraps to the head of the CPI -- is one
+// more product, tail (last nBins-1 samples of xs) against head (first nBins-1 of xs / y) shifted by
+// tau = nBins - 1, i.e. times W_F^(tau m), done by the last workgroup.  Mathematically identical.
+struct CorrHalfArgs {
+  const cf *x, *y;
+  int64_t cpiStride;
+  uint32_t N;
+  XsMap xs;
+  int32_t nBins, nSeg, per, nJobs; // nSeg = ceil(N / (F/2)), per = segments per workgroup
+  const cf *tw;
+  cf *partial; // [nCpi][2][nJobs][nBins]
+  float scale;
+};
+
+template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_half_kernel(CorrHalfArgs a)
+{
+  using W = WgFft<R3>;
+  constexpr int T = W::T, L = W::F / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf *P = reinterpret_cast<cf *>(smem);
+  cf *Q = P + W::A_ELEMS;
+  const int t = threadIdx.x;
+  const int cpi = blockIdx.y;
+  const cf *X = a.x + (int64_t)cpi * a.cpiStride;
+  const cf *Y = a.y + (int64_t)cpi * a.cpiStride;
+  cf tw1[15], tw3[16];
+  W::load_twiddles(t, a.tw, tw1, tw3);
+  // (-1)^m for this thread's spectrum registers: m = q + 16 r + 256 s with q = (t + T j) / 16 and T a
+  // multiple of 32, so the parity of m is that of t / 16
+  const float sgn = ((t >> 4) & 1) ? -1.f : 1.f;
+
+  auto fwd = [&](cf *v) {
+    W::fwd_s1(t, v, tw1, P);
+    __syncthreads();
+    W::fwd_s2(t, v, P, Q);
+    __syncthreads();
+    W::fwd_s3(t, v, tw3, Q);
+    __syncthreads();
+  };
+  // first L samples of a zero-padded window starting at sample n0 of xs / of y (zero beyond N)
+  auto load_xs = [&](uint32_t n0, uint32_t len, cf *v) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t m = (uint32_t)(t + T * k);
+      const bool in = m < len;
+      const cf s = X[xs_index(in ? n0 + m : 0u, a.xs)];
+      v[k] = in ? s : cmake(0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 8; k < 16; k++) v[k] = cmake(0.f, 0.f);
+  };
+  auto load_y = [&](uint32_t n0, uint32_t len, cf *v) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t m = (uint32_t)(t + T * k);
+      const bool in = m < len;
+      const cf s = Y[in ? n0 + m : 0u];
+      v[k] = in ? s : cmake(0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 8; k < 16; k++) v[k] = cmake(0.f, 0.f);
+  };
+  auto seg_len = [&](int g) { return min((uint32_t)L, a.N - (uint32_t)g * (uint32_t)L); };
+
+  cf accR[16], accB[16], prevX[16];
+#pragma unroll
+  for (int e = 0; e < 16; e++) { accR[e] = cmake(0.f, 0.f); accB[e] = cmake(0.f, 0.f); prevX[e] = cmake(0.f, 0.f); }
+  const int g0 = blockIdx.x * a.per, g1 = min(g0 + a.per, a.nSeg);
+  if (g0 > 0 && g0 < g1) { // the segment in front of the run (a full one)
+    load_xs((uint32_t)(g0 - 1) * (uint32_t)L, (uint32_t)L, prevX);
+    fwd(prevX);
+  }
+  for (int g = g0; g < g1; g++) {
+    const uint32_t n0 = (uint32_t)g * (uint32_t)L, len = seg_len(g);
+    cf v[16], yv[16];
+    load_xs(n0, len, v);
+    load_y(n0, len, yv);
+    fwd(v);
+    fwd(yv);
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const cf z = cmake(v[e].x + sgn * prevX[e].x, v[e].y + sgn * prevX[e].y); // X_g + (-1)^m X_{g-1}
+      accR[e] = cmacc(accR[e], v[e], z);
+      accB[e] = cmacc(accB[e], yv[e], z);
+      prevX[e] = v[e];
+    }
+  }
+  if (blockIdx.x == (unsigned)a.nJobs - 1 && a.nBins > 1) { // the wrap-around pairs
+    const uint32_t tau = (uint32_t)a.nBins - 1;
+    cf v[16], yv[16];
+    load_xs(a.N - tau, tau, prevX); // tail of xs
+    load_xs(0u, tau, v);            // head of xs
+    load_y(0u, tau, yv);            // head of y
+    fwd(prevX);
+    fwd(v);
+    fwd(yv);
+#pragma unroll
+    for (int j = 0; j < W::NP; j++)
+#pragma unroll
+      for (int sidx = 0; sidx < R3; sidx++) {
+        const int e = j * R3 + sidx;
+        const int p16 = t + T * j;                         // 16 q + r
+        const int m = (p16 >> 4) + 16 * (p16 & 15) + 256 * sidx;
+        const cf ph = a.tw[((uint32_t)m * tau) & (W::F - 1)]; // W_F^(tau m): the head sits tau samples behind the tail
+        const cf z = cmulc(prevX[e], ph);                  // conj(phase) * X_tail
+        accR[e] = cmacc(accR[e], v[e], z);
+        accB[e] = cmacc(accB[e], yv[e], z);
+      }
+  }
   auto finish = [&](cf *acc, int mode) {
     W::inv_s1(t, acc, tw3, P);
     __syncthreads();
@@ -468,6 +606,7 @@ struct blah2hip_clutter_s {
   cf *d_stage = nullptr; // host entry points: x, y, y_out planes
   size_t stageElems = 0;
   int solveK = 0;            // indices per thread of the Toeplitz solve (0 = by size)
+  bool corrHalf = false;     // half-window correlation (2 transforms per F/2 samples) instead of the windowed one
   int32_t *lastOk = nullptr; // where the last process call wrote its flags
   KernelTimer<BLAH2HIP_CK_COUNT> timer;
 };
@@ -499,12 +638,22 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   auto up8 = [](int v) { return std::max(8, (v + 7) & ~7); };
   const int nJobs = std::min(h->nJobs, up8((2 * slots + (int)nCpi - 1) / (int)nCpi));
   const int firGrid = std::min(h->firGrid, up8((2 * slots + (int)nCpi - 1) / (int)nCpi));
-  CorrArgs ca;
-  ca.x = x; ca.y = y; ca.cpiStride = stride; ca.N = h->N; ca.xs = xs;
-  ca.nBins = h->nBins; ca.segLen = h->segLen; ca.nSeg = h->nSeg; ca.nJobs = nJobs;
-  ca.tw = h->d_tw; ca.partial = h->d_partial; ca.scale = 1.0f / (float)h->F;
   CHIP(h->timer.tic(BLAH2HIP_CK_CORR, st));
-  hipLaunchKernelGGL(clutter_corr_kernel<R3>, dim3(nJobs, nCpi), dim3(W::T), lds, st, ca);
+  if (h->corrHalf) {
+    CHIP(blah2hip_ensure_lds_((const void *)clutter_corr_half_kernel<R3>, (int)lds));
+    CorrHalfArgs ha;
+    ha.x = x; ha.y = y; ha.cpiStride = stride; ha.N = h->N; ha.xs = xs;
+    ha.nBins = h->nBins; ha.nSeg = (int)((h->N + (uint32_t)(h->F / 2) - 1) / (uint32_t)(h->F / 2));
+    ha.per = (ha.nSeg + nJobs - 1) / nJobs; ha.nJobs = nJobs;
+    ha.tw = h->d_tw; ha.partial = h->d_partial; ha.scale = 1.0f / (float)h->F;
+    hipLaunchKernelGGL(clutter_corr_half_kernel<R3>, dim3(nJobs, nCpi), dim3(W::T), lds, st, ha);
+  } else {
+    CorrArgs ca;
+    ca.x = x; ca.y = y; ca.cpiStride = stride; ca.N = h->N; ca.xs = xs;
+    ca.nBins = h->nBins; ca.segLen = h->segLen; ca.nSeg = h->nSeg; ca.nJobs = nJobs;
+    ca.tw = h->d_tw; ca.partial = h->d_partial; ca.scale = 1.0f / (float)h->F;
+    hipLaunchKernelGGL(clutter_corr_kernel<R3>, dim3(nJobs, nCpi), dim3(W::T), lds, st, ca);
+  }
   CHIP(hipGetLastError());
   CHIP(h->timer.toc(BLAH2HIP_CK_CORR, st));
 
@@ -585,6 +734,13 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
   h->r3 = bestR3; h->F = 256 * bestR3;
   h->segLen = h->F - nBins + 1;
   h->nSeg = (int)((n_samples + (uint32_t)h->segLen - 1) / (uint32_t)h->segLen);
+  // correlations: windowed form 3 transforms per segLen samples, half-window form 2 per F/2
+  // (needs nBins - 1 <= F/2 and at least nBins samples)
+  h->corrHalf = (nBins - 1 <= h->F / 2) && ((uint32_t)nBins <= n_samples) && (4.0 / h->F < 3.0 / h->segLen);
+  if (const char *e = std::getenv("BLAH2HIP_CLUTTER_CORR")) { // planner override for the tests: "half" / "window"
+    if (!std::strcmp(e, "half") && nBins - 1 <= h->F / 2 && (uint32_t)nBins <= n_samples) h->corrHalf = true;
+    if (!std::strcmp(e, "window")) h->corrHalf = false;
+  }
   hipDeviceProp_t prop;
   CHIP(hipGetDeviceProperties(&prop, device));
   h->numCU = prop.multiProcessorCount;

@@ -58,3 +58,37 @@ def test_clutter_failure_contract(b2):
     y = (np.arange(n) % 7 + 1j).astype(np.complex128)
     ok, yf = b2.WienerHopf(-3, 20, n).process(np.zeros(n, dtype=np.complex128), y)
     assert not ok and np.array_equal(yf, y)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_clutter_golden_half_window_correlation(b2, name, monkeypatch):
+    """The half-window form of the correlations (2 transforms per F/2 samples, chosen by the planner for
+    filters with many taps) forced on the small fixtures, where a workgroup's run is a few segments and
+    the wrap-around product is a large share of the lags."""
+    monkeypatch.setenv("BLAH2HIP_CLUTTER_CORR", "half")
+    g = load_golden(name)
+    n = int(g["params"][1])
+    dmin, dmax = (int(v) for v in g["clutter_params"])
+    ok, yf = b2.WienerHopf(dmin, dmax, n).process(g["x"], g["y"])
+    assert ok == bool(g["clutter_ok"])
+    assert np.max(np.abs(yf - g["clutter_y"])) / np.max(np.abs(g["clutter_y"])) <= Y_TOL
+
+
+@pytest.mark.parametrize("mode,n,taps", [("auto", 300_000, 700), ("window", 300_000, 700), ("half", 300_000, 700),
+                                         ("window", 1_000_000, 2047), ("half", 50_000, 300), ("half", 4_099, 1025)])
+def test_clutter_correlation_forms_agree_with_the_oracle(b2, mode, n, taps, monkeypatch):
+    """r, b and the filtered channel from both correlation forms against the fp64 oracle: 700 taps (the
+    planner itself picks the half-window form there), 2047 taps on the windowed form (cfg 3 runs the
+    other one), a short CPI, and a CPI of two segments and three samples with the widest filter F = 2048 takes."""
+    if mode != "auto":
+        monkeypatch.setenv("BLAH2HIP_CLUTTER_CORR", mode)
+    x, y = O.synth_iq(n, seed=n % 97 + taps, fs=1_000_000, targets=((20, 40.0, 0.05),))
+    dmin, dmax = -7, taps - 7
+    ok_ref, y_ref, w_ref, r_ref, b_ref = O.wiener_hopf(x, y, dmin, dmax, return_filter=True)
+    wh = b2.WienerHopf(dmin, dmax, n)
+    ok, yf = wh.process(x.astype(np.complex64), y.astype(np.complex64))
+    assert ok and ok_ref
+    _, w, r, b = wh.read_last(0)
+    assert np.max(np.abs(r - r_ref)) / np.abs(r_ref[0]) <= 1e-5
+    assert np.max(np.abs(b - b_ref)) / np.max(np.abs(b_ref)) <= 1e-5
+    assert np.max(np.abs(yf.astype(np.complex128) - y_ref)) / np.max(np.abs(y_ref)) <= Y_TOL
