@@ -210,6 +210,8 @@ def main(argv=None):
                     help="explicit number of Doppler bins (extension; 0 = the reference constructor's rule, which gives "
                          "513 at the headline configuration; 512 gives the literal BASELINE wording)")
     ap.add_argument("--doppler-kernel", default="auto", help="force a Doppler kernel (auto, tile8, tile16, tilem, column, direct)")
+    ap.add_argument("--range-kernel", default="auto", choices=["auto", "wave"],
+                    help="range kernel: by transform length, or the one-wave kernel (F = 2048 only)")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent CPI streams per GPU (engine handles on their own HIP streams); successive "
                          "steps alternate between them so one batch's Doppler stage overlaps the next batch's range stage")
@@ -245,6 +247,8 @@ def main(argv=None):
             for _ in range(NS)]
     for h_ in ambs:
         h_.set_doppler_kernel(a.doppler_kernel)
+        if a.range_kernel == "wave":
+            h_.set_range_kernel(blah2_amd._lib.RANGE_WAVE)
     amb = ambs[0]
     nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
     cells = nD * nC

@@ -98,6 +98,7 @@ struct blah2hip_amb_s {
   int dopForce = BLAH2HIP_DOP_AUTO; // BLAH2HIP_OPT_DOPPLER_KERNEL
   int lastDoppler = 0;              // BLAH2HIP_INFO_LAST_DOPPLER_KERNEL
   int lastRange = 0;                // BLAH2HIP_INFO_LAST_RANGE_KERNEL
+  int rangeKernel = 0;              // BLAH2HIP_OPT_RANGE_KERNEL (0 = by transform length)
   struct AlphaTable { double pfa; size_t n; double *d; };
   std::vector<AlphaTable> alphaTables; // CFAR threshold factors, one per (pfa, size) seen
   cf *d_dtw = nullptr;              // exp(-2 pi i k/M)
@@ -279,6 +280,37 @@ template <int R4, class In> int launch_range8_t(blah2hip_amb_s *h, const RangeAr
   return BLAH2HIP_OK;
 }
 
+template <class In> int launch_rangew_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
+{
+  const size_t lds = (size_t)(WaveFft::TW_ELEMS + RANGEW_WAVES * WaveFft::X_ELEMS) * sizeof(cf);
+  auto kern = rangew_kernel<In>;
+  LDSCFG(kern, lds);
+  const int grid = std::min<int>((a.nPulses + RANGEW_WAVES - 1) / RANGEW_WAVES, h->rangeGridCap);
+#ifdef RANGEW_TRACE
+  static uint64_t *dbg = nullptr;
+  static int calls = 0;
+  if (!dbg) HIPCHK(hipMalloc(&dbg, 64));
+  HIPCHK(hipMemsetAsync(dbg, 0, 64, st));
+  RangeArgs a2 = a;
+  a2.dbg = dbg;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RANGEW_WAVES), lds, st, a2, in);
+  if (++calls == 8) {
+    uint64_t hcnt[6];
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(hcnt, dbg, 48, hipMemcpyDeviceToHost));
+    double tot = 0;
+    for (int k = 0; k < 6; k++) tot += (double)hcnt[k];
+    fprintf(stderr, "[rangew trace] grid %d pulses %d: other %.3f load %.3f X %.3f Y %.3f inv %.3f store %.3f of %.0f ticks/wave\n", grid, a.nPulses,
+            hcnt[0] / tot, hcnt[1] / tot, hcnt[2] / tot, hcnt[3] / tot, hcnt[4] / tot, hcnt[5] / tot, tot / grid / RANGEW_WAVES);
+  }
+#else
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RANGEW_WAVES), lds, st, a, in);
+#endif
+  HIPCHK(hipGetLastError());
+  h->lastRange = BLAH2HIP_RANGE_WAVE;
+  return BLAH2HIP_OK;
+}
+
 // F = 1024: 8 points per thread (one-wave transforms: 10.5 vs 14.3 us/CPI at cfg 2 with 16 points per
 // thread); F = 2048 / 4096: 16 points per thread (10.0 vs 10.3 us/CPI; equal at 4096).  Measured, round 1.
 // F = 1024: 8 points per thread with stage 4 across lanes (4 waves per SIMD); F = 2048 / 4096: 16 points
@@ -289,6 +321,7 @@ template <int R4, class In> int launch_range8_t(blah2hip_amb_s *h, const RangeAr
 // (radix 8-8-8-4 twiddles + the lane butterflies) and the kernel follows that count, not its occupancy.
 template <class In> int launch_range(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
 {
+  if (h->rangeKernel == BLAH2HIP_RANGE_WAVE) return launch_rangew_t(h, a, in, st);
   switch (h->r3) {
   case 4: return launch_range8_t<2>(h, a, in, st);
   case 8: return launch_range_t<8>(h, a, in, st);
@@ -335,7 +368,11 @@ void set_range_residency(blah2hip_amb_s *h)
   const bool e8 = h->r3 == 4;
   size_t lds;
   int waves, wavesPerCU;
-  if (e8) {
+  if (h->rangeKernel == BLAH2HIP_RANGE_WAVE) {
+    lds = (size_t)(WaveFft::TW_ELEMS + RANGEW_WAVES * WaveFft::X_ELEMS) * sizeof(cf);
+    waves = RANGEW_WAVES;
+    wavesPerCU = 4 * RANGEW_WAVES_PER_SIMD;
+  } else if (e8) {
     lds = (size_t)2 * WgFft8<2>::BUF_ELEMS * sizeof(cf);
     waves = h->r3 / 2;  // F/8 threads
     wavesPerCU = 4 * RANGE8_WAVES_PER_SIMD; // the kernel's register cap: 4 waves per SIMD at <= 128 VGPRs
@@ -593,6 +630,13 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
   case BLAH2HIP_OPT_RANGE_GRID:
     if (value < 0 || value > (1 << 20)) return fail(BLAH2HIP_ERR_INVALID, "range grid outside [0, 2^20]");
     h->rangeGridCap = value ? (int)value : h->rangeGridDefault;
+    return BLAH2HIP_OK;
+  case BLAH2HIP_OPT_RANGE_KERNEL:
+    if (value != 0 && value != BLAH2HIP_RANGE_WAVE) return fail(BLAH2HIP_ERR_INVALID, "range kernel: 0 (by transform length) or BLAH2HIP_RANGE_WAVE");
+    if (value == BLAH2HIP_RANGE_WAVE && h->r3 != 8)
+      return fail(BLAH2HIP_ERR_UNSUPPORTED, "the one-wave range kernel is a 2048-point transform");
+    h->rangeKernel = (int)value;
+    set_range_residency(h);
     return BLAH2HIP_OK;
   default: return fail(BLAH2HIP_ERR_INVALID, "unknown option");
   }

@@ -76,38 +76,51 @@ __device__ __forceinline__ cf csub(cf a, cf b) { b2_pk r; asm("v_pk_add_f32 %0, 
 __device__ __forceinline__ cf cadd_mi(cf a, cf b) { b2_pk r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(B2_V(a)), "v"(B2_V(b))); return B2_C(r); }
 // a + (+i) b = (a.x - b.y, a.y + b.x)
 __device__ __forceinline__ cf cadd_pi(cf a, cf b) { b2_pk r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(B2_V(a)), "v"(B2_V(b))); return B2_C(r); }
+// A complex multiply is a dependent pair (v_pk_mul, v_pk_fma).  Both instructions sit in ONE asm
+// statement: between two asm statements of which the second reads what the first wrote, the
+// compiler's hazard recogniser -- which cannot see what the statements are -- inserts an s_nop (one in
+// six instructions of a transform were such nops); the hardware interlocks plain VALU dependencies
+// itself.  The result is early-clobber because the second instruction still reads both sources.
 // a * b
 __device__ __forceinline__ cf cmul(cf a, cf b)
 {
-  b2_pk t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(B2_V(a)), "v"(B2_V(b)));                                                    // (a.x b.x, a.y b.x)
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(B2_V(a)), "v"(B2_V(b)), "v"(t));          // (-a.y b.y, a.x b.y) + t
+  b2_pk r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"                                              // (a.x b.x, a.y b.x)
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"                // (-a.y b.y, a.x b.y) + that
+      : "=&v"(r) : "v"(B2_V(a)), "v"(B2_V(b)));
   return B2_C(r);
 }
 // a * conj(b)
 __device__ __forceinline__ cf cmulc(cf a, cf b)
 {
-  b2_pk t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(B2_V(a)), "v"(B2_V(b)));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(B2_V(a)), "v"(B2_V(b)), "v"(t));          // (a.y b.y, -a.x b.y) + t
+  b2_pk r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"                // (a.y b.y, -a.x b.y) + that
+      : "=&v"(r) : "v"(B2_V(a)), "v"(B2_V(b)));
   return B2_C(r);
 }
 // acc + a * conj(b)
 __device__ __forceinline__ cf cmacc(cf acc, cf a, cf b)
 {
-  b2_pk t, r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(B2_V(a)), "v"(B2_V(b)), "v"(B2_V(acc)));                              // acc + (a.x b.x, a.y b.x)
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(B2_V(a)), "v"(B2_V(b)), "v"(t));
+  b2_pk r = B2_V(acc);
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]\n\t"                                        // acc + (a.x b.x, a.y b.x)
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+      : "+v"(r) : "v"(B2_V(a)), "v"(B2_V(b)));
   return B2_C(r);
 }
 // a * w / a * conj(w) for a compile-time constant w: the pair lives in SGPRs
 template <int SIGN> __device__ __forceinline__ cf twid_k(cf a, float wx, float wy)
 {
   const b2_pk w = {wx, wy};
-  b2_pk t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(B2_V(a)), "s"(w));
-  if (SIGN < 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(B2_V(a)), "s"(w), "v"(t));
-  else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(B2_V(a)), "s"(w), "v"(t));
+  b2_pk r;
+  if (SIGN < 0)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=&v"(r) : "v"(B2_V(a)), "s"(w));
+  else
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=&v"(r) : "v"(B2_V(a)), "s"(w));
   return B2_C(r);
 }
 // a + (SIGN i) b   (SIGN < 0: the forward transform's -i)
@@ -138,6 +151,60 @@ template <int SIGN> B2_HD cf mul_i(cf a)
 }
 // a * w for SIGN < 0, a * conj(w) for SIGN > 0 (w is always the forward root)
 template <int SIGN> B2_HD cf twid(cf a, cf w) { return SIGN < 0 ? cmul(a, w) : cmulc(a, w); }
+
+// W_32^j = exp(-2 pi i j / 32): (cos, -sin) = (w32_c(j), w32_s(j))
+B2_HD constexpr float w32_c(int j)
+{
+  constexpr float c[9] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                          0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
+                          0.19509032201612826785f, 0.0f};
+  j &= 31;
+  return j <= 8 ? c[j] : j <= 16 ? -c[16 - j] : j <= 24 ? -c[j - 16] : c[32 - j];
+}
+B2_HD constexpr float w32_s(int j) { return w32_c(j + 8); } // -sin(2 pi j / 32) = cos(2 pi (j + 8) / 32)
+
+// a * W_32^J (SIGN < 0) or a * conj(W_32^J) (SIGN > 0) for a compile-time J: the constant twiddles of
+// the 8-, 16- and 32-point kernels.  Every such root is u * (c_k + i sigma s_k) with u in {1, i, -1, -i},
+// sigma = +-1 and k in [0, 4], (c_k, s_k) = (cos, sin)(2 pi k / 32): the device form keeps ONE scalar
+// register pair (c_k, s_k) per k and expresses u, sigma and the conjugation in the packed instructions'
+// operand-select and negate modifiers -- five constant pairs for all transforms instead of one pair per
+// distinct root (which overflowed the scalar registers of the 32-point kernel into v_readlane spills).
+#if defined(B2_PACKED_COMPLEX)
+// t = (a.x, a.y) * (SX w[CX]);  r = (-a.y, a.x) * (SY w[CY]) + t, with NX / NY = 1 for negative SX / SY
+#define B2_TWK(CX, NX, CY, NLO, NHI)                                                                              \
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0," #CX "] op_sel_hi:[1," #CX "] neg_lo:[0," #NX "] neg_hi:[0," #NX "]\n\t" \
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1," #CY ",0] op_sel_hi:[0," #CY ",1] neg_lo:[0," #NLO ",0] neg_hi:[0," #NHI ",0]" \
+      : "=&v"(r) : "v"(B2_V(a)), "s"(w))
+template <int SIGN, int J> __device__ __forceinline__ cf twid32(cf a)
+{
+  constexpr int j = J & 31, quad = j >> 3, rem = j & 7;
+  constexpr int k = rem <= 4 ? rem : 8 - rem;           // W^rem = W^k or (-i) conj(W^k)
+  constexpr int e = (quad + (rem > 4 ? 1 : 0)) & 3;     // forward root = (-i)^e * (c_k - i s_k) or (-i)^e * (c_k + i s_k)
+  constexpr int sig_f = rem > 4 ? +1 : -1;              // sign of the imaginary part of the base, forward
+  // conjugation (SIGN > 0): u -> conj(u), sigma -> -sigma
+  constexpr int sigma = SIGN < 0 ? sig_f : -sig_f;
+  constexpr int u = SIGN < 0 ? (4 - e) & 3 : e;         // u = i^u:  (-i)^e = i^(4-e); conj -> i^e
+  // m = i^u (c + i sigma s):  u=0: (c, sigma s)  u=1: (-sigma s, c)  u=2: (-c, -sigma s)  u=3: (sigma s, -c)
+  constexpr int cx = (u & 1), cy = 1 - cx;
+  constexpr int sx = u == 0 ? +1 : u == 1 ? -sigma : u == 2 ? -1 : sigma;
+  constexpr int sy = u == 0 ? sigma : u == 1 ? +1 : u == 2 ? -sigma : -1;
+  const b2_pk w = {w32_c(k), -w32_s(k)}; // (cos, sin), both >= 0
+  b2_pk r;
+  if constexpr (j == 0) return a;
+  else if constexpr (cx == 0 && sx > 0 && sy > 0) B2_TWK(0, 0, 1, 1, 0);
+  else if constexpr (cx == 0 && sx > 0 && sy < 0) B2_TWK(0, 0, 1, 0, 1);
+  else if constexpr (cx == 0 && sx < 0 && sy > 0) B2_TWK(0, 1, 1, 1, 0);
+  else if constexpr (cx == 0 && sx < 0 && sy < 0) B2_TWK(0, 1, 1, 0, 1);
+  else if constexpr (cx == 1 && sx > 0 && sy > 0) B2_TWK(1, 0, 0, 1, 0);
+  else if constexpr (cx == 1 && sx > 0 && sy < 0) B2_TWK(1, 0, 0, 0, 1);
+  else if constexpr (cx == 1 && sx < 0 && sy > 0) B2_TWK(1, 1, 0, 1, 0);
+  else B2_TWK(1, 1, 0, 0, 1);
+  return B2_C(r);
+}
+#undef B2_TWK
+#else
+template <int SIGN, int J> B2_HD cf twid32(cf a) { return twid_k<SIGN>(a, w32_c(J), w32_s(J)); }
+#endif
 
 // 4-point DFT, in place, natural order out.  SIGN = -1 forward, +1 inverse.
 template <int SIGN> B2_HD void dft4(cf &a0, cf &a1, cf &a2, cf &a3)
@@ -171,8 +238,8 @@ template <int SIGN> B2_HD void dft8(cf *v)
   dft4<SIGN>(v[0], v[2], v[4], v[6]); // n0 = 0 -> k1 at v[0],v[2],v[4],v[6]
   dft4<SIGN>(v[1], v[3], v[5], v[7]); // n0 = 1
   // twiddle W8^(k1) on the odd set; W8^2 = (SIGN i) is folded into the butterfly
-  const cf b1 = twid_k<SIGN>(v[3], B2_SQH, -B2_SQH);
-  const cf b3 = twid_k<SIGN>(v[7], -B2_SQH, -B2_SQH);
+  const cf b1 = twid32<SIGN, 4>(v[3]);
+  const cf b3 = twid32<SIGN, 12>(v[7]);
   const cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o2 = v[5];
   v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
   v[1] = cadd(e1, b1); v[5] = csub(e1, b1);
@@ -189,14 +256,14 @@ template <int SIGN> B2_HD void dft16(cf *v)
   dft4<SIGN>(v[2], v[6], v[10], v[14]);
   dft4<SIGN>(v[3], v[7], v[11], v[15]);
   // now v[n0 + 4*k1]; twiddle by W16^(n0*k1) (W16^4 = (SIGN i) on v[10] is folded into step B)
-  v[1 + 4] = twid_k<SIGN>(v[1 + 4], B2_C16, -B2_S16);   // W16^1
-  v[2 + 4] = twid_k<SIGN>(v[2 + 4], B2_SQH, -B2_SQH);   // W16^2
-  v[3 + 4] = twid_k<SIGN>(v[3 + 4], B2_S16, -B2_C16);   // W16^3
-  v[1 + 8] = twid_k<SIGN>(v[1 + 8], B2_SQH, -B2_SQH);   // W16^2
-  v[3 + 8] = twid_k<SIGN>(v[3 + 8], -B2_SQH, -B2_SQH);  // W16^6
-  v[1 + 12] = twid_k<SIGN>(v[1 + 12], B2_S16, -B2_C16); // W16^3
-  v[2 + 12] = twid_k<SIGN>(v[2 + 12], -B2_SQH, -B2_SQH); // W16^6
-  v[3 + 12] = twid_k<SIGN>(v[3 + 12], -B2_C16, B2_S16); // W16^9
+  v[1 + 4] = twid32<SIGN, 2>(v[1 + 4]);       // W16^1
+  v[2 + 4] = twid32<SIGN, 4>(v[2 + 4]);       // W16^2
+  v[3 + 4] = twid32<SIGN, 6>(v[3 + 4]);       // W16^3
+  v[1 + 8] = twid32<SIGN, 4>(v[1 + 8]);       // W16^2
+  v[3 + 8] = twid32<SIGN, 12>(v[3 + 8]);     // W16^6
+  v[1 + 12] = twid32<SIGN, 6>(v[1 + 12]);   // W16^3
+  v[2 + 12] = twid32<SIGN, 12>(v[2 + 12]);  // W16^6
+  v[3 + 12] = twid32<SIGN, 18>(v[3 + 12]);  // W16^9
   // Step B: DFT over n0 for each k1; result k = k1 + 4*k0 lands at v[4*k1 + k0]
   dft4<SIGN>(v[0], v[1], v[2], v[3]);
   dft4<SIGN>(v[4], v[5], v[6], v[7]);

@@ -21,6 +21,7 @@
 #include "blah2hip.h"
 #include "range_core.hpp"
 #include "fft_wg8.hpp"
+#include "fft_wave.hpp"
 #include "bufload.hpp"
 
 namespace blah2 {
@@ -45,6 +46,7 @@ struct RangeArgs {
   cf *out;             // tiled range map, see rmap_index()
   int64_t cpiStride;   // samples between consecutive CPIs of the batch
   int32_t nPulses;     // nCpi * nDoppler
+  uint64_t *dbg = nullptr; // trace builds only (tools/): cycle counts per phase
 };
 
 // segment s of the pulse at sample index pulseBase: v[k] = x'[t + T*k], yv[k] = y'[t + T*k]
@@ -210,6 +212,132 @@ __global__ __launch_bounds__(64 * R4, RANGE8_WAVES_PER_SIMD) void range8_kernel(
     W::inv_s1(t, acc, tw1, B);
     store_lags_g<T, 8>(a.out, p, cpi, i, t, acc);
   }
+}
+
+// --------------------------------------------------------------------------
+// Range kernel on the one-wave transform (fft_wave.hpp, F = 2048): identical mathematics and
+// interface, ONE wave64 per pulse, 32 points per lane, one LDS exchange per transform through a
+// wave-private region and no workgroup barrier anywhere.  The lags come out in natural order
+// z[t + 64*c], so the store is the same 128-byte-run pattern as the other kernels'.
+#ifndef RANGEW_WAVES_PER_SIMD
+#define RANGEW_WAVES_PER_SIMD 2
+#endif
+// segment s of the pulse: v[k] = x'[t + 64*k], yv[k] = y'[t + 64*k], k in [0, 32)
+template <class In>
+__device__ __forceinline__ void bufload_seg_w(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, cf *v, cf *yv)
+{
+  using B = BufLoad<In>;
+  constexpr int STEP = 64 * B::STRIDE;
+  constexpr int NV = (31 * STEP >> 12) + 1;
+  const int s0 = s * p.segLen;
+  const int cnt = min(p.segLen, p.nCorr - s0);
+  const b2_v4i xd = make_rsrc(B::xp(in, pulseBase + s0), cnt * B::STRIDE);
+  const b2_v4i yd = make_rsrc(B::yp(in, pulseBase), p.nCorr * B::STRIDE);
+  int vx[1] = {t * B::STRIDE};
+  int vy[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) vy[j] = (s0 + p.delayMin + t) * B::STRIDE + j * 4096; // may be negative: reads as zero
+  typename B::raw xr[32], yr[32];
+  bufload_chan<In, STEP, 32, true>(xr, xd, vx);
+  bufload_chan<In, STEP, 32, false>(yr, yd, vy);
+  bufwait<48, 16>(xr);
+  bufwait<32, 16>(xr + 16);
+#pragma unroll
+  for (int k = 0; k < 32; k++) v[k] = B::cvt(xr[k]);
+  bufwait<16, 16>(yr);
+  bufwait<0, 16>(yr + 16);
+#pragma unroll
+  for (int k = 0; k < 32; k++) yv[k] = B::cvt(yr[k]);
+}
+
+// lags z[t + 64*c] of one pulse into the tiled range map: lane t owns position t & 15 of tile
+// (t >> 4) + 4*c, so consecutive c are a constant stride apart
+__device__ __forceinline__ void store_lags_w(cf *out, const RangePlan &p, int cpi, int pulse, int t, const cf *v)
+{
+  const int nTiles = (p.nDelay + 15) >> 4;
+  cf *o = out + (((int64_t)cpi * nTiles + (t >> 4)) * p.nDoppler + pulse) * 16 + (t & 15);
+  const int64_t step = (int64_t)p.nDoppler * 64; // four tiles
+  int rem = p.nDelay - t;                        // lane t stores register c iff 64*c < rem
+  int nd = p.nDelay;
+  // opaque per call: otherwise the 32 lane masks and 32 uniform conditions are hoisted out of the
+  // pulse loop and live (spilled) across the whole kernel
+  asm volatile("" : "+v"(rem), "+s"(nd));
+#pragma unroll
+  for (int c = 0; c < 32; c++) {
+    if (64 * c >= nd) break; // wave-uniform
+    if (64 * c < rem) *o = cmake(v[c].x * p.scale, v[c].y * p.scale);
+    o += step;
+  }
+}
+
+#ifdef RANGEW_TRACE
+#define RW_T(k) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); tr[k] += now_ - t0_; t0_ = now_; }
+#else
+#define RW_T(k)
+#endif
+
+// RANGEW_WAVES independent waves per workgroup share the stage-twiddle table; each has its own
+// exchange region and walks its own pulses (no barrier after the table is filled).
+#ifndef RANGEW_WAVES
+#define RANGEW_WAVES 8
+#endif
+template <class In>
+__global__ __launch_bounds__(64 * RANGEW_WAVES, RANGEW_WAVES_PER_SIMD) void rangew_kernel(RangeArgs a, In in)
+{
+  using W = WaveFft;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf *table = reinterpret_cast<cf *>(smem);
+  const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  cf *X = table + W::TW_ELEMS + wave * W::X_ELEMS;
+  W::fill_table(threadIdx.x, 64 * RANGEW_WAVES, a.tw, table);
+  __syncthreads();
+  W::Tw w;
+  W::load_twiddles(t, a.tw, table, w);
+  const RangePlan p = a.plan;
+#ifdef RANGEW_TRACE
+  uint64_t tr[6] = {0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime();
+#endif
+  for (int pulse = blockIdx.x * RANGEW_WAVES + wave; pulse < a.nPulses; pulse += gridDim.x * RANGEW_WAVES) {
+    const int cpi = pulse / p.nDoppler;
+    const int i = pulse - cpi * p.nDoppler;
+    const int64_t base = (int64_t)cpi * a.cpiStride + (int64_t)i * p.nCorr;
+    cf acc[32];
+#pragma unroll
+    for (int e = 0; e < 32; e++) acc[e] = cmake(0.f, 0.f);
+    for (int s = 0; s < p.nSeg; s++) {
+      cf v[32], yv[32];
+      RW_T(0)
+      bufload_seg_w(in, p, base, s, t, v, yv);
+#ifdef RANGEW_TRACE
+      asm volatile("" : "+v"(v[0].x), "+v"(yv[31].y));
+#endif
+      RW_T(1)
+      W::transform<-1>(t, v, w, X);  // v  = X spectrum
+#ifdef RANGEW_TRACE
+      asm volatile("" : "+v"(v[0].x));
+#endif
+      RW_T(2)
+      W::transform<-1>(t, yv, w, X); // yv = Y spectrum
+#ifdef RANGEW_TRACE
+      asm volatile("" : "+v"(yv[0].x));
+#endif
+      RW_T(3)
+#pragma unroll
+      for (int e = 0; e < 32; e++) acc[e] = cmacc(acc[e], yv[e], v[e]);
+    }
+    RW_T(0)
+    W::transform<+1>(t, acc, w, X);
+#ifdef RANGEW_TRACE
+    asm volatile("" : "+v"(acc[0].x));
+#endif
+    RW_T(4)
+    store_lags_w(a.out, p, cpi, i, t, acc);
+    RW_T(5)
+  }
+#ifdef RANGEW_TRACE
+  if (t == 0 && a.dbg)
+    for (int k = 0; k < 6; k++) atomicAdd((unsigned long long *)&a.dbg[k], (unsigned long long)tr[k]);
+#endif
 }
 
 // --------------------------------------------------------------------------

@@ -189,6 +189,10 @@ class Ambiguity:
     def set_range_grid(self, n):
         check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_RANGE_GRID, int(n)))
 
+    def set_range_kernel(self, which):
+        """0 = by transform length, ``_lib.RANGE_WAVE`` = the one-wave kernel (F = 2048 only)."""
+        check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_RANGE_KERNEL, int(which)))
+
     def info(self, key):
         v = C.c_int64(0)
         check(self._L.blah2hip_amb_get_info(self._h, key, C.byref(v)))

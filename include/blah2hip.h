@@ -125,6 +125,7 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 /* Execution plan, per handle.  Options take effect on the next process call. */
 #define BLAH2HIP_OPT_DOPPLER_KERNEL 1 /* BLAH2HIP_DOP_*; AUTO picks by launch size */
 #define BLAH2HIP_OPT_RANGE_GRID 2     /* workgroups of the range kernel; 0 = residency default */
+#define BLAH2HIP_OPT_RANGE_KERNEL 3   /* 0 = by transform length, or BLAH2HIP_RANGE_WAVE (F = 2048 only) */
 #define BLAH2HIP_DOP_AUTO 0
 #define BLAH2HIP_DOP_TILE8 1   /* nD <= 513: 8-column tiles, one wave per column */
 #define BLAH2HIP_DOP_TILE16 2  /* nD <= 513: 16-column tiles */
@@ -133,6 +134,7 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 #define BLAH2HIP_DOP_DIRECT 5  /* any nD: direct DFT */
 #define BLAH2HIP_RANGE_E16 1   /* 16 points per thread (F = 2048, 4096) */
 #define BLAH2HIP_RANGE_E8 2    /* 8 points per thread, last stage across lanes (F = 1024) */
+#define BLAH2HIP_RANGE_WAVE 3  /* one wave per pulse, 32 points per lane, no barriers (F = 2048) */
 /* BLAH2HIP_ERR_UNSUPPORTED when the kernel does not cover the handle's Doppler length */
 int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value);
 #define BLAH2HIP_INFO_LAST_DOPPLER_KERNEL 1 /* BLAH2HIP_DOP_* the last process call launched (0 = none yet) */

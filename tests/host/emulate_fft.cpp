@@ -9,6 +9,7 @@
 //                                          -> prints max rel error vs the direct definition
 #include "../../blah2_amd/csrc/range_core.hpp"
 #include "../../blah2_amd/csrc/fft_wg8.hpp"
+#include "../../blah2_amd/csrc/fft_wave.hpp"
 
 #include <cmath>
 #include <complex>
@@ -156,6 +157,67 @@ template <int R4> int test_fft8()
   return (err / peak < 2e-6 && ierr < 2e-6) ? 0 : 1;
 }
 
+// one-wave transform (fft_wave.hpp): 64 lanes x 32 points, the lane exchange emulated on lane pairs
+template <int SIGN> void wave_transform(std::vector<cf> &v, const std::vector<cf> &tw, std::vector<cf> &X)
+{
+  using W = WaveFft;
+  std::vector<W::Tw> w(64);
+  std::vector<cf> table(W::TW_ELEMS);
+  for (int t = 0; t < 64; t++) W::fill_table(t, 64, tw.data(), table.data());
+  for (int t = 0; t < 64; t++) W::load_twiddles(t, tw.data(), table.data(), w[t]);
+  for (int t = 0; t < 64; t++) W::s1<SIGN>(&v[t * 32], w[t]);
+  for (int t1 = 0; t1 < 32; t1++) W::sw_host(&v[t1 * 32], &v[(t1 + 32) * 32]);
+  for (int t = 0; t < 64; t++) W::s2<SIGN>(t, &v[t * 32], w[t], X.data());
+  for (int t = 0; t < 64; t++) W::s3<SIGN>(t, &v[t * 32], X.data());
+}
+
+int test_fft_wave()
+{
+  using W = WaveFft;
+  constexpr int F = W::F;
+  std::mt19937 gen(777);
+  std::uniform_real_distribution<float> dist(-1.f, 1.f);
+  std::vector<cf> in(F), tw(F), X(W::X_ELEMS);
+  for (auto &c : in) c = cmake(dist(gen), dist(gen));
+  for (int k = 0; k < F; k++) { double a = -2.0 * M_PI * k / F; tw[k] = cmake((float)std::cos(a), (float)std::sin(a)); }
+  // the 32-point kernel on its own
+  double e32 = 0;
+  for (int sign = -1; sign <= 1; sign += 2) {
+    cf v[32];
+    for (int k = 0; k < 32; k++) v[k] = in[k];
+    if (sign < 0) dft32<-1>(v); else dft32<+1>(v);
+    for (int m = 0; m < 32; m++) {
+      cd acc = 0;
+      for (int n = 0; n < 32; n++) acc += cd(in[n].x, in[n].y) * std::polar(1.0, sign * 2.0 * M_PI * ((m * n) % 32) / 32.0);
+      e32 = std::max(e32, std::abs(cd(v[m].x, v[m].y) - acc));
+    }
+  }
+  std::vector<cf> v(F);
+  for (int t = 0; t < 64; t++)
+    for (int k = 0; k < 32; k++) v[t * 32 + k] = in[t + 64 * k];
+  wave_transform<-1>(v, tw, X);
+  double peak = 0, err = 0;
+  for (int m = 0; m < F; m++) {
+    cd acc = 0;
+    for (int n = 0; n < F; n++) {
+      double a = -2.0 * M_PI * (double)(((long)m * n) % F) / F;
+      acc += cd(in[n].x, in[n].y) * cd(std::cos(a), std::sin(a));
+    }
+    peak = std::max(peak, std::abs(acc));
+    const cf g = v[(m % 64) * 32 + m / 64];
+    err = std::max(err, std::abs(cd(g.x, g.y) - acc));
+  }
+  wave_transform<+1>(v, tw, X);
+  double ierr = 0;
+  for (int t = 0; t < 64; t++)
+    for (int c = 0; c < 32; c++) {
+      const cf g = v[t * 32 + c], e = in[t + 64 * c];
+      ierr = std::max(ierr, (double)std::abs(cd(g.x / F - e.x, g.y / F - e.y)));
+    }
+  std::printf("WAVE F=%d dft32_abs_err=%.3e fwd_rel_err=%.3e inv_abs_err=%.3e\n", F, e32, err / peak, ierr);
+  return (e32 < 2e-5 && err / peak < 2e-6 && ierr < 2e-6) ? 0 : 1;
+}
+
 template <int R3>
 int test_range(int nCorr, int nD, int dMin, int dMax, int nSeg, int segLen, unsigned seed)
 {
@@ -236,7 +298,7 @@ int test_range(int nCorr, int nD, int dMin, int dMax, int nSeg, int segLen, unsi
 int main(int argc, char **argv)
 {
   if (argc >= 2 && !std::strcmp(argv[1], "fft"))
-    return test_fft<4>() | test_fft<8>() | test_fft<16>() | test_fft8<2>() | test_fft8<4>() | test_fft8<8>();
+    return test_fft<4>() | test_fft<8>() | test_fft<16>() | test_fft8<2>() | test_fft8<4>() | test_fft8<8>() | test_fft_wave();
   if (argc >= 10 && !std::strcmp(argv[1], "range")) {
     const int R3 = std::atoi(argv[2]);
     const int a[7] = {std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]),

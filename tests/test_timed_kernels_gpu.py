@@ -38,13 +38,16 @@ def assert_cpi(got, met, ref, tag, cell_tol=CELL_TOL):
     assert abs(met[0] - noise) <= DB_TOL and abs(met[1] - mx) <= DB_TOL, f"{tag}: metrics {met} vs {(noise, mx)}"
 
 
-def run_batch(b2, geom, B, kernel, seeds, fmt="c32", expect=None, cell_tol=CELL_TOL, targets=((37, -63.0, 0.05),)):
+def run_batch(b2, geom, B, kernel, seeds, fmt="c32", expect=None, cell_tol=CELL_TOL, targets=((37, -63.0, 0.05),),
+              range_kernel=0):
     """B distinct CPIs through blah2hip_amb_process_dev in ONE call; every CPI against the oracle."""
     import torch
     dmin, dmax, fmin, fmax, fs, n = geom
     amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, max_batch=B)
     if kernel != "auto":
         amb.set_doppler_kernel(kernel)
+    if range_kernel:
+        amb.set_range_kernel(range_kernel)
     xs, ys = zip(*(O.synth_iq(n, seed=s, fs=fs, targets=targets) for s in seeds))
     nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
     out = torch.zeros((B, nD, nC), dtype=torch.complex64, device="cuda")
@@ -81,6 +84,27 @@ def test_cfg2_batched_takes_the_tile_kernel(b2, B):
     assert (amb.get_n_doppler_bins(), amb.get_n_delay_bins(), amb.dims.fft_len) == (513, 411, 2048)
     from blah2_amd import _lib
     assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_E16
+
+
+@pytest.mark.parametrize("fmt", ["c32", "i16"])
+def test_cfg2_one_wave_range_kernel(b2, fmt):
+    """The one-wave range kernel (32 points per lane, one LDS exchange, no barriers) on batches of
+    BASELINE configs[1]: grid-stride over the pulses of several CPIs, three segments per pulse."""
+    from blah2_amd import _lib
+    amb = run_batch(b2, CFG2, 3, "auto", seeds=(70, 71, 72), fmt=fmt, expect="tile8", range_kernel=_lib.RANGE_WAVE)
+    assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE
+
+
+def test_one_wave_range_kernel_ragged_geometry(b2, monkeypatch):
+    """Ragged pulse length, a lag window that starts at a positive lag and a last segment of a few
+    samples, single CPI and a batch."""
+    from blah2_amd import _lib
+    monkeypatch.setenv("BLAH2HIP_FFT_LEN", "2048")
+    geom = (1, 299, -100, 100, 1_000_000, 777_001)
+    for B in (1, 2):
+        amb = run_batch(b2, geom, B, "auto", seeds=range(80, 80 + B), range_kernel=_lib.RANGE_WAVE,
+                        expect="column", targets=((40, 30.0, 0.05),))
+        assert amb.dims.fft_len == 2048 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE
 
 
 def test_cfg2_batched_int16_wire_format(b2):
