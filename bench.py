@@ -210,8 +210,11 @@ def main(argv=None):
                     help="explicit number of Doppler bins (extension; 0 = the reference constructor's rule, which gives "
                          "513 at the headline configuration; 512 gives the literal BASELINE wording)")
     ap.add_argument("--doppler-kernel", default="auto", help="force a Doppler kernel (auto, tile8, tile16, tilem, column, direct)")
-    ap.add_argument("--range-kernel", default="auto", choices=["auto", "wave"],
-                    help="range kernel: by transform length, or the one-wave kernel (F = 2048 only)")
+    ap.add_argument("--prewarm-s", type=float, default=0.6,
+                    help="seconds of untimed steps BEFORE the W warmup steps: the shader clock needs ~0.3 s of load to ramp up "
+                         "from idle (measured: steps 5..25 of a cold run are 4-5 %% slower than steady state)")
+    ap.add_argument("--range-kernel", default="auto", choices=["auto", "wave", "e16"],
+                    help="range kernel: by transform length (F = 2048: the one-wave kernel), or forced")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent CPI streams per GPU (engine handles on their own HIP streams); successive "
                          "steps alternate between them so one batch's Doppler stage overlaps the next batch's range stage")
@@ -247,8 +250,8 @@ def main(argv=None):
             for _ in range(NS)]
     for h_ in ambs:
         h_.set_doppler_kernel(a.doppler_kernel)
-        if a.range_kernel == "wave":
-            h_.set_range_kernel(blah2_amd._lib.RANGE_WAVE)
+        if a.range_kernel != "auto":
+            h_.set_range_kernel({"wave": blah2_amd._lib.RANGE_WAVE, "e16": blah2_amd._lib.RANGE_E16}[a.range_kernel])
     amb = ambs[0]
     nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
     cells = nD * nC
@@ -312,6 +315,14 @@ def main(argv=None):
             dist.barrier()
             torch.cuda.synchronize()
 
+    # clock ramp (untimed, reported as config.prewarm_s): same steps, same buffers
+    t_pre = time.perf_counter()
+    n_pre = 0
+    while a.prewarm_s > 0 and time.perf_counter() - t_pre < a.prewarm_s:
+        for i in range(4):
+            step(n_pre + i)
+        n_pre += 4
+        torch.cuda.synchronize()
     for i in range(a.warmup):
         step(i)
     sync()
@@ -459,6 +470,8 @@ def main(argv=None):
                        "n_doppler_bins": nD, "n_delay_bins": nC, "n_corr": amb.get_n_corr(),
                        "fft_len": amb.dims.fft_len, "n_seg": amb.dims.n_seg, "seg_len": amb.dims.seg_len,
                        "doppler_kernel": amb.last_doppler_kernel(),
+                       "prewarm_s": a.prewarm_s, "prewarm_steps": n_pre,
+                       "range_kernel": {1: "e16", 2: "e8", 3: "wave"}.get(amb.info(blah2_amd._lib.INFO_LAST_RANGE_KERNEL)),
                        "ring_batches": ring, "streams_per_gpu": NS, "sharding": f"{world} independent CPI streams, one per GPU",
                        "ranks_seen_by_rccl": ranks_seen if dist is not None else None},
             "cells_per_s": total_cpis * cells / elapsed,

@@ -280,6 +280,13 @@ template <int R4, class In> int launch_range8_t(blah2hip_amb_s *h, const RangeAr
   return BLAH2HIP_OK;
 }
 
+// F = 2048 runs on the one-wave kernel unless the workgroup kernel is asked for (measured, round 2,
+// cfg 2 x 128 on one box, steady clocks: 1.329 vs 1.385 ms per step of the whole chain).
+bool use_wave_range(const blah2hip_amb_s *h)
+{
+  return h->r3 == 8 && h->rangeKernel != BLAH2HIP_RANGE_E16;
+}
+
 template <class In> int launch_rangew_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
 {
   const size_t lds = (size_t)(WaveFft::TW_ELEMS + RANGEW_WAVES * WaveFft::X_ELEMS) * sizeof(cf);
@@ -321,7 +328,7 @@ template <class In> int launch_rangew_t(blah2hip_amb_s *h, const RangeArgs &a, I
 // (radix 8-8-8-4 twiddles + the lane butterflies) and the kernel follows that count, not its occupancy.
 template <class In> int launch_range(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
 {
-  if (h->rangeKernel == BLAH2HIP_RANGE_WAVE) return launch_rangew_t(h, a, in, st);
+  if (use_wave_range(h)) return launch_rangew_t(h, a, in, st);
   switch (h->r3) {
   case 4: return launch_range8_t<2>(h, a, in, st);
   case 8: return launch_range_t<8>(h, a, in, st);
@@ -368,7 +375,7 @@ void set_range_residency(blah2hip_amb_s *h)
   const bool e8 = h->r3 == 4;
   size_t lds;
   int waves, wavesPerCU;
-  if (h->rangeKernel == BLAH2HIP_RANGE_WAVE) {
+  if (use_wave_range(h)) {
     lds = (size_t)(WaveFft::TW_ELEMS + RANGEW_WAVES * WaveFft::X_ELEMS) * sizeof(cf);
     waves = RANGEW_WAVES;
     wavesPerCU = 4 * RANGEW_WAVES_PER_SIMD;
@@ -632,9 +639,12 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
     h->rangeGridCap = value ? (int)value : h->rangeGridDefault;
     return BLAH2HIP_OK;
   case BLAH2HIP_OPT_RANGE_KERNEL:
-    if (value != 0 && value != BLAH2HIP_RANGE_WAVE) return fail(BLAH2HIP_ERR_INVALID, "range kernel: 0 (by transform length) or BLAH2HIP_RANGE_WAVE");
+    if (value != 0 && value != BLAH2HIP_RANGE_WAVE && value != BLAH2HIP_RANGE_E16)
+      return fail(BLAH2HIP_ERR_INVALID, "range kernel: 0 (by transform length), BLAH2HIP_RANGE_E16 or BLAH2HIP_RANGE_WAVE");
     if (value == BLAH2HIP_RANGE_WAVE && h->r3 != 8)
       return fail(BLAH2HIP_ERR_UNSUPPORTED, "the one-wave range kernel is a 2048-point transform");
+    if (value == BLAH2HIP_RANGE_E16 && h->r3 == 4)
+      return fail(BLAH2HIP_ERR_UNSUPPORTED, "F = 1024 runs on the 8-points-per-thread kernel only");
     h->rangeKernel = (int)value;
     set_range_residency(h);
     return BLAH2HIP_OK;

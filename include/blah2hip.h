@@ -125,14 +125,15 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 /* Execution plan, per handle.  Options take effect on the next process call. */
 #define BLAH2HIP_OPT_DOPPLER_KERNEL 1 /* BLAH2HIP_DOP_*; AUTO picks by launch size */
 #define BLAH2HIP_OPT_RANGE_GRID 2     /* workgroups of the range kernel; 0 = residency default */
-#define BLAH2HIP_OPT_RANGE_KERNEL 3   /* 0 = by transform length, or BLAH2HIP_RANGE_WAVE (F = 2048 only) */
+#define BLAH2HIP_OPT_RANGE_KERNEL 3   /* 0 = by transform length (F = 1024: E8, 2048: WAVE, 4096: E16); BLAH2HIP_RANGE_E16 forces the
+                                       * workgroup kernel at F = 2048, BLAH2HIP_RANGE_WAVE is the default there */
 #define BLAH2HIP_DOP_AUTO 0
 #define BLAH2HIP_DOP_TILE8 1   /* nD <= 513: 8-column tiles, one wave per column */
 #define BLAH2HIP_DOP_TILE16 2  /* nD <= 513: 16-column tiles */
 #define BLAH2HIP_DOP_TILEM 3   /* 513 < nD <= 2049: multi-wave columns, 8 or 4 per workgroup */
 #define BLAH2HIP_DOP_COLUMN 4  /* nD <= 2049: one column per workgroup (small launches) */
 #define BLAH2HIP_DOP_DIRECT 5  /* any nD: direct DFT */
-#define BLAH2HIP_RANGE_E16 1   /* 16 points per thread (F = 2048, 4096) */
+#define BLAH2HIP_RANGE_E16 1   /* 16 points per thread, one workgroup per pulse (F = 4096; F = 2048 on request) */
 #define BLAH2HIP_RANGE_E8 2    /* 8 points per thread, last stage across lanes (F = 1024) */
 #define BLAH2HIP_RANGE_WAVE 3  /* one wave per pulse, 32 points per lane, no barriers (F = 2048) */
 /* BLAH2HIP_ERR_UNSUPPORTED when the kernel does not cover the handle's Doppler length */
