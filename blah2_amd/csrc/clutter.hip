@@ -23,6 +23,9 @@
 // Results are mathematically identical to the reference's (same linear
 // system, same linear convolution); arithmetic is fp32 for the transforms and
 // fp64 for the reduction and the solve.
+// the correlation kernels run at 244-256 VGPRs: keep the butterflies as single-instruction statements
+// (fft_wg.hpp; the grouped form spills 5-33 registers here and costs 3.6 %, measured)
+#define B2_SPLIT_BUTTERFLIES 1
 #include <hip/hip_runtime.h>
 
 #include "blah2hip.h"

@@ -207,6 +207,64 @@ template <int SIGN, int J> B2_HD cf twid32(cf a) { return twid_k<SIGN>(a, w32_c(
 #endif
 
 // 4-point DFT, in place, natural order out.  SIGN = -1 forward, +1 inverse.
+#if defined(B2_PACKED_COMPLEX) && !defined(B2_SPLIT_BUTTERFLIES)
+// The device forms are ONE asm statement per butterfly group (eight packed adds): a statement boundary
+// between dependent packed instructions costs an s_nop from the compiler's hazard recogniser (see cmul).
+// One-wave range kernel -4.6 %, workgroup range kernel -1 % (measured).  The grouped form holds two
+// more registers per group while it runs; a translation unit whose kernels sit at the register cap
+// (clutter.hip: the correlation kernels) defines B2_SPLIT_BUTTERFLIES to keep one statement per add.
+#define B2_SUB " neg_lo:[0,1] neg_hi:[0,1]"
+#define B2_AMI " op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" /* a + (-i) b */
+#define B2_API " op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" /* a + (+i) b */
+// %0..%3 = a0..a3 (a0, a1 end up as scratch; a2, a3 receive outputs 2, 3), %4, %5 = outputs 0, 1
+#define B2_DFT4_BODY(F0, F1, PI, MI)                                      \
+  "v_pk_add_f32 %4, %0, %2" F0 "\n\t"  /* t0 */                           \
+  "v_pk_add_f32 %0, %0, %2" F1 "\n\t"  /* t1 */                           \
+  "v_pk_add_f32 %5, %1, %3\n\t"        /* t2 */                           \
+  "v_pk_add_f32 %1, %1, %3" B2_SUB "\n\t" /* d */                         \
+  "v_pk_add_f32 %2, %4, %5" B2_SUB "\n\t" /* out2 = t0 - t2 */            \
+  "v_pk_add_f32 %4, %4, %5\n\t"        /* out0 = t0 + t2 */               \
+  "v_pk_add_f32 %5, %0, %1" PI "\n\t"  /* out1 = t1 + (SIGN i) d */       \
+  "v_pk_add_f32 %3, %0, %1" MI           /* out3 = t1 - (SIGN i) d */
+template <int SIGN> __device__ __forceinline__ void dft4(cf &a0, cf &a1, cf &a2, cf &a3)
+{
+  b2_pk x0 = B2_V(a0), x1 = B2_V(a1), x2 = B2_V(a2), x3 = B2_V(a3), o0, o1;
+  if (SIGN < 0) asm(B2_DFT4_BODY("", B2_SUB, B2_AMI, B2_API) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "=&v"(o0), "=&v"(o1));
+  else asm(B2_DFT4_BODY("", B2_SUB, B2_API, B2_AMI) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "=&v"(o0), "=&v"(o1));
+  a0 = B2_C(o0); a1 = B2_C(o1); a2 = B2_C(x2); a3 = B2_C(x3);
+}
+// the same with its third input still to be multiplied by (SIGN i)
+template <int SIGN> __device__ __forceinline__ void dft4_rot2(cf &a0, cf &a1, cf &a2r, cf &a3)
+{
+  b2_pk x0 = B2_V(a0), x1 = B2_V(a1), x2 = B2_V(a2r), x3 = B2_V(a3), o0, o1;
+  if (SIGN < 0) asm(B2_DFT4_BODY(B2_AMI, B2_API, B2_AMI, B2_API) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "=&v"(o0), "=&v"(o1));
+  else asm(B2_DFT4_BODY(B2_API, B2_AMI, B2_API, B2_AMI) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "=&v"(o0), "=&v"(o1));
+  a0 = B2_C(o0); a1 = B2_C(o1); a2r = B2_C(x2); a3 = B2_C(x3);
+}
+// last stage of the 8-point DFT: (e_k, o_k) -> (e_k + o_k, e_k - o_k), the third pair with o times (SIGN i);
+// sums land in s0..s3, differences replace the o operands
+template <int SIGN> __device__ __forceinline__ void dft8_tail(cf *v, cf b1, cf b3)
+{
+  b2_pk o0 = B2_V(v[1]), o1 = B2_V(b1), o2 = B2_V(v[5]), o3 = B2_V(b3), s0, s1, s2, s3;
+#define B2_DFT8_TAIL(PI, MI)                                                   \
+  "v_pk_add_f32 %4, %8, %0\n\tv_pk_add_f32 %0, %8, %0" B2_SUB "\n\t"          \
+  "v_pk_add_f32 %5, %9, %1\n\tv_pk_add_f32 %1, %9, %1" B2_SUB "\n\t"          \
+  "v_pk_add_f32 %6, %10, %2" PI "\n\tv_pk_add_f32 %2, %10, %2" MI "\n\t"      \
+  "v_pk_add_f32 %7, %11, %3\n\tv_pk_add_f32 %3, %11, %3" B2_SUB
+  if (SIGN < 0)
+    asm(B2_DFT8_TAIL(B2_AMI, B2_API) : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3)
+        : "v"(B2_V(v[0])), "v"(B2_V(v[2])), "v"(B2_V(v[4])), "v"(B2_V(v[6])));
+  else
+    asm(B2_DFT8_TAIL(B2_API, B2_AMI) : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3)
+        : "v"(B2_V(v[0])), "v"(B2_V(v[2])), "v"(B2_V(v[4])), "v"(B2_V(v[6])));
+#undef B2_DFT8_TAIL
+  v[0] = B2_C(s0); v[4] = B2_C(o0);
+  v[1] = B2_C(s1); v[5] = B2_C(o1);
+  v[2] = B2_C(s2); v[6] = B2_C(o2);
+  v[3] = B2_C(s3); v[7] = B2_C(o3);
+}
+#undef B2_DFT4_BODY
+#else
 template <int SIGN> B2_HD void dft4(cf &a0, cf &a1, cf &a2, cf &a3)
 {
   const cf t0 = cadd(a0, a2), t1 = csub(a0, a2);
@@ -226,6 +284,15 @@ template <int SIGN> B2_HD void dft4_rot2(cf &a0, cf &a1, cf &a2r, cf &a3)
   a2r = csub(t0, t2);
   a3 = csub_i<SIGN>(t1, d);
 }
+template <int SIGN> B2_HD void dft8_tail(cf *v, cf b1, cf b3)
+{
+  const cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o2 = v[5];
+  v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+  v[1] = cadd(e1, b1); v[5] = csub(e1, b1);
+  v[2] = cadd_i<SIGN>(e2, o2); v[6] = csub_i<SIGN>(e2, o2);
+  v[3] = cadd(e3, b3); v[7] = csub(e3, b3);
+}
+#endif
 
 #define B2_SQH 0.70710678118654752440f
 #define B2_C16 0.92387953251128675613f
@@ -240,11 +307,7 @@ template <int SIGN> B2_HD void dft8(cf *v)
   // twiddle W8^(k1) on the odd set; W8^2 = (SIGN i) is folded into the butterfly
   const cf b1 = twid32<SIGN, 4>(v[3]);
   const cf b3 = twid32<SIGN, 12>(v[7]);
-  const cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o2 = v[5];
-  v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
-  v[1] = cadd(e1, b1); v[5] = csub(e1, b1);
-  v[2] = cadd_i<SIGN>(e2, o2); v[6] = csub_i<SIGN>(e2, o2);
-  v[3] = cadd(e3, b3); v[7] = csub(e3, b3);
+  dft8_tail<SIGN>(v, b1, b3);
 }
 
 // 16-point DFT, in place, natural order out.
