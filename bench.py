@@ -404,7 +404,8 @@ def main(argv=None):
             bc = tj.get("bench_config", {})
             if (bc.get("config"), bc.get("batch"), bc.get("fmt"), bc.get("chain", "amb")) != (a.config, B, a.fmt, a.chain):
                 continue
-            traffic = tj["kernels"]["range_kernel"]["hbm_bytes"]
+            rk = next(k_ for k_ in ("rangew_kernel", "range_kernel", "range8_kernel") if k_ in tj["kernels"])
+            traffic = tj["kernels"][rk]["hbm_bytes"]
             traffic_src = os.path.relpath(pth, ROOT)
             break
         except Exception:
@@ -478,7 +479,8 @@ def main(argv=None):
             "us_per_cpi": elapsed / (B * a.steps) * 1e6,
             "per_gpu_cpis_per_s": total_cpis / elapsed / world,
             "parity": parity,
-            "roofline": {"bound": "hbm", "kernel": "range_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": {1: "range_kernel", 2: "range8_kernel", 3: "rangew_kernel"}.get(
+                             amb.info(blah2_amd._lib.INFO_LAST_RANGE_KERNEL), "range_kernel"), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "copy_ceiling": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
