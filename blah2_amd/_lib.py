@@ -23,9 +23,9 @@ CLUTTER_KERNEL_NAMES = {CK_CORR: "clutter_corr", CK_REDUCE: "clutter_reduce", CK
                         CK_FIR: "clutter_fir"}
 OPT_DOPPLER_KERNEL, OPT_RANGE_GRID, OPT_RANGE_KERNEL = 1, 2, 3
 CLUTTER_OPT_SOLVE_K = 1
-DOP_AUTO, DOP_TILE8, DOP_TILE16, DOP_TILEM, DOP_COLUMN, DOP_DIRECT = 0, 1, 2, 3, 4, 5
+DOP_AUTO, DOP_TILE8, DOP_TILE16, DOP_TILEM, DOP_COLUMN, DOP_DIRECT, DOP_TILEW = 0, 1, 2, 3, 4, 5, 6
 DOPPLER_KERNEL_NAMES = {DOP_AUTO: "auto", DOP_TILE8: "tile8", DOP_TILE16: "tile16", DOP_TILEM: "tilem",
-                        DOP_COLUMN: "column", DOP_DIRECT: "direct"}
+                        DOP_COLUMN: "column", DOP_DIRECT: "direct", DOP_TILEW: "tilew"}
 RANGE_E16, RANGE_E8, RANGE_WAVE = 1, 2, 3
 INFO_LAST_DOPPLER_KERNEL, INFO_LAST_RANGE_KERNEL, INFO_DOPPLER_FFT_LEN, INFO_RANGE_GRID, INFO_NUM_CU = 1, 2, 3, 4, 5
 

@@ -104,6 +104,7 @@ struct blah2hip_amb_s {
   cf *d_dtw = nullptr;              // exp(-2 pi i k/M)
   cf *d_chirp = nullptr;            // exp(-i pi n^2/nD)
   cf *d_bf = nullptr;               // chirp-kernel spectrum / M in register layout
+  cf *d_bfn = nullptr;              // the same in natural order (M = 2048 only: doppler_tilew_kernel)
   double *d_sat = nullptr;          // 2-D CFAR summed-area table [max_batch][nD+1][nDelay+1]
 
   KernelTimer<BLAH2HIP_K_COUNT> timer;
@@ -214,7 +215,7 @@ void host_fft(std::vector<std::complex<double>> &a)
 }
 
 // Bluestein tables for the Doppler DFT of length nD on an M = 256*r3 point FFT
-void doppler_tables(int nD, int r3, std::vector<cf> &tw, std::vector<cf> &chirp, std::vector<cf> &bf)
+void doppler_tables(int nD, int r3, std::vector<cf> &tw, std::vector<cf> &chirp, std::vector<cf> &bf, std::vector<cf> &bfn)
 {
   const int M = 256 * r3, T = 16 * r3;
   tw.resize(M);
@@ -241,6 +242,8 @@ void doppler_tables(int nD, int r3, std::vector<cf> &tw, std::vector<cf> &chirp,
         const std::complex<double> v = b[m] / (double)M;
         bf[(size_t)e * T + t] = cmake((float)v.real(), (float)v.imag());
       }
+  bfn.resize(M);
+  for (int m = 0; m < M; m++) bfn[m] = cmake((float)(b[m].real() / M), (float)(b[m].imag() / M));
 }
 
 template <int R3> int launch_doppler_t(blah2hip_amb_s *h, const DopplerArgs &a, uint32_t n_cpi, hipStream_t st)
@@ -403,6 +406,7 @@ bool doppler_kernel_applicable(const blah2hip_amb_s *h, int which)
   case BLAH2HIP_DOP_TILE8:
   case BLAH2HIP_DOP_TILE16: return h->dopR3 == 4;
   case BLAH2HIP_DOP_TILEM: return (h->dopR3 == 8 && nD <= DopM<8>::MAX_ND) || (h->dopR3 == 16 && nD <= DopM<16>::MAX_ND);
+  case BLAH2HIP_DOP_TILEW: return h->dopR3 == 8 && nD <= DOPW_MAX_ND;
   case BLAH2HIP_DOP_COLUMN: return h->dopR3 != 0;
   case BLAH2HIP_DOP_DIRECT: return true;
   default: return false;
@@ -418,6 +422,7 @@ int pick_doppler(const blah2hip_amb_s *h, uint32_t n_cpi)
   const int tiles = (nDelay + ncol - 1) / ncol;
   const bool fills = (int)n_cpi * tiles >= h->numCU / 2;
   if (fills && h->dopR3 == 4) return BLAH2HIP_DOP_TILE8; // 8 columns x 2 workgroups per CU beat 16 x 1 (57 vs 74 us per 32 CPIs)
+  if (fills && doppler_kernel_applicable(h, BLAH2HIP_DOP_TILEW)) return BLAH2HIP_DOP_TILEW;
   if (fills && doppler_kernel_applicable(h, BLAH2HIP_DOP_TILEM)) return BLAH2HIP_DOP_TILEM;
   return BLAH2HIP_DOP_COLUMN;
 }
@@ -570,7 +575,10 @@ int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler
   HIPCHK(hipMemcpy(h->d_doppler, h->dopplerAxis.data(), nD * sizeof(double), hipMemcpyHostToDevice));
   if (h->dopR3) {
     std::vector<cf> dtw, chirp, bf;
-    doppler_tables((int)nD, h->dopR3, dtw, chirp, bf);
+    std::vector<cf> bfn;
+    doppler_tables((int)nD, h->dopR3, dtw, chirp, bf, bfn);
+    HIPCHK(hipMalloc(&h->d_bfn, bfn.size() * sizeof(cf)));
+    HIPCHK(hipMemcpy(h->d_bfn, bfn.data(), bfn.size() * sizeof(cf), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&h->d_dtw, dtw.size() * sizeof(cf)));
     HIPCHK(hipMalloc(&h->d_chirp, chirp.size() * sizeof(cf)));
     HIPCHK(hipMalloc(&h->d_bf, bf.size() * sizeof(cf)));
@@ -599,7 +607,7 @@ int blah2hip_amb_destroy(blah2hip_amb_t h)
                   (void *)h->d_partSum, (void *)h->d_partMax, (void *)h->d_metrics,
                   (void *)h->d_doppler, h->d_in, (void *)h->d_rot,
                   (void *)h->d_hits, (void *)h->d_count, (void *)h->d_sat, (void *)h->d_dtw, (void *)h->d_chirp,
-                  (void *)h->d_bf})
+                  (void *)h->d_bf, (void *)h->d_bfn})
     if (p) (void)hipFree(p);
   for (auto &t : h->alphaTables)
     if (t.d) (void)hipFree(t.d);
@@ -743,6 +751,7 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   da.tw = h->d_dtw;
   da.chirp = h->d_chirp;
   da.bf = h->d_bf;
+  da.bfn = h->d_bfn;
   da.partSum = h->d_partSum;
   da.partMax = h->d_partMax;
   da.nD = (int32_t)nD;
@@ -764,6 +773,33 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
       LDSCFG(doppler_tile_kernel<8>, lds);
       hipLaunchKernelGGL(doppler_tile_kernel<8>, dim3(grid, n_cpi), dim3(512), lds, st, da);
     }
+    nPartsUsed = grid;
+    break;
+  }
+  case BLAH2HIP_DOP_TILEW: {
+    const int grid = (int)((nDelay + DOPW_NCOL - 1) / DOPW_NCOL);
+    const size_t lds = (size_t)DOPW_LDS_ELEMS * sizeof(cf);
+    LDSCFG(doppler_tilew_kernel, lds);
+    // persistent: one workgroup per CU (LDS) walks the tiles of the whole batch
+    const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, h->numCU);
+#ifdef DOPW_TRACE
+    static uint64_t *dbg = nullptr;
+    static int calls = 0;
+    if (!dbg) HIPCHK(hipMalloc(&dbg, 64));
+    HIPCHK(hipMemsetAsync(dbg, 0, 64, st));
+    hipLaunchKernelGGL(doppler_tilew_kernel, dim3(wgs), dim3(64 * DOPW_NCOL), lds, st, da, (int)n_cpi, dbg);
+    if (++calls == 8) {
+      uint64_t hc[8];
+      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(hipMemcpy(hc, dbg, 64, hipMemcpyDeviceToHost));
+      double tot = 0;
+      for (int k = 0; k < 8; k++) tot += (double)hc[k];
+      fprintf(stderr, "[dopw trace] wgs %d: fill %.3f barriers %.3f colread+issue %.3f transforms %.3f bfmul %.3f park %.3f stores %.3f of %.0f ticks/wave\n", wgs,
+              hc[0] / tot, hc[1] / tot, hc[2] / tot, hc[3] / tot, hc[4] / tot, hc[5] / tot, hc[6] / tot, tot / wgs / DOPW_NCOL);
+    }
+#else
+    hipLaunchKernelGGL(doppler_tilew_kernel, dim3(wgs), dim3(64 * DOPW_NCOL), lds, st, da, (int)n_cpi, (uint64_t *)nullptr);
+#endif
     nPartsUsed = grid;
     break;
   }

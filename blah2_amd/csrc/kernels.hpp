@@ -395,6 +395,7 @@ struct DopplerArgs {
   const cf *tw;     // fft kernel: exp(-2 pi i k/M), [M]
   const cf *chirp;  // fft kernel: exp(-i pi n^2/nD), [nD]
   const cf *bf;     // fft kernel: kernel spectrum / M, [16][T]
+  const cf *bfn;    // the same in natural order [M] (M = 2048: doppler_tilew_kernel)
   double *partSum;  // [nCpi][partsPerCpi]
   float *partMax;   // [nCpi][partsPerCpi]
   int32_t nD, nDelay, nTiles;
@@ -644,6 +645,184 @@ __global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a)
     a.partSum[part] = sacc;
     a.partMax[part] = m;
   }
+}
+
+// Tile variant for 513 < nD <= 1025 on the ONE-WAVE 2048-point transform (fft_wave.hpp): the phases of
+// doppler_tile_kernel<8> with one wave per column doing both transforms of the chirp-z convolution in
+// its own exchange region (which is also the column's staging area), no barrier between the tile
+// fill and the write-back.  Eight columns per 512-thread workgroup; LDS = the stage-twiddle table +
+// 8 regions = 148 KB, so ONE workgroup per CU (two waves per SIMD) -- a workgroup is therefore
+// PERSISTENT and software-pipelined over its tiles: the next tile's loads are issued (into 17
+// registers per thread) right after this tile's column has been taken out of LDS and land during the
+// two transforms; this tile's row stores drain while the next tile is filled.  The kernel spectrum
+// (natural order, 16 KB, shared by every workgroup) comes from L2 right before its use.
+// Replaces doppler_tilem_kernel<8> (two-wave columns, workgroup barriers at every stage, one tile
+// per workgroup) in the automatic choice; numbers in DESIGN.md.
+__device__ __forceinline__ int relaunder(int v);
+constexpr int DOPW_NCOL = 8;
+constexpr int DOPW_MAX_ND = 1025;
+// region stride: odd, so that the transposing accesses of phases 1 and 4 (8 columns x 2 rows per
+// 16-lane group) hit 16 distinct bank pairs (at the even stride 2112 they were 8-way conflicts)
+constexpr int DOPW_RS = WaveFft::X_ELEMS + 1;
+constexpr int DOPW_CHIRP_ELEMS = 1088; // rows t + 64*k, k < 17
+constexpr int DOPW_LDS_ELEMS = WaveFft::TW_ELEMS + DOPW_NCOL * DOPW_RS + DOPW_CHIRP_ELEMS;
+__global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(DopplerArgs a, int nCpi, uint64_t *dbg)
+{
+#ifdef DOPW_TRACE
+  uint64_t tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime();
+#define DW_T(k) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); tr[k] += now_ - t0_; t0_ = now_; }
+#else
+#define DW_T(k)
+#endif
+  using W = WaveFft;
+  constexpr int NCOL = DOPW_NCOL, NT = 64 * NCOL, SH = 3;
+  constexpr int NR = 17;  // rows t + 64*k, k < 17, cover nD <= 1025 + 62
+  constexpr int NRT = 17; // tile cells per thread: nD * 8 / 512 <= 16.02
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double wsum[NCOL];
+  __shared__ float wmax[NCOL];
+  cf *table = reinterpret_cast<cf *>(smem);
+  cf *regions = table + W::TW_ELEMS;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, t = tid & 63; // wave = column of the half tile
+  const int nD = a.nD;
+  const int tilesPerCpi = (a.nDelay + NCOL - 1) / NCOL;
+  const int nTilesAll = tilesPerCpi * nCpi;
+  const int cells = nD * NCOL;
+  cf *region = regions + w * DOPW_RS;
+
+  // the chirp (the same for every column) lives in LDS: 34 registers less across the loop
+  cf *chirpL = regions + NCOL * DOPW_RS;
+  for (int i = tid; i < DOPW_CHIRP_ELEMS; i += NT) chirpL[i] = a.chirp[min(i, nD - 1)];
+  W::fill_table(tid, NT, a.tw, table);
+  W::Tw tw;
+  W::load_twiddles(t, a.tw, table, tw);
+
+  // coalesced read of a half tile (NCOL columns x nD pulses, 64 bytes per pulse row)
+  cf nt[NRT];
+  auto tile_load = [&](int it) {
+    const int cpi = it / tilesPerCpi, sub = it - cpi * tilesPerCpi;
+    const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, sub * NCOL);
+    const int tl = relaunder(tid); // per-phase address arithmetic is recomputed, not kept live across the loop
+#pragma unroll
+    for (int j = 0; j < NRT; j++) {
+      const int idx = tl + NT * j;
+      const int c = idx & (NCOL - 1), row = idx >> SH;
+      nt[j] = Rt[idx < cells ? row * 16 + c : 0];
+    }
+  };
+  int it = blockIdx.x;
+  if (it < nTilesAll) tile_load(it);
+  for (; it < nTilesAll; it += gridDim.x) {
+    const int cpi = it / tilesPerCpi, sub = it - cpi * tilesPerCpi;
+    const int col0 = sub * NCOL;
+    // phase 1: the tile, transposed into the per-column regions (the previous tile's row stores
+    // have read the regions: barrier at the end of the loop body)
+    {
+      const int tl = relaunder(tid);
+#pragma unroll
+      for (int j = 0; j < NRT; j++) {
+        const int idx = tl + NT * j;
+        const int c = idx & (NCOL - 1), row = idx >> SH;
+        if (idx < cells) regions[c * DOPW_RS + row] = nt[j];
+      }
+    }
+    DW_T(0)
+    __syncthreads();
+    DW_T(1)
+
+    // phase 2: this wave's column -> registers (DC removal + chirp); then the next tile's loads go
+    // out; transform, x kernel spectrum, inverse.  From here to the next barrier `region` is this
+    // wave's private exchange buffer (a single wave's LDS operations execute in order).
+    cf v[32];
+    const cf r0 = region[0];
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      const int i = t + 64 * k;
+      const cf rv = region[min(i, nD - 1)];
+      const cf p = cmul(csub(rv, r0), chirpL[i]);
+      v[k] = cmake(i < nD ? p.x : 0.f, i < nD ? p.y : 0.f);
+    }
+#pragma unroll
+    for (int k = NR; k < 32; k++) v[k] = cmake(0.f, 0.f);
+    // The kernel spectrum (16 KB, L2-resident) is requested here and lands during the forward
+    // transform; the next tile is requested only AFTER the spectrum has been used and lands during the
+    // inverse transform: loads return in order, so a spectrum load behind the tile's HBM loads waits
+    // for the tile (measured: 36 % of the kernel), and both sets in flight at once do not fit the
+    // registers.  Fetched every time: held across the loop the spectrum would cost 64 registers.
+    cf bf[32];
+    {
+      const cf *bfp = a.bfn + relaunder(t);
+#pragma unroll
+      for (int e = 0; e < 32; e++) bf[e] = bfp[64 * e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    DW_T(2)
+    W::transform<-1>(t, v, tw, region);
+    DW_T(3)
+#pragma unroll
+    for (int e = 0; e < 32; e++) v[e] = cmul(v[e], bf[e]);
+    if (it + (int)gridDim.x < nTilesAll) tile_load(it + gridDim.x);
+    __builtin_amdgcn_wave_barrier();
+    DW_T(4)
+    W::transform<+1>(t, v, tw, region);
+    __builtin_amdgcn_wave_barrier();
+    DW_T(3)
+
+    // phase 3: rotate rows by nD/2+1 and park the column back in its region
+    const int t3 = relaunder(t); // the 17 rotated row indices are recomputed, not carried across the loop
+#pragma unroll
+    for (int c = 0; c < NR; c++) {
+      const int k = t3 + 64 * c;
+      cf d = cmul(v[c], chirpL[k]);
+      if (c == 0 && t3 == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
+      int o = k - (nD / 2 + 1);
+      if (o < 0) o += nD;
+      if (k < nD) region[o] = d;
+    }
+    DW_T(5)
+    __syncthreads();
+    DW_T(1)
+
+    // phase 4: coalesced row-segment stores + Map::set_metrics partials
+    double lsum = 0.0;
+    float lmax = 0.f;
+    cf *mapb = a.map + (size_t)cpi * nD * a.nDelay + col0;
+    const int ncol = min(NCOL, a.nDelay - col0);
+    const int tl4 = relaunder(tid);
+#pragma unroll
+    for (int j = 0; j < NRT; j++) {
+      const int idx = tl4 + NT * j;
+      const int c = idx & (NCOL - 1), o = idx >> SH;
+      const bool ok = idx < cells && c < ncol;
+      const cf d = regions[c * DOPW_RS + min(o, nD - 1)];
+      if (ok) mapb[(size_t)o * a.nDelay + c] = d;
+      const float db = db_of(d);
+      lsum += ok ? (double)db : 0.0;
+      lmax = ok ? fmaxf(lmax, db) : lmax;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lsum += __shfl_xor(lsum, off);
+      lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    }
+    if (t == 0) { wsum[w] = lsum; wmax[w] = lmax; }
+    DW_T(6)
+    __syncthreads(); // also: every thread has taken its rows out of the regions
+    if (tid == 0) {
+      double sacc = 0.0;
+      float m = 0.f; // Map.cpp:193: the running max starts at 0
+      for (int i = 0; i < NCOL; i++) { sacc += wsum[i]; m = fmaxf(m, wmax[i]); }
+      const size_t part = (size_t)cpi * tilesPerCpi + sub;
+      a.partSum[part] = sacc;
+      a.partMax[part] = m;
+    }
+    DW_T(1)
+  }
+#ifdef DOPW_TRACE
+  if (t == 0 && dbg)
+    for (int k = 0; k < 8; k++) atomicAdd((unsigned long long *)&dbg[k], (unsigned long long)tr[k]);
+#endif
 }
 
 // Tile variant for multi-wave columns: 513 < nD <= 1025 (M = 2048, R3 = 8: a column is a

@@ -130,11 +130,13 @@ def test_tile_kernels_row_groups_and_ragged_tiles(b2, fmax, n, nD, kernel):
     assert amb.get_n_doppler_bins() == nD and amb.get_n_delay_bins() == 300
 
 
-@pytest.mark.parametrize("fmax,n,nD", [(257, 1_030_000, 515), (512, 2_050_000, 1025)])
-def test_two_wave_tile_kernel(b2, fmax, n, nD):
-    """513 < nD <= 1025 -> doppler_tilem_kernel<8> (two-wave columns, 8 per workgroup)."""
+@pytest.mark.parametrize("fmax,n,nD", [(257, 1_030_000, 515), (400, 1_602_000, 801), (512, 2_050_000, 1025)])
+@pytest.mark.parametrize("kernel", ["tilew", "tilem"])
+def test_one_wave_and_two_wave_tile_kernels(b2, fmax, n, nD, kernel):
+    """513 < nD <= 1025 -> doppler_tilew_kernel (one-wave 2048-point columns, 8 per workgroup; the
+    automatic choice) and doppler_tilem_kernel<8> (two-wave columns), each forced; ragged last tile."""
     geom = (-7, 292, -fmax, fmax, n, n)
-    amb = run_batch(b2, geom, 2, "tilem", seeds=(80 + nD, 81 + nD), targets=((37, -13.0, 0.05),))
+    amb = run_batch(b2, geom, 2, kernel, seeds=(80 + nD, 81 + nD), targets=((37, -13.0, 0.05),))
     assert amb.get_n_doppler_bins() == nD
     from blah2_amd import _lib
     assert amb.info(_lib.INFO_DOPPLER_FFT_LEN) == 2048
@@ -174,4 +176,6 @@ def _expected_doppler(b2, geom):
     d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
     if d.n_doppler_bins <= 513:
         return "tile8" if 2 * -(-d.n_delay_bins // 8) >= 128 else "column"
-    return "tilem" if 2 * -(-d.n_delay_bins // 8) >= 128 else "column"
+    if d.n_doppler_bins <= 1025:
+        return "tilew" if 2 * -(-d.n_delay_bins // 8) >= 128 else "column"
+    return "tilem" if 2 * -(-d.n_delay_bins // 4) >= 128 else "column"
