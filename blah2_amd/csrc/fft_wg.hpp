@@ -310,14 +310,9 @@ template <int SIGN> B2_HD void dft8(cf *v)
   dft8_tail<SIGN>(v, b1, b3);
 }
 
-// 16-point DFT, in place, natural order out.
-template <int SIGN> B2_HD void dft16(cf *v)
+// steps after the first of the 16-point DFT: twiddles, DFT over n0, transpose
+template <int SIGN> B2_HD void dft16_tail(cf *v)
 {
-  // n = n0 + 4*n1 ; k = k1 + 4*k0.  Step A: DFT over n1 for each n0.
-  dft4<SIGN>(v[0], v[4], v[8], v[12]);
-  dft4<SIGN>(v[1], v[5], v[9], v[13]);
-  dft4<SIGN>(v[2], v[6], v[10], v[14]);
-  dft4<SIGN>(v[3], v[7], v[11], v[15]);
   // now v[n0 + 4*k1]; twiddle by W16^(n0*k1) (W16^4 = (SIGN i) on v[10] is folded into step B)
   v[1 + 4] = twid32<SIGN, 2>(v[1 + 4]);       // W16^1
   v[2 + 4] = twid32<SIGN, 4>(v[2 + 4]);       // W16^2
@@ -340,6 +335,45 @@ template <int SIGN> B2_HD void dft16(cf *v)
   t = v[6]; v[6] = v[9]; v[9] = t;
   t = v[7]; v[7] = v[13]; v[13] = t;
   t = v[11]; v[11] = v[14]; v[14] = t;
+}
+
+
+// 16-point DFT, in place, natural order out.
+template <int SIGN> B2_HD void dft16(cf *v)
+{
+  // n = n0 + 4*n1 ; k = k1 + 4*k0.  Step A: DFT over n1 for each n0.
+  dft4<SIGN>(v[0], v[4], v[8], v[12]);
+  dft4<SIGN>(v[1], v[5], v[9], v[13]);
+  dft4<SIGN>(v[2], v[6], v[10], v[14]);
+  dft4<SIGN>(v[3], v[7], v[11], v[15]);
+  dft16_tail<SIGN>(v);
+}
+
+// 4-point DFTs with trailing zero inputs (the zero-padded reference segments)
+template <int SIGN> B2_HD void dft4_z3(cf &a0, cf &a1, cf &a2, cf &a3) // a3 = 0 on entry
+{
+  const cf t0 = cadd(a0, a2), t1 = csub(a0, a2), d = a1;
+  a0 = cadd(t0, d);
+  a1 = cadd_i<SIGN>(t1, d);
+  a2 = csub(t0, d);
+  a3 = csub_i<SIGN>(t1, d);
+}
+template <int SIGN> B2_HD void dft4_z23(cf &a0, cf &a1, cf &a2, cf &a3) // a2 = a3 = 0 on entry
+{
+  const cf e = a0, d = a1;
+  a0 = cadd(e, d);
+  a1 = cadd_i<SIGN>(e, d);
+  a2 = csub(e, d);
+  a3 = csub_i<SIGN>(e, d);
+}
+// 16-point DFT whose inputs v[9..15] are zero (not read): 18 instead of 32 adds in the first step
+template <int SIGN> B2_HD void dft16_nz9(cf *v)
+{
+  dft4_z3<SIGN>(v[0], v[4], v[8], v[12]);
+  dft4_z23<SIGN>(v[1], v[5], v[9], v[13]);
+  dft4_z23<SIGN>(v[2], v[6], v[10], v[14]);
+  dft4_z23<SIGN>(v[3], v[7], v[11], v[15]);
+  dft16_tail<SIGN>(v);
 }
 
 template <int R, int SIGN> B2_HD void dftR(cf *v)
@@ -388,6 +422,15 @@ template <int R3> struct WgFft {
   B2_HD static void fwd_s1(int t, cf *v, const cf *tw1, cf *A)
   {
     dft16<-1>(v);
+#pragma unroll
+    for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw1[q - 1]);
+#pragma unroll
+    for (int q = 0; q < 16; q++) A[q * PA + t] = v[q];
+  }
+  // the same for a zero-padded segment whose inputs v[9..15] are zero (and were not loaded)
+  B2_HD static void fwd_s1_nz9(int t, cf *v, const cf *tw1, cf *A)
+  {
+    dft16_nz9<-1>(v);
 #pragma unroll
     for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw1[q - 1]);
 #pragma unroll

@@ -50,7 +50,8 @@ struct RangeArgs {
 };
 
 // segment s of the pulse at sample index pulseBase: v[k] = x'[t + T*k], yv[k] = y'[t + T*k]
-template <int T, int E, class In>
+// EX < E: only the first EX loads of the x segment are issued (the rest of x' is zero padding)
+template <int T, int E, class In, int EX = E>
 __device__ __forceinline__ void bufload_seg(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, cf *v, cf *yv)
 {
   using B = BufLoad<In>;
@@ -64,12 +65,12 @@ __device__ __forceinline__ void bufload_seg(const In &in, const RangePlan &p, in
   int vy[NV];
 #pragma unroll
   for (int j = 0; j < NV; j++) vy[j] = (s0 + p.delayMin + t) * B::STRIDE + j * 4096; // may be negative: reads as zero
-  typename B::raw xr[E], yr[E];
-  bufload_chan<In, STEP, E, true>(xr, xd, vx);
+  typename B::raw xr[EX], yr[E];
+  bufload_chan<In, STEP, EX, true>(xr, xd, vx);
   bufload_chan<In, STEP, E, false>(yr, yd, vy);
-  bufwait<E, E>(xr);
+  bufwait<E, EX>(xr);
 #pragma unroll
-  for (int k = 0; k < E; k++) v[k] = B::cvt(xr[k]);
+  for (int k = 0; k < EX; k++) v[k] = B::cvt(xr[k]);
   bufwait<0, E>(yr);
 #pragma unroll
   for (int k = 0; k < E; k++) yv[k] = B::cvt(yr[k]);
@@ -97,9 +98,13 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
     const int64_t base = (int64_t)cpi * a.cpiStride + (int64_t)i * p.nCorr;
 
     cf v[16], yv[16], acc[16];
+    // zero-padded reference segments that end below 9*T samples (cfg 3: 2049 of 4096) have x'[t + T*k] = 0
+    // for k >= 9: those loads are not issued and the first 16-point step skips the zero inputs
+    const bool xshort = !ILV && p.segLen <= 9 * 16 * R3;
     for (int s = 0; s < p.nSeg; s++) {
       // both channels' loads go out first: 32 requests in flight per thread
-      bufload_seg<16 * R3, 16>(in, p, base, s, t, v, yv);
+      if (xshort) bufload_seg<16 * R3, 16, In, 9>(in, p, base, s, t, v, yv);
+      else bufload_seg<16 * R3, 16>(in, p, base, s, t, v, yv);
       if (ILV) {
         // The x and y transforms advance together, each through its own exchange
         // buffer (P for x, Q for y, used first in the A layout and then in the B
@@ -120,7 +125,8 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
         W::fwd_s3(t, yv, tw3, Q); // yv = Y spectrum
       } else {
         // one transform at a time, P in the A layout and Q in the B layout
-        W::fwd_s1(t, v, tw1, P);
+        if (xshort) W::fwd_s1_nz9(t, v, tw1, P);
+        else W::fwd_s1(t, v, tw1, P);
         __syncthreads();
         W::fwd_s2(t, v, P, Q);
         __syncthreads();
@@ -661,9 +667,11 @@ __global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a)
 __device__ __forceinline__ int relaunder(int v);
 constexpr int DOPW_NCOL = 8;
 constexpr int DOPW_MAX_ND = 1025;
-// region stride: odd, so that the transposing accesses of phases 1 and 4 (8 columns x 2 rows per
-// 16-lane group) hit 16 distinct bank pairs (at the even stride 2112 they were 8-way conflicts)
-constexpr int DOPW_RS = WaveFft::X_ELEMS + 1;
+// region stride = 2 (mod 8): the transposing accesses of phases 1 and 4 (a 16-lane group touches 4
+// column pairs x 4 rows, one column of each pair per instruction) hit 16 distinct bank pairs
+// (at the stride 2112 = 0 (mod 16) all columns fell on the same banks)
+constexpr int DOPW_RS = WaveFft::X_ELEMS + 2;
+static_assert(DOPW_RS % 8 == 2, "");
 constexpr int DOPW_CHIRP_ELEMS = 1088; // rows t + 64*k, k < 17
 constexpr int DOPW_LDS_ELEMS = WaveFft::TW_ELEMS + DOPW_NCOL * DOPW_RS + DOPW_CHIRP_ELEMS;
 __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(DopplerArgs a, int nCpi, uint64_t *dbg)
@@ -677,7 +685,7 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
   using W = WaveFft;
   constexpr int NCOL = DOPW_NCOL, NT = 64 * NCOL, SH = 3;
   constexpr int NR = 17;  // rows t + 64*k, k < 17, cover nD <= 1025 + 62
-  constexpr int NRT = 17; // tile cells per thread: nD * 8 / 512 <= 16.02
+  constexpr int NRP = 9;  // tile cell PAIRS (two neighbouring columns, 16 bytes) per thread: nD * 4 / 512 <= 8.01
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double wsum[NCOL];
   __shared__ float wmax[NCOL];
@@ -688,7 +696,6 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
   const int nD = a.nD;
   const int tilesPerCpi = (a.nDelay + NCOL - 1) / NCOL;
   const int nTilesAll = tilesPerCpi * nCpi;
-  const int cells = nD * NCOL;
   cf *region = regions + w * DOPW_RS;
 
   // the chirp (the same for every column) lives in LDS: 34 registers less across the loop
@@ -699,16 +706,18 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
   W::load_twiddles(t, a.tw, table, tw);
 
   // coalesced read of a half tile (NCOL columns x nD pulses, 64 bytes per pulse row)
-  cf nt[NRT];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 nt[NRP];
+  const int pairs = nD * (NCOL / 2);
   auto tile_load = [&](int it) {
     const int cpi = it / tilesPerCpi, sub = it - cpi * tilesPerCpi;
     const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, sub * NCOL);
     const int tl = relaunder(tid); // per-phase address arithmetic is recomputed, not kept live across the loop
 #pragma unroll
-    for (int j = 0; j < NRT; j++) {
+    for (int j = 0; j < NRP; j++) {
       const int idx = tl + NT * j;
-      const int c = idx & (NCOL - 1), row = idx >> SH;
-      nt[j] = Rt[idx < cells ? row * 16 + c : 0];
+      const int pc = idx & (NCOL / 2 - 1), row = idx >> (SH - 1);
+      nt[j] = *reinterpret_cast<const f4 *>(Rt + (idx < pairs ? row * 16 + 2 * pc : 0));
     }
   };
   int it = blockIdx.x;
@@ -721,10 +730,13 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
     {
       const int tl = relaunder(tid);
 #pragma unroll
-      for (int j = 0; j < NRT; j++) {
+      for (int j = 0; j < NRP; j++) {
         const int idx = tl + NT * j;
-        const int c = idx & (NCOL - 1), row = idx >> SH;
-        if (idx < cells) regions[c * DOPW_RS + row] = nt[j];
+        const int pc = idx & (NCOL / 2 - 1), row = idx >> (SH - 1);
+        if (idx < pairs) {
+          regions[(2 * pc) * DOPW_RS + row] = cmake(nt[j].x, nt[j].y);
+          regions[(2 * pc + 1) * DOPW_RS + row] = cmake(nt[j].z, nt[j].w);
+        }
       }
     }
     DW_T(0)
@@ -736,9 +748,10 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
     // wave's private exchange buffer (a single wave's LDS operations execute in order).
     cf v[32];
     const cf r0 = region[0];
+    const int t2 = relaunder(t);
 #pragma unroll
     for (int k = 0; k < NR; k++) {
-      const int i = t + 64 * k;
+      const int i = t2 + 64 * k;
       const cf rv = region[min(i, nD - 1)];
       const cf p = cmul(csub(rv, r0), chirpL[i]);
       v[k] = cmake(i < nD ? p.x : 0.f, i < nD ? p.y : 0.f);
@@ -778,7 +791,7 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
       if (c == 0 && t3 == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
       int o = k - (nD / 2 + 1);
       if (o < 0) o += nD;
-      if (k < nD) region[o] = d;
+      region[k < nD ? o : DOPW_RS - 1] = d; // rows beyond nD go to a spare slot: no branch per row
     }
     DW_T(5)
     __syncthreads();
@@ -790,23 +803,33 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
     cf *mapb = a.map + (size_t)cpi * nD * a.nDelay + col0;
     const int ncol = min(NCOL, a.nDelay - col0);
     const int tl4 = relaunder(tid);
+    const bool wide = (a.nDelay & 1) == 0; // 16-byte row pieces need the rows to start 16-byte aligned
 #pragma unroll
-    for (int j = 0; j < NRT; j++) {
+    for (int j = 0; j < NRP; j++) {
       const int idx = tl4 + NT * j;
-      const int c = idx & (NCOL - 1), o = idx >> SH;
-      const bool ok = idx < cells && c < ncol;
-      const cf d = regions[c * DOPW_RS + min(o, nD - 1)];
-      if (ok) mapb[(size_t)o * a.nDelay + c] = d;
-      const float db = db_of(d);
-      lsum += ok ? (double)db : 0.0;
-      lmax = ok ? fmaxf(lmax, db) : lmax;
+      const int pc = idx & (NCOL / 2 - 1), o = idx >> (SH - 1);
+      const bool ok0 = idx < pairs && 2 * pc < ncol, ok1 = idx < pairs && 2 * pc + 1 < ncol;
+      const cf d0 = regions[(2 * pc) * DOPW_RS + min(o, nD - 1)];
+      const cf d1 = regions[(2 * pc + 1) * DOPW_RS + min(o, nD - 1)];
+      cf *dst = mapb + (size_t)o * a.nDelay + 2 * pc;
+      if (wide && ok1) {
+        f4 q = {d0.x, d0.y, d1.x, d1.y};
+        *reinterpret_cast<f4 *>(dst) = q;
+      } else {
+        if (ok0) dst[0] = d0;
+        if (ok1) dst[1] = d1;
+      }
+      const float db0 = db_of(d0), db1 = db_of(d1);
+      lsum += (ok0 ? (double)db0 : 0.0) + (ok1 ? (double)db1 : 0.0);
+      lmax = ok0 ? fmaxf(lmax, db0) : lmax;
+      lmax = ok1 ? fmaxf(lmax, db1) : lmax;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       lsum += __shfl_xor(lsum, off);
       lmax = fmaxf(lmax, __shfl_xor(lmax, off));
     }
-    if (t == 0) { wsum[w] = lsum; wmax[w] = lmax; }
+    if (t == 0) { const int wl = relaunder(tid) >> 6; wsum[wl] = lsum; wmax[wl] = lmax; }
     DW_T(6)
     __syncthreads(); // also: every thread has taken its rows out of the regions
     if (tid == 0) {

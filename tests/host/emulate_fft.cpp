@@ -218,6 +218,23 @@ int test_fft_wave()
   return (e32 < 2e-5 && err / peak < 2e-6 && ierr < 2e-6) ? 0 : 1;
 }
 
+// the pruned 16-point DFT of the zero-padded reference segments against the full one
+int test_dft16_nz9()
+{
+  std::mt19937 gen(99);
+  std::uniform_real_distribution<float> dist(-1.f, 1.f);
+  double err = 0;
+  for (int rep = 0; rep < 4; rep++) {
+    cf a[16], b[16];
+    for (int k = 0; k < 16; k++) a[k] = b[k] = k < 9 ? cmake(dist(gen), dist(gen)) : cmake(0.f, 0.f);
+    for (int k = 9; k < 16; k++) b[k] = cmake(123.f, -7.f); // never read
+    if (rep & 1) { dft16<+1>(a); dft16_nz9<+1>(b); } else { dft16<-1>(a); dft16_nz9<-1>(b); }
+    for (int k = 0; k < 16; k++) err = std::max(err, (double)std::hypot(a[k].x - b[k].x, a[k].y - b[k].y));
+  }
+  std::printf("NZ9 dft16 pruned_vs_full_abs_err=%.3e\n", err);
+  return err < 1e-6 ? 0 : 1;
+}
+
 template <int R3>
 int test_range(int nCorr, int nD, int dMin, int dMax, int nSeg, int segLen, unsigned seed)
 {
@@ -298,7 +315,7 @@ int test_range(int nCorr, int nD, int dMin, int dMax, int nSeg, int segLen, unsi
 int main(int argc, char **argv)
 {
   if (argc >= 2 && !std::strcmp(argv[1], "fft"))
-    return test_fft<4>() | test_fft<8>() | test_fft<16>() | test_fft8<2>() | test_fft8<4>() | test_fft8<8>() | test_fft_wave();
+    return test_fft<4>() | test_fft<8>() | test_fft<16>() | test_fft8<2>() | test_fft8<4>() | test_fft8<8>() | test_fft_wave() | test_dft16_nz9();
   if (argc >= 10 && !std::strcmp(argv[1], "range")) {
     const int R3 = std::atoi(argv[2]);
     const int a[7] = {std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]),
