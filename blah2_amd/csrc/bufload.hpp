@@ -80,8 +80,10 @@ template <> struct BufLoad<InF16> {
 // tied to the wait so that nothing reads them earlier
 template <int N, int E, class R> __device__ __forceinline__ void bufwait(R *r)
 {
-  static_assert(E == 8 || E == 9 || E == 16, "");
-  if constexpr (E == 9)
+  static_assert(E == 4 || E == 8 || E == 9 || E == 16, "");
+  if constexpr (E == 4)
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
+  else if constexpr (E == 9)
     asm volatile("s_waitcnt vmcnt(%9)"
                  : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8])
                  : "n"(N)

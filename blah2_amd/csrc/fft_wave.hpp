@@ -46,14 +46,16 @@ template <int SIGN, int N0, int K1 = 1> B2_HD void dft32_twiddles(cf *u)
 }
 
 // 32-point DFT, in place, natural order out.  n = n0 + 4*n1, k = k1 + 8*k0.
-template <int SIGN> B2_HD void dft32(cf *v)
+// NZ = 24 / 28: the inputs v[NZ..31] are zero (zero padding of a segment window) and are not read.
+template <int SIGN, int NZ = 32> B2_HD void dft32(cf *v)
 {
+  static_assert(NZ == 24 || NZ == 28 || NZ == 32, "");
   cf u[4][8];
 #pragma unroll
   for (int n0 = 0; n0 < 4; n0++) {
 #pragma unroll
-    for (int n1 = 0; n1 < 8; n1++) u[n0][n1] = v[n0 + 4 * n1];
-    dft8<SIGN>(u[n0]); // -> u[n0][k1]
+    for (int n1 = 0; n1 < NZ / 4; n1++) u[n0][n1] = v[n0 + 4 * n1];
+    dft8_z<SIGN, NZ / 4>(u[n0]); // -> u[n0][k1]
   }
   dft32_twiddles<SIGN, 1>(u[1]);
   dft32_twiddles<SIGN, 2>(u[2]);
@@ -93,9 +95,9 @@ struct WaveFft {
   }
 
   // v[k1] = in[t + 64*k1] on entry
-  template <int SIGN> B2_HD static void s1(cf *v, const Tw &w)
+  template <int SIGN, int NZ = 32> B2_HD static void s1(cf *v, const Tw &w)
   {
-    dft32<SIGN>(v);
+    dft32<SIGN, NZ>(v);
 #pragma unroll
     for (int q = 1; q < 32; q++) v[q] = twid<SIGN>(v[q], w.tab[(q - 1) * 64]);
   }
@@ -154,9 +156,9 @@ struct WaveFft {
   }
 
 #if defined(__HIPCC__)
-  template <int SIGN> __device__ __forceinline__ static void transform(int t, cf *v, const Tw &w, cf *X)
+  template <int SIGN, int NZ = 32> __device__ __forceinline__ static void transform(int t, cf *v, const Tw &w, cf *X)
   {
-    s1<SIGN>(v, w);
+    s1<SIGN, NZ>(v, w);
     sw(v);
     s2<SIGN>(t, v, w, X);
     s3<SIGN>(t, v, X);

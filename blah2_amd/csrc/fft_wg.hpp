@@ -298,6 +298,23 @@ template <int SIGN> B2_HD void dft8_tail(cf *v, cf b1, cf b3)
 #define B2_C16 0.92387953251128675613f
 #define B2_S16 0.38268343236508977173f
 
+// 4-point DFTs with trailing zero inputs (the zero-padded reference segments)
+template <int SIGN> B2_HD void dft4_z3(cf &a0, cf &a1, cf &a2, cf &a3) // a3 = 0 on entry
+{
+  const cf t0 = cadd(a0, a2), t1 = csub(a0, a2), d = a1;
+  a0 = cadd(t0, d);
+  a1 = cadd_i<SIGN>(t1, d);
+  a2 = csub(t0, d);
+  a3 = csub_i<SIGN>(t1, d);
+}
+template <int SIGN> B2_HD void dft4_z23(cf &a0, cf &a1, cf &a2, cf &a3) // a2 = a3 = 0 on entry
+{
+  const cf e = a0, d = a1;
+  a0 = cadd(e, d);
+  a1 = cadd_i<SIGN>(e, d);
+  a2 = csub(e, d);
+  a3 = csub_i<SIGN>(e, d);
+}
 // 8-point DFT, in place, natural order out.
 template <int SIGN> B2_HD void dft8(cf *v)
 {
@@ -338,6 +355,19 @@ template <int SIGN> B2_HD void dft16_tail(cf *v)
 }
 
 
+// 8-point DFT whose inputs v[K..7] are zero (not read), K = 6, 7 or 8
+template <int SIGN, int K> B2_HD void dft8_z(cf *v)
+{
+  static_assert(K >= 6 && K <= 8, "");
+  if (K <= 6) dft4_z3<SIGN>(v[0], v[2], v[4], v[6]);
+  else dft4<SIGN>(v[0], v[2], v[4], v[6]);
+  if (K <= 7) dft4_z3<SIGN>(v[1], v[3], v[5], v[7]);
+  else dft4<SIGN>(v[1], v[3], v[5], v[7]);
+  const cf b1 = twid32<SIGN, 4>(v[3]);
+  const cf b3 = twid32<SIGN, 12>(v[7]);
+  dft8_tail<SIGN>(v, b1, b3);
+}
+
 // 16-point DFT, in place, natural order out.
 template <int SIGN> B2_HD void dft16(cf *v)
 {
@@ -349,23 +379,6 @@ template <int SIGN> B2_HD void dft16(cf *v)
   dft16_tail<SIGN>(v);
 }
 
-// 4-point DFTs with trailing zero inputs (the zero-padded reference segments)
-template <int SIGN> B2_HD void dft4_z3(cf &a0, cf &a1, cf &a2, cf &a3) // a3 = 0 on entry
-{
-  const cf t0 = cadd(a0, a2), t1 = csub(a0, a2), d = a1;
-  a0 = cadd(t0, d);
-  a1 = cadd_i<SIGN>(t1, d);
-  a2 = csub(t0, d);
-  a3 = csub_i<SIGN>(t1, d);
-}
-template <int SIGN> B2_HD void dft4_z23(cf &a0, cf &a1, cf &a2, cf &a3) // a2 = a3 = 0 on entry
-{
-  const cf e = a0, d = a1;
-  a0 = cadd(e, d);
-  a1 = cadd_i<SIGN>(e, d);
-  a2 = csub(e, d);
-  a3 = csub_i<SIGN>(e, d);
-}
 // 16-point DFT whose inputs v[9..15] are zero (not read): 18 instead of 32 adds in the first step
 template <int SIGN> B2_HD void dft16_nz9(cf *v)
 {

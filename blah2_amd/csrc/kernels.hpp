@@ -228,10 +228,12 @@ __global__ __launch_bounds__(64 * R4, RANGE8_WAVES_PER_SIMD) void range8_kernel(
 #ifndef RANGEW_WAVES_PER_SIMD
 #define RANGEW_WAVES_PER_SIMD 2
 #endif
-// segment s of the pulse: v[k] = x'[t + 64*k], yv[k] = y'[t + 64*k], k in [0, 32)
-template <class In>
+// segment s of the pulse: v[k] = x'[t + 64*k], k < NX, yv[k] = y'[t + 64*k], k < NY (the rest of the
+// windows is zero padding, or -- y' beyond segLen + nDelay - 2 -- never meets a wanted lag)
+template <class In, int NX, int NY>
 __device__ __forceinline__ void bufload_seg_w(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, cf *v, cf *yv)
 {
+  static_assert((NX == 24 || NX == 32) && (NY == 28 || NY == 32), "");
   using B = BufLoad<In>;
   constexpr int STEP = 64 * B::STRIDE;
   constexpr int NV = (31 * STEP >> 12) + 1;
@@ -243,17 +245,19 @@ __device__ __forceinline__ void bufload_seg_w(const In &in, const RangePlan &p, 
   int vy[NV];
 #pragma unroll
   for (int j = 0; j < NV; j++) vy[j] = (s0 + p.delayMin + t) * B::STRIDE + j * 4096; // may be negative: reads as zero
-  typename B::raw xr[32], yr[32];
-  bufload_chan<In, STEP, 32, true>(xr, xd, vx);
-  bufload_chan<In, STEP, 32, false>(yr, yd, vy);
-  bufwait<48, 16>(xr);
-  bufwait<32, 16>(xr + 16);
+  typename B::raw xr[NX], yr[NY];
+  bufload_chan<In, STEP, NX, true>(xr, xd, vx);
+  bufload_chan<In, STEP, NY, false>(yr, yd, vy);
+  bufwait<NY + NX - 16, 16>(xr);
+  if constexpr (NX == 32) bufwait<NY, 16>(xr + 16);
+  else bufwait<NY, 8>(xr + 16);
 #pragma unroll
-  for (int k = 0; k < 32; k++) v[k] = B::cvt(xr[k]);
-  bufwait<16, 16>(yr);
-  bufwait<0, 16>(yr + 16);
+  for (int k = 0; k < NX; k++) v[k] = B::cvt(xr[k]);
+  bufwait<NY - 16, 16>(yr);
+  if constexpr (NY == 32) bufwait<0, 16>(yr + 16);
+  else { bufwait<4, 8>(yr + 16); bufwait<0, 4>(yr + 24); }
 #pragma unroll
-  for (int k = 0; k < 32; k++) yv[k] = B::cvt(yr[k]);
+  for (int k = 0; k < NY; k++) yv[k] = B::cvt(yr[k]);
 }
 
 // lags z[t + 64*c] of one pulse into the tiled range map: lane t owns position t & 15 of tile
@@ -287,7 +291,11 @@ __device__ __forceinline__ void store_lags_w(cf *out, const RangePlan &p, int cp
 #ifndef RANGEW_WAVES
 #define RANGEW_WAVES 8
 #endif
-template <class In>
+// SHORTW: windows short enough for the pruned form, segLen <= 24*64 and segLen + nDelay - 1 <= 28*64 (cfg 2:
+// x' has 1300 and y' needs 1709 of 2048 samples): x' = 0 from 24*64 on, y' is not needed from 28*64 on --
+// 12 of 64 loads are not issued and the first 32-point step of both transforms skips the zero inputs.
+// A template parameter, not a branch: both forms in one loop body spill.
+template <class In, bool SHORTW>
 __global__ __launch_bounds__(64 * RANGEW_WAVES, RANGEW_WAVES_PER_SIMD) void rangew_kernel(RangeArgs a, In in)
 {
   using W = WaveFft;
@@ -312,18 +320,19 @@ __global__ __launch_bounds__(64 * RANGEW_WAVES, RANGEW_WAVES_PER_SIMD) void rang
     for (int e = 0; e < 32; e++) acc[e] = cmake(0.f, 0.f);
     for (int s = 0; s < p.nSeg; s++) {
       cf v[32], yv[32];
+      constexpr int NX = SHORTW ? 24 : 32, NY = SHORTW ? 28 : 32;
       RW_T(0)
-      bufload_seg_w(in, p, base, s, t, v, yv);
+      bufload_seg_w<In, NX, NY>(in, p, base, s, t, v, yv);
 #ifdef RANGEW_TRACE
-      asm volatile("" : "+v"(v[0].x), "+v"(yv[31].y));
+      asm volatile("" : "+v"(v[0].x), "+v"(yv[NY - 1].y));
 #endif
       RW_T(1)
-      W::transform<-1>(t, v, w, X);  // v  = X spectrum
+      W::transform<-1, NX>(t, v, w, X);  // v  = X spectrum
 #ifdef RANGEW_TRACE
       asm volatile("" : "+v"(v[0].x));
 #endif
       RW_T(2)
-      W::transform<-1>(t, yv, w, X); // yv = Y spectrum
+      W::transform<-1, NY>(t, yv, w, X); // yv = Y spectrum
 #ifdef RANGEW_TRACE
       asm volatile("" : "+v"(yv[0].x));
 #endif
