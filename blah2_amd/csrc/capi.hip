@@ -293,7 +293,7 @@ bool use_wave_range(const blah2hip_amb_s *h)
 template <class In> int launch_rangew_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
 {
   const size_t lds = (size_t)(WaveFft::TW_ELEMS + RANGEW_WAVES * WaveFft::X_ELEMS) * sizeof(cf);
-  const bool shortw = a.plan.segLen <= 24 * 64 && a.plan.segLen + a.plan.nDelay - 1 <= 28 * 64;
+  const bool shortw = a.plan.segLen <= 24 * 64 && a.plan.segLen + a.plan.nDelay - 1 <= 28 * 64 && a.plan.nDelay <= 7 * 64;
   auto kern = shortw ? rangew_kernel<In, true> : rangew_kernel<In, false>;
   LDSCFG(kern, lds);
   const int grid = std::min<int>((a.nPulses + RANGEW_WAVES - 1) / RANGEW_WAVES, h->rangeGridCap);

@@ -68,6 +68,24 @@ template <int SIGN, int NZ = 32> B2_HD void dft32(cf *v)
   }
 }
 
+// 32-point DFT of which only the outputs v[0..6] are wanted (the inverse transform of a lag window of at
+// most 7*64 lags): the DFT over n0 reduces to the k0 = 0 sums for k1 = 0..6.  v[7..31] are left undefined.
+template <int SIGN> B2_HD void dft32_out7(cf *v)
+{
+  cf u[4][8];
+#pragma unroll
+  for (int n0 = 0; n0 < 4; n0++) {
+#pragma unroll
+    for (int n1 = 0; n1 < 8; n1++) u[n0][n1] = v[n0 + 4 * n1];
+    dft8<SIGN>(u[n0]); // -> u[n0][k1]
+  }
+  dft32_twiddles<SIGN, 1>(u[1]);
+  dft32_twiddles<SIGN, 2>(u[2]);
+  dft32_twiddles<SIGN, 3>(u[3]);
+#pragma unroll
+  for (int k1 = 0; k1 < 7; k1++) v[k1] = cadd(cadd(u[0][k1], u[2][k1]), cadd(u[1][k1], u[3][k1]));
+}
+
 struct WaveFft {
   static constexpr int F = 2048;
   static constexpr int L = 64;  // lanes
@@ -147,21 +165,22 @@ struct WaveFft {
       X[(q + 32) * P + t1] = u1;
     }
   }
-  // leaves out[t + 64*a] in v[a]
-  template <int SIGN> B2_HD static void s3(int t, cf *v, const cf *X)
+  // leaves out[t + 64*a] in v[a]; OUT7: only a < 7 (the rest of v is undefined)
+  template <int SIGN, bool OUT7 = false> B2_HD static void s3(int t, cf *v, const cf *X)
   {
 #pragma unroll
     for (int t1 = 0; t1 < 32; t1++) v[t1] = X[t * P + t1];
-    dft32<SIGN>(v);
+    if (OUT7) dft32_out7<SIGN>(v);
+    else dft32<SIGN>(v);
   }
 
 #if defined(__HIPCC__)
-  template <int SIGN, int NZ = 32> __device__ __forceinline__ static void transform(int t, cf *v, const Tw &w, cf *X)
+  template <int SIGN, int NZ = 32, bool OUT7 = false> __device__ __forceinline__ static void transform(int t, cf *v, const Tw &w, cf *X)
   {
     s1<SIGN, NZ>(v, w);
     sw(v);
     s2<SIGN>(t, v, w, X);
-    s3<SIGN>(t, v, X);
+    s3<SIGN, OUT7>(t, v, X);
   }
 #endif
 };

@@ -262,6 +262,7 @@ __device__ __forceinline__ void bufload_seg_w(const In &in, const RangePlan &p, 
 
 // lags z[t + 64*c] of one pulse into the tiled range map: lane t owns position t & 15 of tile
 // (t >> 4) + 4*c, so consecutive c are a constant stride apart
+template <int NC>
 __device__ __forceinline__ void store_lags_w(cf *out, const RangePlan &p, int cpi, int pulse, int t, const cf *v)
 {
   const int nTiles = (p.nDelay + 15) >> 4;
@@ -273,7 +274,7 @@ __device__ __forceinline__ void store_lags_w(cf *out, const RangePlan &p, int cp
   // pulse loop and live (spilled) across the whole kernel
   asm volatile("" : "+v"(rem), "+s"(nd));
 #pragma unroll
-  for (int c = 0; c < 32; c++) {
+  for (int c = 0; c < NC; c++) {
     if (64 * c >= nd) break; // wave-uniform
     if (64 * c < rem) *o = cmake(v[c].x * p.scale, v[c].y * p.scale);
     o += step;
@@ -294,7 +295,8 @@ __device__ __forceinline__ void store_lags_w(cf *out, const RangePlan &p, int cp
 // SHORTW: windows short enough for the pruned form, segLen <= 24*64 and segLen + nDelay - 1 <= 28*64 (cfg 2:
 // x' has 1300 and y' needs 1709 of 2048 samples): x' = 0 from 24*64 on, y' is not needed from 28*64 on --
 // 12 of 64 loads are not issued and the first 32-point step of both transforms skips the zero inputs.
-// A template parameter, not a branch: both forms in one loop body spill.
+// A template parameter, not a branch: both forms in one loop body spill.  The same instantiation (short
+// windows imply nDelay <= 7*64) computes only the 7 wanted outputs per lane of the inverse transform.
 template <class In, bool SHORTW>
 __global__ __launch_bounds__(64 * RANGEW_WAVES, RANGEW_WAVES_PER_SIMD) void rangew_kernel(RangeArgs a, In in)
 {
@@ -341,12 +343,12 @@ __global__ __launch_bounds__(64 * RANGEW_WAVES, RANGEW_WAVES_PER_SIMD) void rang
       for (int e = 0; e < 32; e++) acc[e] = cmacc(acc[e], yv[e], v[e]);
     }
     RW_T(0)
-    W::transform<+1>(t, acc, w, X);
+    W::template transform<+1, 32, SHORTW>(t, acc, w, X);
 #ifdef RANGEW_TRACE
     asm volatile("" : "+v"(acc[0].x));
 #endif
     RW_T(4)
-    store_lags_w(a.out, p, cpi, i, t, acc);
+    store_lags_w<SHORTW ? 7 : 32>(a.out, p, cpi, i, t, acc);
     RW_T(5)
   }
 #ifdef RANGEW_TRACE

@@ -231,7 +231,17 @@ int test_dft16_nz9()
     if (rep & 1) { dft16<+1>(a); dft16_nz9<+1>(b); } else { dft16<-1>(a); dft16_nz9<-1>(b); }
     for (int k = 0; k < 16; k++) err = std::max(err, (double)std::hypot(a[k].x - b[k].x, a[k].y - b[k].y));
   }
-  std::printf("NZ9 dft16 pruned_vs_full_abs_err=%.3e\n", err);
+  // dft32 with trailing zero inputs / with only the first seven outputs
+  for (int rep = 0; rep < 6; rep++) {
+    const int nz = rep < 2 ? 24 : (rep < 4 ? 28 : 32);
+    cf a[32], b[32];
+    for (int k = 0; k < 32; k++) a[k] = b[k] = k < nz ? cmake(dist(gen), dist(gen)) : cmake(0.f, 0.f);
+    for (int k = nz; k < 32; k++) b[k] = cmake(55.f, 66.f); // never read
+    dft32<-1>(a);
+    if (nz == 24) dft32<-1, 24>(b); else if (nz == 28) dft32<-1, 28>(b); else dft32_out7<-1>(b);
+    for (int k = 0; k < (nz == 32 ? 7 : 32); k++) err = std::max(err, (double)std::hypot(a[k].x - b[k].x, a[k].y - b[k].y));
+  }
+  std::printf("NZ9 dft16 / dft32 pruned_vs_full_abs_err=%.3e\n", err);
   return err < 1e-6 ? 0 : 1;
 }
 
