@@ -244,7 +244,7 @@ def main(argv=None):
 
     cfg, cfg_desc = CONFIGS[a.config]
     dmin, dmax, fmin, fmax, fs, n = cfg
-    B = a.batch if a.batch > 0 else ({"cfg3": 64 if a.chain == "full" else 32, "cfg5": 8, "small": 1024}.get(a.config, 128))
+    B = a.batch if a.batch > 0 else ({"cfg3": 128 if a.chain == "full" else 32, "cfg5": 8, "small": 1024}.get(a.config, 128))
     NS = max(1, a.streams) if a.chain == "amb" else 1
     ambs = [blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B, n_doppler_bins=a.n_doppler)
             for _ in range(NS)]

@@ -766,13 +766,17 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   case BLAH2HIP_DOP_TILE16: {
     const int ncol = which == BLAH2HIP_DOP_TILE16 ? 16 : 8;
     const int grid = (int)((nDelay + ncol - 1) / ncol);
-    const size_t lds = ((size_t)ncol * DOPT_PITCH + 1024) * sizeof(cf);
+    // persistent: the resident workgroups (LDS: one of 16 columns or two of 8 per CU) walk the tiles of the batch
     if (ncol == 16) {
+      const size_t lds = (size_t)dopt_lds_elems<16>() * sizeof(cf);
+      const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, h->numCU);
       LDSCFG(doppler_tile_kernel<16>, lds);
-      hipLaunchKernelGGL(doppler_tile_kernel<16>, dim3(grid, n_cpi), dim3(1024), lds, st, da);
+      hipLaunchKernelGGL(doppler_tile_kernel<16>, dim3(wgs), dim3(1024), lds, st, da, (int)n_cpi);
     } else {
+      const size_t lds = (size_t)dopt_lds_elems<8>() * sizeof(cf);
+      const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, 2 * h->numCU);
       LDSCFG(doppler_tile_kernel<8>, lds);
-      hipLaunchKernelGGL(doppler_tile_kernel<8>, dim3(grid, n_cpi), dim3(512), lds, st, da);
+      hipLaunchKernelGGL(doppler_tile_kernel<8>, dim3(wgs), dim3(512), lds, st, da, (int)n_cpi);
     }
     nPartsUsed = grid;
     break;

@@ -528,139 +528,178 @@ __global__ __launch_bounds__(16 * R3) void doppler_fft_kernel(DopplerArgs a)
 // 128-byte-stride gathers/scatters of doppler_fft_kernel, which spent 57 % of
 // its wave cycles waiting on memory (profiles/r01_pmc.csv).
 constexpr int DOPT_PITCH = WgFft<4>::A_ELEMS + 1; // 1089: odd pitch -> 16 columns hit 16 different bank pairs
+constexpr int DOPT_CHIRP = 264;                    // HALF the chirp: c[nD - n] = (-1)^nD c[n], n <= nD/2 <= 256
+template <int NCOL> constexpr int dopt_lds_elems() { return NCOL * DOPT_PITCH + 1024 + DOPT_CHIRP; }
 
-// NCOL = 16: whole 128-byte lines per row, 139 KB of LDS, one workgroup per CU;
+__device__ __forceinline__ int relaunder(int v);
+
+// NCOL = 16: whole 128-byte lines per row, 147 KB of LDS, one workgroup per CU;
 // NCOL = 8: half lines (the sibling workgroup takes the other half out of L2),
-// 70 KB, two workgroups per CU so that one's memory phases overlap the other's math.
+// 75 KB, two workgroups per CU so that one's memory phases overlap the other's math.
+// Workgroups are PERSISTENT (grid = resident workgroups, each walks its tiles): twiddles (31
+// gathered loads per thread), chirp and kernel spectrum are set up once per workgroup instead of
+// once per tile, the next tile's loads are issued as soon as this tile's column is in registers and
+// land during the transforms, and a tile's row stores drain while the next tile is filled.  The
+// kernel spectrum and the chirp live in LDS (nothing queues behind the tile loads: loads return
+// in order; the chirp as its first half only -- exp(-i pi n^2/nD) at nD - n is (-1)^nD times its value
+// at n -- because two 8-column workgroups per CU leave 3.8 KB), per-phase address arithmetic is
+// recomputed instead of carried across the loop.
 template <int NCOL>
-__global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a)
+__global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a, int nCpi)
 {
   using W = WgFft<4>;
   constexpr int T = 64;
   constexpr int NR = 9; // nD <= 513: rows t + 64*k, k < 9, are the only ones that exist
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double wsum[16];
+  __shared__ float wmax[16];
   cf *lds = reinterpret_cast<cf *>(smem);
   const int tid = threadIdx.x;
   const int w = tid >> 6, t = tid & 63; // wave = column of the tile
   const int nD = a.nD;
   constexpr int NT = 64 * NCOL;     // threads
   constexpr int SH = (NCOL == 16) ? 4 : 3;
-  const int sub = blockIdx.x, cpi = blockIdx.y; // sub-tile of NCOL columns
-  const int col0 = sub * NCOL;
   cf *region = lds + w * DOPT_PITCH;
-
-  // phase 1: coalesced tile read (all loads in flight before the first use),
-  // transposed into the per-column regions
-  const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, col0);
-  const int cells = nD * NCOL;
-  cf v[16];
-#pragma unroll
-  for (int j = 0; j < NR; j++) {
-    const int idx = tid + NT * j;
-    const int c = idx & (NCOL - 1), row = idx >> SH;
-    v[j] = Rt[idx < cells ? row * 16 + c : 0];
-  }
-  // tables while the tile is in flight; the kernel spectrum goes to LDS (16 more
-  // live registers would serialise its 16 loads behind one another)
   cf *bfL = lds + NCOL * DOPT_PITCH;
-  cf bfs[1024 / NT];
+  cf *chirpL = bfL + 1024;
+  const int tilesPerCpi = (a.nDelay + NCOL - 1) / NCOL;
+  const int nTilesAll = tilesPerCpi * nCpi;
+  const int cells = nD * NCOL;
+
+  // once per workgroup: tables
 #pragma unroll
-  for (int j = 0; j < 1024 / NT; j++) bfs[j] = a.bf[tid + NT * j];
-  cf tw1[15], tw3[16], ch[NR];
+  for (int j = 0; j < 1024 / NT; j++) bfL[tid + NT * j] = a.bf[tid + NT * j];
+  for (int i = tid; i < DOPT_CHIRP; i += NT) chirpL[i] = a.chirp[min(i, nD - 1)];
+  const float csign = (nD & 1) ? -1.f : 1.f;
+  // chirp value of row n < nD from the half table
+  auto chirp_at = [&](int n) {
+    const bool hi = 2 * n > nD;
+    const cf c = chirpL[hi ? nD - n : n];
+    return cmake(hi ? csign * c.x : c.x, hi ? csign * c.y : c.y);
+  };
+  cf tw1[15], tw3[16];
   W::load_twiddles(t, a.tw, tw1, tw3);
-#pragma unroll
-  for (int k = 0; k < NR; k++) ch[k] = a.chirp[min(t + T * k, nD - 1)];
-#pragma unroll
-  for (int j = 0; j < NR; j++) {
-    const int idx = tid + NT * j;
-    const int c = idx & (NCOL - 1), row = idx >> SH;
-    if (idx < cells) lds[c * DOPT_PITCH + row] = v[j];
-  }
-#pragma unroll
-  for (int j = 0; j < 1024 / NT; j++) bfL[tid + NT * j] = bfs[j];
-  __syncthreads();
 
-  // phase 2: this wave's column -> registers (DC removal + chirp), then the transform
-  const cf r0 = region[0];
+  // coalesced read of one (half) tile: all loads in flight before the first use
+  cf nt[NR];
+  auto tile_load = [&](int it) {
+    const int cpi = it / tilesPerCpi, sub = it - cpi * tilesPerCpi;
+    const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, sub * NCOL);
+    const int tl = relaunder(tid);
 #pragma unroll
-  for (int k = 0; k < NR; k++) {
-    const int i = t + T * k;
-    const cf rv = region[min(i, nD - 1)];
-    const cf p = cmul(csub(rv, r0), ch[k]);
-    v[k] = cmake(i < nD ? p.x : 0.f, i < nD ? p.y : 0.f);
-  }
+    for (int j = 0; j < NR; j++) {
+      const int idx = tl + NT * j;
+      const int c = idx & (NCOL - 1), row = idx >> SH;
+      nt[j] = Rt[idx < cells ? row * 16 + c : 0];
+    }
+  };
+  int it = blockIdx.x;
+  if (it < nTilesAll) tile_load(it);
+  for (; it < nTilesAll; it += gridDim.x) {
+    const int cpi = it / tilesPerCpi, sub = it - cpi * tilesPerCpi;
+    const int col0 = sub * NCOL;
+    // phase 1: the tile, transposed into the per-column regions
+    {
+      const int tl = relaunder(tid);
 #pragma unroll
-  for (int k = NR; k < 16; k++) v[k] = cmake(0.f, 0.f);
-  // from here on `region` is this wave's private exchange buffer (A and B alias:
-  // a single wave's LDS operations execute in order)
-  // __builtin_amdgcn_wave_barrier(): no instruction, only stops the compiler from
-  // moving LDS accesses of different lanes' data across the stage boundaries
-  __builtin_amdgcn_wave_barrier();
-  W::fwd_s1(t, v, tw1, region);
-  __builtin_amdgcn_wave_barrier();
-  W::fwd_s2_load(t, v, region);
-  __builtin_amdgcn_wave_barrier();
-  dft16<-1>(v);
-  W::fwd_s2_store(t, v, region);
-  __builtin_amdgcn_wave_barrier();
-  W::fwd_s3(t, v, tw3, region);
-#pragma unroll
-  for (int e = 0; e < 16; e++) v[e] = cmul(v[e], bfL[e * T + t]);
-  __builtin_amdgcn_wave_barrier();
-  W::inv_s1(t, v, tw3, region);
-  __builtin_amdgcn_wave_barrier();
-  W::inv_s2_load(t, v, region);
-  __builtin_amdgcn_wave_barrier();
-  dft16<+1>(v);
-  W::inv_s2_store(t, v, region);
-  __builtin_amdgcn_wave_barrier();
-  W::inv_s3(t, v, tw1, region);
-  __builtin_amdgcn_wave_barrier();
+      for (int j = 0; j < NR; j++) {
+        const int idx = tl + NT * j;
+        const int c = idx & (NCOL - 1), row = idx >> SH;
+        if (idx < cells) lds[c * DOPT_PITCH + row] = nt[j];
+      }
+    }
+    __syncthreads();
 
-  // phase 3: rotate rows by nD/2+1 and park the column back in its region
+    // phase 2: this wave's column -> registers (DC removal + chirp), next tile's loads, then the
+    // transform.  From here on `region` is this wave's private exchange buffer (A and B alias: a
+    // single wave's LDS operations execute in order; __builtin_amdgcn_wave_barrier() is no
+    // instruction, it only stops the compiler from moving LDS accesses across the stage boundaries)
+    cf v[16];
+    const cf r0 = region[0];
+    {
+      const int t2 = relaunder(t);
 #pragma unroll
-  for (int c = 0; c < NR; c++) {
-    const int k = t + T * c;
-    cf d = cmul(v[c], ch[c]);
-    if (c == 0 && t == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
-    int o = k - (nD / 2 + 1);
-    if (o < 0) o += nD;
-    if (k < nD) region[o] = d;
-  }
-  __syncthreads();
+      for (int k = 0; k < NR; k++) {
+        const int i = t2 + T * k;
+        const cf rv = region[min(i, nD - 1)];
+        const cf p = cmul(csub(rv, r0), chirp_at(min(i, nD - 1)));
+        v[k] = cmake(i < nD ? p.x : 0.f, i < nD ? p.y : 0.f);
+      }
+    }
+#pragma unroll
+    for (int k = NR; k < 16; k++) v[k] = cmake(0.f, 0.f);
+    if (it + (int)gridDim.x < nTilesAll) tile_load(it + gridDim.x);
+    __builtin_amdgcn_wave_barrier();
+    W::fwd_s1(t, v, tw1, region);
+    __builtin_amdgcn_wave_barrier();
+    W::fwd_s2_load(t, v, region);
+    __builtin_amdgcn_wave_barrier();
+    dft16<-1>(v);
+    W::fwd_s2_store(t, v, region);
+    __builtin_amdgcn_wave_barrier();
+    W::fwd_s3(t, v, tw3, region);
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = cmul(v[e], bfL[e * T + t]);
+    __builtin_amdgcn_wave_barrier();
+    W::inv_s1(t, v, tw3, region);
+    __builtin_amdgcn_wave_barrier();
+    W::inv_s2_load(t, v, region);
+    __builtin_amdgcn_wave_barrier();
+    dft16<+1>(v);
+    W::inv_s2_store(t, v, region);
+    __builtin_amdgcn_wave_barrier();
+    W::inv_s3(t, v, tw1, region);
+    __builtin_amdgcn_wave_barrier();
 
-  // phase 4: coalesced row-segment stores + Map::set_metrics partials
-  double lsum = 0.0;
-  float lmax = 0.f;
-  cf *mapb = a.map + (size_t)cpi * nD * a.nDelay + col0;
-  const int ncol = min(NCOL, a.nDelay - col0);
+    // phase 3: rotate rows by nD/2+1 and park the column back in its region
+    {
+      const int t3 = relaunder(t);
 #pragma unroll
-  for (int j = 0; j < NR; j++) {
-    const int idx = tid + NT * j;
-    const int c = idx & (NCOL - 1), o = idx >> SH;
-    const bool ok = idx < cells && c < ncol;
-    const cf d = lds[c * DOPT_PITCH + min(o, nD - 1)];
-    if (ok) mapb[(size_t)o * a.nDelay + c] = d;
-    const float db = db_of(d);
-    lsum += ok ? (double)db : 0.0;
-    lmax = ok ? fmaxf(lmax, db) : lmax;
-  }
-  const size_t part = (size_t)cpi * gridDim.x + blockIdx.x;
-  __shared__ double wsum[16];
-  __shared__ float wmax[16];
+      for (int c = 0; c < NR; c++) {
+        const int k = t3 + T * c;
+        cf d = cmul(v[c], chirp_at(min(k, nD - 1)));
+        if (c == 0 && t3 == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
+        int o = k - (nD / 2 + 1);
+        if (o < 0) o += nD;
+        region[k < nD ? o : DOPT_PITCH - 1] = d; // rows beyond nD go to a spare slot: no branch per row
+      }
+    }
+    __syncthreads();
+
+    // phase 4: coalesced row-segment stores + Map::set_metrics partials
+    double lsum = 0.0;
+    float lmax = 0.f;
+    cf *mapb = a.map + (size_t)cpi * nD * a.nDelay + col0;
+    const int ncol = min(NCOL, a.nDelay - col0);
+    {
+      const int tl = relaunder(tid);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    lsum += __shfl_xor(lsum, off);
-    lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-  }
-  if (t == 0) { wsum[w] = lsum; wmax[w] = lmax; }
-  __syncthreads();
-  if (tid == 0) {
-    double sacc = 0.0;
-    float m = 0.f; // Map.cpp:193: the running max starts at 0
-    for (int i = 0; i < NCOL; i++) { sacc += wsum[i]; m = fmaxf(m, wmax[i]); }
-    a.partSum[part] = sacc;
-    a.partMax[part] = m;
+      for (int j = 0; j < NR; j++) {
+        const int idx = tl + NT * j;
+        const int c = idx & (NCOL - 1), o = idx >> SH;
+        const bool ok = idx < cells && c < ncol;
+        const cf d = lds[c * DOPT_PITCH + min(o, nD - 1)];
+        if (ok) mapb[(size_t)o * a.nDelay + c] = d;
+        const float db = db_of(d);
+        lsum += ok ? (double)db : 0.0;
+        lmax = ok ? fmaxf(lmax, db) : lmax;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lsum += __shfl_xor(lsum, off);
+      lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    }
+    if (t == 0) { const int wl = relaunder(tid) >> 6; wsum[wl] = lsum; wmax[wl] = lmax; }
+    __syncthreads(); // also: every thread has taken its rows out of the regions
+    if (tid == 0) {
+      double sacc = 0.0;
+      float m = 0.f; // Map.cpp:193: the running max starts at 0
+      for (int i = 0; i < NCOL; i++) { sacc += wsum[i]; m = fmaxf(m, wmax[i]); }
+      const size_t part = (size_t)cpi * tilesPerCpi + sub;
+      a.partSum[part] = sacc;
+      a.partMax[part] = m;
+    }
   }
 }
 
@@ -675,7 +714,6 @@ __global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a)
 // (natural order, 16 KB, shared by every workgroup) comes from L2 right before its use.
 // Replaces doppler_tilem_kernel<8> (two-wave columns, workgroup barriers at every stage, one tile
 // per workgroup) in the automatic choice; numbers in DESIGN.md.
-__device__ __forceinline__ int relaunder(int v);
 constexpr int DOPW_NCOL = 8;
 constexpr int DOPW_MAX_ND = 1025;
 // region stride = 2 (mod 8): the transposing accesses of phases 1 and 4 (a 16-lane group touches 4

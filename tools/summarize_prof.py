@@ -26,14 +26,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 
-KERNELS = ("rangew_kernel", "range8_kernel", "range_kernel", "doppler_tilem_kernel", "doppler_tile_kernel", "doppler_fft_kernel",
+KERNELS = ("rangew_kernel", "range8_kernel", "range_kernel", "doppler_tilew_kernel", "doppler_tilem_kernel", "doppler_tile_kernel", "doppler_fft_kernel",
            "doppler_dft_kernel", "metrics_kernel", "cfar1d_kernel", "cfar2d_kernel", "sat_rows_kernel", "sat_cols_kernel",
            "rotate_kernel", "clutter_corr_half_kernel", "clutter_corr_kernel", "clutter_fir_kernel", "clutter_solve_kernel", "clutter_reduce_kernel",
            "db_map_kernel", "cal_")
 
 
 # kernels whose global reads are 64-byte (or shorter) pieces of 128-byte lines
-HALF_LINE_READERS = ("doppler_tile_kernel", "doppler_tilem_kernel")
+HALF_LINE_READERS = ("doppler_tile_kernel", "doppler_tilem_kernel", "doppler_tilew_kernel")
 
 
 def short(name):
