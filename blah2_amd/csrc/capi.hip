@@ -70,8 +70,8 @@ struct blah2hip_amb_s {
   std::vector<double> dopplerAxis;
   hipStream_t stream = nullptr;
   int numCU = 256;
-  int rangeGridCap = 1024, rangeGridDefault = 1024;
-  size_t rangeLds = 0;
+  int rangeGridForce = 0;           // BLAH2HIP_OPT_RANGE_GRID (0 = the launched kernel's residency)
+  int rangeGridLast = 0;            // BLAH2HIP_INFO_RANGE_GRID: workgroup cap of the last launch
   void *h_pin = nullptr;            // pinned host staging of the c64 entry point
   size_t h_pin_bytes = 0;
 
@@ -257,13 +257,33 @@ template <int R3> int launch_doppler_t(blah2hip_amb_s *h, const DopplerArgs &a, 
   return BLAH2HIP_OK;
 }
 
+// F = 2048 runs on the one-wave kernel (measured, round 2, cfg 2 x 128 on one box, steady clocks:
+// 1.329 vs 1.385 ms per step of the whole chain) once a launch has a pulse for every wave slot of the
+// chip; smaller launches -- a single CPI of the real-time path: 513 pulses -- keep the workgroup
+// kernel, where two waves share a pulse (one CPI: range 22.7 vs 34.7 us).
+bool use_wave_range(const blah2hip_amb_s *h, int nPulses)
+{
+  if (h->r3 != 8 || h->rangeKernel == BLAH2HIP_RANGE_E16) return false;
+  if (h->rangeKernel == BLAH2HIP_RANGE_WAVE) return true;
+  return nPulses >= 4 * RANGEW_WAVES_PER_SIMD * h->numCU;
+}
+
+// Workgroups of a range kernel that fit a CU (LDS and registers): the grid of a launch is capped
+// there and the kernel walks the pulses with a grid stride.
+int range_grid_cap(blah2hip_amb_s *h, size_t lds, int wavesPerWg, int wavesPerCU)
+{
+  const int perCU = std::max(1, std::min((int)((160 * 1024) / lds), wavesPerCU / std::max(1, wavesPerWg)));
+  h->rangeGridLast = h->rangeGridForce ? h->rangeGridForce : perCU * h->numCU;
+  return h->rangeGridLast;
+}
+
 template <int R3, class In> int launch_range_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
 {
   using W = WgFft<R3>;
   const size_t lds = (size_t)(W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
   auto kern = range_kernel<R3, In>;
   LDSCFG(kern, lds);
-  const int grid = std::min<int>(a.nPulses, h->rangeGridCap);
+  const int grid = std::min<int>(a.nPulses, range_grid_cap(h, lds, R3 / 4, 8)); // 196-230 VGPRs: 2 waves per SIMD
   hipLaunchKernelGGL(kern, dim3(grid), dim3(W::T), lds, st, a, in);
   HIPCHK(hipGetLastError());
   h->lastRange = BLAH2HIP_RANGE_E16;
@@ -276,18 +296,11 @@ template <int R4, class In> int launch_range8_t(blah2hip_amb_s *h, const RangeAr
   const size_t lds = (size_t)2 * W::BUF_ELEMS * sizeof(cf);
   auto kern = range8_kernel<R4, In>;
   LDSCFG(kern, lds);
-  const int grid = std::min<int>(a.nPulses, h->rangeGridCap);
+  const int grid = std::min<int>(a.nPulses, range_grid_cap(h, lds, R4, 4 * RANGE8_WAVES_PER_SIMD));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(W::T), lds, st, a, in);
   HIPCHK(hipGetLastError());
   h->lastRange = BLAH2HIP_RANGE_E8;
   return BLAH2HIP_OK;
-}
-
-// F = 2048 runs on the one-wave kernel unless the workgroup kernel is asked for (measured, round 2,
-// cfg 2 x 128 on one box, steady clocks: 1.329 vs 1.385 ms per step of the whole chain).
-bool use_wave_range(const blah2hip_amb_s *h)
-{
-  return h->r3 == 8 && h->rangeKernel != BLAH2HIP_RANGE_E16;
 }
 
 template <class In> int launch_rangew_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
@@ -296,7 +309,7 @@ template <class In> int launch_rangew_t(blah2hip_amb_s *h, const RangeArgs &a, I
   const bool shortw = a.plan.segLen <= 24 * 64 && a.plan.segLen + a.plan.nDelay - 1 <= 28 * 64 && a.plan.nDelay <= 7 * 64;
   auto kern = shortw ? rangew_kernel<In, true> : rangew_kernel<In, false>;
   LDSCFG(kern, lds);
-  const int grid = std::min<int>((a.nPulses + RANGEW_WAVES - 1) / RANGEW_WAVES, h->rangeGridCap);
+  const int grid = std::min<int>((a.nPulses + RANGEW_WAVES - 1) / RANGEW_WAVES, range_grid_cap(h, lds, RANGEW_WAVES, 4 * RANGEW_WAVES_PER_SIMD));
 #ifdef RANGEW_TRACE
   static uint64_t *dbg = nullptr;
   static int calls = 0;
@@ -332,7 +345,7 @@ template <class In> int launch_rangew_t(blah2hip_amb_s *h, const RangeArgs &a, I
 // (radix 8-8-8-4 twiddles + the lane butterflies) and the kernel follows that count, not its occupancy.
 template <class In> int launch_range(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
 {
-  if (use_wave_range(h)) return launch_rangew_t(h, a, in, st);
+  if (use_wave_range(h, a.nPulses)) return launch_rangew_t(h, a, in, st);
   switch (h->r3) {
   case 4: return launch_range8_t<2>(h, a, in, st);
   case 8: return launch_range_t<8>(h, a, in, st);
@@ -370,31 +383,6 @@ int host_tail(blah2hip_amb_s *h, float *map_out, double *metrics)
   if (metrics) HIPCHK(hipMemcpyAsync(metrics, h->d_metrics, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return BLAH2HIP_OK;
-}
-
-// Workgroups of the range kernel that fit a CU (LDS and registers): the grid of a launch is capped
-// there and the kernel walks the pulses with a grid stride.
-void set_range_residency(blah2hip_amb_s *h)
-{
-  const bool e8 = h->r3 == 4;
-  size_t lds;
-  int waves, wavesPerCU;
-  if (use_wave_range(h)) {
-    lds = (size_t)(WaveFft::TW_ELEMS + RANGEW_WAVES * WaveFft::X_ELEMS) * sizeof(cf);
-    waves = RANGEW_WAVES;
-    wavesPerCU = 4 * RANGEW_WAVES_PER_SIMD;
-  } else if (e8) {
-    lds = (size_t)2 * WgFft8<2>::BUF_ELEMS * sizeof(cf);
-    waves = h->r3 / 2;  // F/8 threads
-    wavesPerCU = 4 * RANGE8_WAVES_PER_SIMD; // the kernel's register cap: 4 waves per SIMD at <= 128 VGPRs
-  } else {
-    lds = (size_t)(h->r3 == 8 ? WgFft<8>::A_ELEMS + WgFft<8>::B_ELEMS : WgFft<16>::A_ELEMS + WgFft<16>::B_ELEMS) * sizeof(cf);
-    waves = h->r3 / 4;  // F/16 threads
-    wavesPerCU = 8;     // 230-247 VGPRs: 2 waves per SIMD
-  }
-  h->rangeLds = lds;
-  const int perCU = std::max(1, std::min((int)((160 * 1024) / lds), wavesPerCU / std::max(1, waves)));
-  h->rangeGridCap = h->rangeGridDefault = perCU * h->numCU;
 }
 
 // Which Doppler kernel a launch of n_cpi CPIs runs.  The tile kernels (coalesced tile
@@ -542,7 +530,6 @@ int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler
 
   const uint32_t nD = h->dims.n_doppler_bins, nDelay = h->dims.n_delay_bins;
   const int F = h->dims.fft_len;
-  set_range_residency(h);
 
   std::vector<cf> tw(F);
   for (int k = 0; k < F; k++) tw[k] = root_of_unity(k, F);
@@ -645,7 +632,7 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
     return BLAH2HIP_OK;
   case BLAH2HIP_OPT_RANGE_GRID:
     if (value < 0 || value > (1 << 20)) return fail(BLAH2HIP_ERR_INVALID, "range grid outside [0, 2^20]");
-    h->rangeGridCap = value ? (int)value : h->rangeGridDefault;
+    h->rangeGridForce = (int)value;
     return BLAH2HIP_OK;
   case BLAH2HIP_OPT_RANGE_KERNEL:
     if (value != 0 && value != BLAH2HIP_RANGE_WAVE && value != BLAH2HIP_RANGE_E16)
@@ -655,7 +642,6 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
     if (value == BLAH2HIP_RANGE_E16 && h->r3 == 4)
       return fail(BLAH2HIP_ERR_UNSUPPORTED, "F = 1024 runs on the 8-points-per-thread kernel only");
     h->rangeKernel = (int)value;
-    set_range_residency(h);
     return BLAH2HIP_OK;
   default: return fail(BLAH2HIP_ERR_INVALID, "unknown option");
   }
@@ -668,7 +654,7 @@ int blah2hip_amb_get_info(blah2hip_amb_t h, int key, int64_t *value)
   case BLAH2HIP_INFO_LAST_DOPPLER_KERNEL: *value = h->lastDoppler; return BLAH2HIP_OK;
   case BLAH2HIP_INFO_LAST_RANGE_KERNEL: *value = h->lastRange; return BLAH2HIP_OK;
   case BLAH2HIP_INFO_DOPPLER_FFT_LEN: *value = 256 * h->dopR3; return BLAH2HIP_OK;
-  case BLAH2HIP_INFO_RANGE_GRID: *value = h->rangeGridCap; return BLAH2HIP_OK;
+  case BLAH2HIP_INFO_RANGE_GRID: *value = h->rangeGridLast; return BLAH2HIP_OK;
   case BLAH2HIP_INFO_NUM_CU: *value = h->numCU; return BLAH2HIP_OK;
   default: return fail(BLAH2HIP_ERR_INVALID, "unknown info key");
   }

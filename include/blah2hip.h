@@ -124,9 +124,10 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 
 /* Execution plan, per handle.  Options take effect on the next process call. */
 #define BLAH2HIP_OPT_DOPPLER_KERNEL 1 /* BLAH2HIP_DOP_*; AUTO picks by launch size */
-#define BLAH2HIP_OPT_RANGE_GRID 2     /* workgroups of the range kernel; 0 = residency default */
-#define BLAH2HIP_OPT_RANGE_KERNEL 3   /* 0 = by transform length (F = 1024: E8, 2048: WAVE, 4096: E16); BLAH2HIP_RANGE_E16 forces the
-                                       * workgroup kernel at F = 2048, BLAH2HIP_RANGE_WAVE is the default there */
+#define BLAH2HIP_OPT_RANGE_GRID 2     /* workgroups of the range kernel; 0 = the launched kernel's residency */
+#define BLAH2HIP_OPT_RANGE_KERNEL 3   /* 0 = by transform length and launch size (F = 1024: E8; 4096: E16; 2048: WAVE once a launch
+                                       * has a pulse per wave slot of the chip -- 8 x CUs -- else E16, e.g. a single CPI);
+                                       * BLAH2HIP_RANGE_E16 / BLAH2HIP_RANGE_WAVE force one of the two at F = 2048 */
 #define BLAH2HIP_DOP_AUTO 0
 #define BLAH2HIP_DOP_TILE8 1   /* nD <= 513: 8-column tiles, one wave per column */
 #define BLAH2HIP_DOP_TILE16 2  /* nD <= 513: 16-column tiles */

@@ -83,7 +83,9 @@ def test_cfg2_batched_takes_the_tile_kernel(b2, B):
     amb = run_batch(b2, CFG2, B, "auto", seeds=range(40, 40 + B), expect="tile8")
     assert (amb.get_n_doppler_bins(), amb.get_n_delay_bins(), amb.dims.fft_len) == (513, 411, 2048)
     from blah2_amd import _lib
-    assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE  # the default at F = 2048
+    # F = 2048: the one-wave kernel once the launch has a pulse per wave slot (8 per CU), else the workgroup kernel
+    full = B * 513 >= 8 * amb.info(_lib.INFO_NUM_CU)
+    assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == (_lib.RANGE_WAVE if full else _lib.RANGE_E16)
 
 
 @pytest.mark.parametrize("fmt", ["c32", "i16"])
@@ -158,11 +160,12 @@ def test_auto_rule_small_launch_keeps_the_column_kernel(b2):
         amb.set_doppler_kernel("tilem")
 
 
-@pytest.mark.parametrize("geom,fft_len,kernel", [(CFG2, 2048, "wave"), ((-24, 2023, -64, 64, 1_260_000, 1_260_000), 4096, "e16"),
+@pytest.mark.parametrize("geom,fft_len,kernel", [(CFG2, 2048, "e16"), ((-24, 2023, -64, 64, 1_260_000, 1_260_000), 4096, "e16"),
                                                   ((-10, 100, -100, 100, 1_000_000, 100_000), 1024, "e8")])
 def test_range_kernel_of_every_transform_length_batched(b2, geom, fft_len, kernel):
     """F = 1024 -> the 8-point-per-thread kernel whose last transform stage runs across lanes (DPP),
-    F = 2048 -> the one-wave kernel, F = 4096 -> the 16-point workgroup kernel; two distinct CPIs per launch."""
+    F = 2048 / 4096 -> the 16-point workgroup kernel (two CPIs are below the launch size at which F = 2048
+    switches to the one-wave kernel); two distinct CPIs per launch."""
     from blah2_amd import _lib
     amb = run_batch(b2, geom, 2, "auto", seeds=(5, 6), expect=_expected_doppler(b2, geom),
                     targets=((37, -13.0, 0.05),), cell_tol=2e-4)
