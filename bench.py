@@ -347,6 +347,12 @@ def main(argv=None):
 
     # second, identical region with every kernel bracketed by HIP events on the
     # launch stream: per-kernel durations for the roofline line
+    # (the device idled while the maps above were copied out: ramp the clock up again first, see --prewarm-s)
+    t_pre = time.perf_counter()
+    while a.prewarm_s > 0 and time.perf_counter() - t_pre < 0.5 * a.prewarm_s:
+        for i in range(4):
+            step(a.warmup + i)
+        torch.cuda.synchronize()
     for h_ in ambs:
         h_.set_timing(True)
     if wh is not None:

@@ -410,7 +410,10 @@ int pick_doppler(const blah2hip_amb_s *h, uint32_t n_cpi)
   const int ncol = h->dopR3 == 4 ? 8 : (h->dopR3 == 8 ? DopM<8>::NCOL : DopM<16>::NCOL);
   const int tiles = (nDelay + ncol - 1) / ncol;
   const bool fills = (int)n_cpi * tiles >= h->numCU / 2;
-  if (fills && h->dopR3 == 4) return BLAH2HIP_DOP_TILE8; // 8 columns x 2 workgroups per CU beat 16 x 1 (57 vs 74 us per 32 CPIs)
+  // nD <= 513: whole 16-column tiles (128-byte row pieces, one persistent workgroup per CU) once a launch has
+  // a tile per CU (cfg 2 x 128: 1.49 vs 1.59 us/CPI); 8-column half tiles, two workgroups per CU, below
+  if (h->dopR3 == 4 && (int)n_cpi * ((nDelay + 15) / 16) >= h->numCU) return BLAH2HIP_DOP_TILE16;
+  if (fills && h->dopR3 == 4) return BLAH2HIP_DOP_TILE8;
   if (fills && doppler_kernel_applicable(h, BLAH2HIP_DOP_TILEW)) return BLAH2HIP_DOP_TILEW;
   if (fills && doppler_kernel_applicable(h, BLAH2HIP_DOP_TILEM)) return BLAH2HIP_DOP_TILEM;
   return BLAH2HIP_DOP_COLUMN;

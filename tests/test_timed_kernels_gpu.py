@@ -177,7 +177,9 @@ def _expected_doppler(b2, geom):
     # what the launch-size rule picks for two CPIs of this geometry (asserted inside run_batch)
     dmin, dmax, fmin, fmax, fs, n = geom
     d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
-    if d.n_doppler_bins <= 513:
+    if d.n_doppler_bins <= 513:  # 256 CUs: whole tiles from one per CU on, half tiles from one per two CUs
+        if 2 * -(-d.n_delay_bins // 16) >= 256:
+            return "tile16"
         return "tile8" if 2 * -(-d.n_delay_bins // 8) >= 128 else "column"
     if d.n_doppler_bins <= 1025:
         return "tilew" if 2 * -(-d.n_delay_bins // 8) >= 128 else "column"
