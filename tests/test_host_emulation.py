@@ -21,6 +21,9 @@ def test_workgroup_fft_forward_inverse(emu):
     out = subprocess.run([emu, "fft"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("E8 R4=") == 3 and out.stdout.count("R3=") == 3
+    # the one-wave 2048-point transform (32 points per lane, lane exchange emulated on lane pairs) and the
+    # pruned 16- / 32-point kernels of the zero-padded segments
+    assert "WAVE F=2048" in out.stdout and "pruned_vs_full_abs_err=0.000e+00" in out.stdout
 
 
 # (R3, nCorr, nDoppler, delayMin, delayMax, nSeg, segLen)
