@@ -337,7 +337,7 @@ template <class In> int launch_rangew_t(blah2hip_amb_s *h, const RangeArgs &a, I
 
 // F = 1024: 8 points per thread (one-wave transforms: 10.5 vs 14.3 us/CPI at cfg 2 with 16 points per
 // thread); F = 2048 / 4096: 16 points per thread (10.0 vs 10.3 us/CPI; equal at 4096).  Measured, round 1.
-// F = 1024: 8 points per thread with stage 4 across lanes (4 waves per SIMD); F = 2048 / 4096: 16 points
+// F = 1024: 8 points per thread with stage 4 across lanes (3 waves per SIMD); F = 2048 / 4096: 16 points
 // per thread.  Measured in round 2 (range kernel, us per launch): F = 1024 (tests/golden `medium`
 // geometry x 1024 CPIs) 362 with the lane form, 446 with the LDS form of stage 4 it replaced;
 // F = 2048 (cfg 2 x 128): 16-point 1192, 8-point lane form 1363-1372 (4 or 3 waves per SIMD); F = 4096

@@ -37,8 +37,10 @@ namespace blah2 {
 // HBM traffic per pulse: 2*nCorr*8 B in (C32) or nCorr*8 B in (I16), nDelay*8 B out.
 // LDS: A and B exchange buffers, (16*PA + 16*PB)*8 B  (19 KB / 36 KB / 70 KB for
 // F = 1024 / 2048 / 4096).
+// 3 waves per SIMD: 138 VGPRs, no scratch; at 4 (128 VGPRs) the kernel spills 14-16 registers for the
+// same speed (measured, `small` config: 1.55 M vs 1.53 M CPIs/s)
 #ifndef RANGE8_WAVES_PER_SIMD
-#define RANGE8_WAVES_PER_SIMD 4
+#define RANGE8_WAVES_PER_SIMD 3
 #endif
 struct RangeArgs {
   RangePlan plan;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
 
 // --------------------------------------------------------------------------
 // Range kernel on the 8-points-per-thread transform (fft_wg8.hpp): identical mathematics and
-// interface, T = F/8 threads per pulse, half the registers per thread (4 waves per SIMD).  Stage 4 of
+// interface, T = F/8 threads per pulse, half the registers per thread (3 waves per SIMD, see RANGE8_WAVES_PER_SIMD).  Stage 4 of
 // the transform runs across lanes (fwd_s3_lanes / inv_s4_lanes), so a transform has two LDS exchanges
 // and two barriers.  Buffer schedule (A = E1 layout, B = E2 layout, every transform the same):
 //   forward  s1 -> A | barrier | s2: A -> B | barrier | s3 + s4: B -> registers
@@ -961,7 +963,7 @@ __global__ __launch_bounds__(1024) void doppler_tilem_kernel(DopplerArgs a)
   // R3 = 16 carries 15 stage-3 twiddles (7 for R3 = 8) and would spill at the 128 VGPRs a
   // 1024-thread workgroup leaves: there each twiddle set and the chirp are fetched (L1/L2)
   // right before the stage that uses them instead of being held across the whole transform
-  constexpr bool RELOAD = (R3 == 16);
+  constexpr bool RELOAD = true; // (R3 = 8 held them until the grouped butterflies took two more registers: 6 spills)
   cf tw1[15], tw3[16], ch[NR];
   if (RELOAD) W::load_tw1(t, a.tw, tw1);
   else W::load_twiddles(t, a.tw, tw1, tw3);
