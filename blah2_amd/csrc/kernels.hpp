@@ -305,7 +305,8 @@ __global__ __launch_bounds__(64 * RANGEW_WAVES, RANGEW_WAVES_PER_SIMD) void rang
   using W = WaveFft;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf *table = reinterpret_cast<cf *>(smem);
-  const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: the pulse loop stays scalar
   cf *X = table + W::TW_ELEMS + wave * W::X_ELEMS;
   W::fill_table(threadIdx.x, 64 * RANGEW_WAVES, a.tw, table);
   __syncthreads();
