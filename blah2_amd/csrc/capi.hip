@@ -99,6 +99,9 @@ struct blah2hip_amb_s {
   int lastDoppler = 0;              // BLAH2HIP_INFO_LAST_DOPPLER_KERNEL
   int lastRange = 0;                // BLAH2HIP_INFO_LAST_RANGE_KERNEL
   int rangeKernel = 0;              // BLAH2HIP_OPT_RANGE_KERNEL (0 = by transform length)
+  int fftLenForce = 0;              // BLAH2HIP_OPT_FFT_LEN (0 = planner)
+  int dopGridForce = 0;             // BLAH2HIP_OPT_DOPPLER_GRID (0 = residency of the persistent kernel)
+  int dopGridLast = 0, dopTilesLast = 0; // BLAH2HIP_INFO_DOPPLER_GRID / _TILES
   struct AlphaTable { double pfa; size_t n; double *d; };
   std::vector<AlphaTable> alphaTables; // CFAR threshold factors, one per (pfa, size) seen
   cf *d_dtw = nullptr;              // exp(-2 pi i k/M)
@@ -157,8 +160,7 @@ void derive_dims(blah2hip_amb_s *h, uint32_t n, bool roundHamming, uint32_t nDop
 bool choose_plan(blah2hip_amb_s *h)
 {
   const int nCorr = h->dims.n_corr, nDelay = h->dims.n_delay_bins;
-  int forced = 0;
-  if (const char *e = std::getenv("BLAH2HIP_FFT_LEN")) forced = std::atoi(e);
+  const int forced = h->fftLenForce;
   double best = 1e300;
   bool found = false;
   for (int r3 : {4, 8, 16}) {
@@ -353,6 +355,19 @@ template <class In> int launch_range(blah2hip_amb_s *h, const RangeArgs &a, In i
   }
 }
 
+// exp(-2 pi i k / F) for the handle's current plan (create, and again when BLAH2HIP_OPT_FFT_LEN re-plans)
+int upload_range_table(blah2hip_amb_s *h)
+{
+  const int F = (int)h->dims.fft_len;
+  std::vector<cf> tw(F);
+  for (int k = 0; k < F; k++) tw[k] = root_of_unity(k, F);
+  if (h->d_tw) HIPCHK(hipFree(h->d_tw));
+  h->d_tw = nullptr;
+  HIPCHK(hipMalloc(&h->d_tw, F * sizeof(cf)));
+  HIPCHK(hipMemcpy(h->d_tw, tw.data(), F * sizeof(cf), hipMemcpyHostToDevice));
+  return BLAH2HIP_OK;
+}
+
 int tic(blah2hip_amb_s *h, int k, hipStream_t st)
 {
   HIPCHK(h->timer.tic(k, st));
@@ -532,10 +547,7 @@ int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 
   const uint32_t nD = h->dims.n_doppler_bins, nDelay = h->dims.n_delay_bins;
-  const int F = h->dims.fft_len;
 
-  std::vector<cf> tw(F);
-  for (int k = 0; k < F; k++) tw[k] = root_of_unity(k, F);
   std::vector<cf> dw(nD);
   for (uint32_t k = 0; k < nD; k++) dw[k] = root_of_unity(k, nD);
   const size_t cells = (size_t)nD * nDelay;
@@ -551,7 +563,7 @@ int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler
   // metrics partials per CPI: the largest workgroup count of any Doppler kernel this handle may launch
   h->nParts = std::max(h->dopGridX, h->dopTilesX * h->dopTilesY);
 
-  HIPCHK(hipMalloc(&h->d_tw, F * sizeof(cf)));
+  { const int rc_ = upload_range_table(h); if (rc_) return rc_; }
   HIPCHK(hipMalloc(&h->d_dopW, nD * sizeof(cf)));
   HIPCHK(hipMalloc(&h->d_R, rcells * max_batch * sizeof(cf)));
   HIPCHK(hipMalloc(&h->d_map, cells * max_batch * sizeof(cf)));
@@ -561,7 +573,6 @@ int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler
   HIPCHK(hipMalloc(&h->d_doppler, nD * sizeof(double)));
   HIPCHK(hipMalloc(&h->d_count, max_batch * sizeof(uint32_t)));
   HIPCHK(hipMemset(h->d_R, 0, rcells * max_batch * sizeof(cf))); // padding columns stay finite
-  HIPCHK(hipMemcpy(h->d_tw, tw.data(), F * sizeof(cf), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->d_dopW, dw.data(), nD * sizeof(cf), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->d_doppler, h->dopplerAxis.data(), nD * sizeof(double), hipMemcpyHostToDevice));
   if (h->dopR3) {
@@ -646,6 +657,26 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
       return fail(BLAH2HIP_ERR_UNSUPPORTED, "F = 1024 runs on the 8-points-per-thread kernel only");
     h->rangeKernel = (int)value;
     return BLAH2HIP_OK;
+  case BLAH2HIP_OPT_DOPPLER_GRID:
+    if (value < 0 || value > (1 << 20)) return fail(BLAH2HIP_ERR_INVALID, "Doppler grid outside [0, 2^20]");
+    h->dopGridForce = (int)value;
+    return BLAH2HIP_OK;
+  case BLAH2HIP_OPT_FFT_LEN: {
+    if (value != 0 && value != 1024 && value != 2048 && value != 4096)
+      return fail(BLAH2HIP_ERR_INVALID, "range transform length: 0 (planner), 1024, 2048 or 4096");
+    const int prevForce = h->fftLenForce, prevR3 = h->r3;
+    const RangePlan prevPlan = h->plan;
+    h->fftLenForce = (int)value;
+    if (!choose_plan(h)) {
+      h->fftLenForce = prevForce; h->r3 = prevR3; h->plan = prevPlan;
+      return fail(BLAH2HIP_ERR_UNSUPPORTED, "the lag window does not fit this transform length");
+    }
+    h->rangeKernel = 0; // a forced kernel belongs to a transform length
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize()); // the table may still be in use by enqueued work
+    int rc = upload_range_table(h);
+    return rc;
+  }
   default: return fail(BLAH2HIP_ERR_INVALID, "unknown option");
   }
 }
@@ -659,6 +690,8 @@ int blah2hip_amb_get_info(blah2hip_amb_t h, int key, int64_t *value)
   case BLAH2HIP_INFO_DOPPLER_FFT_LEN: *value = 256 * h->dopR3; return BLAH2HIP_OK;
   case BLAH2HIP_INFO_RANGE_GRID: *value = h->rangeGridLast; return BLAH2HIP_OK;
   case BLAH2HIP_INFO_NUM_CU: *value = h->numCU; return BLAH2HIP_OK;
+  case BLAH2HIP_INFO_DOPPLER_GRID: *value = h->dopGridLast; return BLAH2HIP_OK;
+  case BLAH2HIP_INFO_DOPPLER_TILES: *value = h->dopTilesLast; return BLAH2HIP_OK;
   default: return fail(BLAH2HIP_ERR_INVALID, "unknown info key");
   }
 }
@@ -747,7 +780,7 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   da.nD = (int32_t)nD;
   da.nDelay = (int32_t)nDelay;
   da.nTiles = h->nTiles;
-  int nPartsUsed = 0;
+  int nPartsUsed = 0, dopGrid = 0, dopTiles = 0;
   if ((rc = tic(h, BLAH2HIP_K_DOPPLER, st))) return rc;
   const int which = pick_doppler(h, n_cpi);
   switch (which) {
@@ -758,12 +791,14 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     // persistent: the resident workgroups (LDS: one of 16 columns or two of 8 per CU) walk the tiles of the batch
     if (ncol == 16) {
       const size_t lds = (size_t)dopt_lds_elems<16>() * sizeof(cf);
-      const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, h->numCU);
+      const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, h->dopGridForce ? h->dopGridForce : h->numCU);
+      dopGrid = wgs; dopTiles = grid * (int)n_cpi;
       LDSCFG(doppler_tile_kernel<16>, lds);
       hipLaunchKernelGGL(doppler_tile_kernel<16>, dim3(wgs), dim3(1024), lds, st, da, (int)n_cpi);
     } else {
       const size_t lds = (size_t)dopt_lds_elems<8>() * sizeof(cf);
-      const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, 2 * h->numCU);
+      const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, h->dopGridForce ? h->dopGridForce : 2 * h->numCU);
+      dopGrid = wgs; dopTiles = grid * (int)n_cpi;
       LDSCFG(doppler_tile_kernel<8>, lds);
       hipLaunchKernelGGL(doppler_tile_kernel<8>, dim3(wgs), dim3(512), lds, st, da, (int)n_cpi);
     }
@@ -775,7 +810,8 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     const size_t lds = (size_t)DOPW_LDS_ELEMS * sizeof(cf);
     LDSCFG(doppler_tilew_kernel, lds);
     // persistent: one workgroup per CU (LDS) walks the tiles of the whole batch
-    const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, h->numCU);
+    const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, h->dopGridForce ? h->dopGridForce : h->numCU);
+    dopGrid = wgs; dopTiles = grid * (int)n_cpi;
 #ifdef DOPW_TRACE
     static uint64_t *dbg = nullptr;
     static int calls = 0;
@@ -827,6 +863,8 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   }
   HIPCHK(hipGetLastError());
   h->lastDoppler = which;
+  h->dopGridLast = dopGrid;
+  h->dopTilesLast = dopTiles;
   if ((rc = toc(h, BLAH2HIP_K_DOPPLER, st))) return rc;
 
   {

@@ -610,11 +610,60 @@ struct blah2hip_clutter_s {
   size_t stageElems = 0;
   int solveK = 0;            // indices per thread of the Toeplitz solve (0 = by size)
   bool corrHalf = false;     // half-window correlation (2 transforms per F/2 samples) instead of the windowed one
+  int fftLenForce = 0;       // BLAH2HIP_CLUTTER_OPT_FFT_LEN (0 = planner)
+  int corrForce = 0;         // BLAH2HIP_CLUTTER_OPT_CORR
   int32_t *lastOk = nullptr; // where the last process call wrote its flags
   KernelTimer<BLAH2HIP_CK_COUNT> timer;
 };
 
 namespace {
+
+// Transform length, segmentation, correlation form and the buffers sized by them (create, and again when
+// BLAH2HIP_CLUTTER_OPT_FFT_LEN / _CORR re-plan).  F - nBins + 1 useful samples per F log F work.
+int clutter_plan(blah2hip_clutter_s *h)
+{
+  const int nBins = h->nBins;
+  int bestR3 = 0;
+  double best = 1e300;
+  for (int r3 : {4, 8, 16}) {
+    const int F = 256 * r3;
+    if (h->fftLenForce && F != h->fftLenForce) continue;
+    const int L = F - nBins + 1;
+    if (L < 16) continue;
+    // measured per-point speed of the three transform kernels (tools/gpu_diag.py)
+    const double cost = (double)F * std::log2((double)F) / (double)L * (r3 == 16 ? 1.4 : (r3 == 4 ? 1.08 : 1.0));
+    if (cost < best) { best = cost; bestR3 = r3; }
+  }
+  if (!bestR3) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip transform lengths (<= 4096)");
+  h->r3 = bestR3; h->F = 256 * bestR3;
+  h->segLen = h->F - nBins + 1;
+  h->nSeg = (int)((h->N + (uint32_t)h->segLen - 1) / (uint32_t)h->segLen);
+  // correlations: windowed form 3 transforms per segLen samples, half-window form 2 per F/2
+  // (needs nBins - 1 <= F/2 and at least nBins samples)
+  const bool halfOk = (nBins - 1 <= h->F / 2) && ((uint32_t)nBins <= h->N);
+  h->corrHalf = halfOk && (4.0 / h->F < 3.0 / h->segLen);
+  if (h->corrForce == BLAH2HIP_CLUTTER_CORR_HALF) {
+    if (!halfOk) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "the half-window correlation needs nBins - 1 <= F/2 and nBins <= nSamples");
+    h->corrHalf = true;
+  }
+  if (h->corrForce == BLAH2HIP_CLUTTER_CORR_WINDOW) h->corrHalf = false;
+  auto up8 = [](int v) { return std::max(8, (v + 7) & ~7); };
+  h->nJobs = up8(std::min(h->nSeg, 2 * h->numCU)); // partial correlations per CPI (x2 modes in one workgroup)
+  h->firGrid = up8(std::min(h->nSeg, 8 * h->numCU));
+  std::vector<cf> tw(h->F);
+  for (int k = 0; k < h->F; k++) {
+    const double a = -2.0 * M_PI * (double)k / (double)h->F;
+    tw[k] = cmake((float)std::cos(a), (float)std::sin(a));
+  }
+  if (h->d_tw) CHIP(hipFree(h->d_tw));
+  h->d_tw = nullptr;
+  if (h->d_partial) CHIP(hipFree(h->d_partial));
+  h->d_partial = nullptr;
+  CHIP(hipMalloc(&h->d_tw, h->F * sizeof(cf)));
+  CHIP(hipMemcpy(h->d_tw, tw.data(), h->F * sizeof(cf), hipMemcpyHostToDevice));
+  CHIP(hipMalloc(&h->d_partial, (size_t)h->maxBatch * 2 * h->nJobs * nBins * sizeof(cf)));
+  return BLAH2HIP_OK;
+}
 
 template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const cf *y, uint32_t nCpi,
                                      int64_t stride, cf *yout, int64_t outStride, int32_t *ok, hipStream_t st)
@@ -710,21 +759,6 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
     CFAIL(BLAH2HIP_ERR_NO_DEVICE, "no HIP device visible (the HIP path is the only path)");
   if (device < 0 || device >= ndev) CFAIL(BLAH2HIP_ERR_INVALID, "device index out of range");
   CHIP(hipSetDevice(device));
-  // transform length: F - nBins + 1 useful samples per F log F work
-  int bestR3 = 0;
-  double best = 1e300;
-  int forced = 0;
-  if (const char *e = std::getenv("BLAH2HIP_CLUTTER_FFT_LEN")) forced = std::atoi(e);
-  for (int r3 : {4, 8, 16}) {
-    const int F = 256 * r3;
-    if (forced && F != forced) continue;
-    const int L = F - nBins + 1;
-    if (L < 16) continue;
-    // measured per-point speed of the three transform kernels (tools/gpu_diag.py)
-    const double cost = (double)F * std::log2((double)F) / (double)L * (r3 == 16 ? 1.4 : (r3 == 4 ? 1.08 : 1.0));
-    if (cost < best) { best = cost; bestR3 = r3; }
-  }
-  if (!bestR3) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip transform lengths (<= 4096)");
   // the solve keeps two fp64 vectors of nBins in LDS and 4 indices per thread at most
   if (((size_t)2 * nBins + 16) * sizeof(dcx) > 160 * 1024 - 2048 || nBins > 4096)
     CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip Toeplitz solve");
@@ -734,31 +768,11 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
   h->device = device;
   h->delayMin = delay_min; h->delayMax = delay_max;
   h->N = n_samples; h->maxBatch = max_batch; h->nBins = nBins;
-  h->r3 = bestR3; h->F = 256 * bestR3;
-  h->segLen = h->F - nBins + 1;
-  h->nSeg = (int)((n_samples + (uint32_t)h->segLen - 1) / (uint32_t)h->segLen);
-  // correlations: windowed form 3 transforms per segLen samples, half-window form 2 per F/2
-  // (needs nBins - 1 <= F/2 and at least nBins samples)
-  h->corrHalf = (nBins - 1 <= h->F / 2) && ((uint32_t)nBins <= n_samples) && (4.0 / h->F < 3.0 / h->segLen);
-  if (const char *e = std::getenv("BLAH2HIP_CLUTTER_CORR")) { // planner override for the tests: "half" / "window"
-    if (!std::strcmp(e, "half") && nBins - 1 <= h->F / 2 && (uint32_t)nBins <= n_samples) h->corrHalf = true;
-    if (!std::strcmp(e, "window")) h->corrHalf = false;
-  }
   hipDeviceProp_t prop;
   CHIP(hipGetDeviceProperties(&prop, device));
   h->numCU = prop.multiProcessorCount;
-  auto up8 = [](int v) { return std::max(8, (v + 7) & ~7); };
-  h->nJobs = up8(std::min(h->nSeg, 2 * prop.multiProcessorCount)); // partial correlations per CPI (x2 modes in one workgroup)
-  h->firGrid = up8(std::min(h->nSeg, 8 * prop.multiProcessorCount));
   CHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  std::vector<cf> tw(h->F);
-  for (int k = 0; k < h->F; k++) {
-    const double a = -2.0 * M_PI * (double)k / (double)h->F;
-    tw[k] = cmake((float)std::cos(a), (float)std::sin(a));
-  }
-  CHIP(hipMalloc(&h->d_tw, h->F * sizeof(cf)));
-  CHIP(hipMemcpy(h->d_tw, tw.data(), h->F * sizeof(cf), hipMemcpyHostToDevice));
-  CHIP(hipMalloc(&h->d_partial, (size_t)max_batch * 2 * h->nJobs * nBins * sizeof(cf)));
+  { const int rc_ = clutter_plan(h); if (rc_) return rc_; }
   CHIP(hipMalloc(&h->d_rb, (size_t)max_batch * 2 * nBins * sizeof(dcx)));
   CHIP(hipMalloc(&h->d_w, (size_t)max_batch * nBins * sizeof(cf)));
   CHIP(hipMalloc(&h->d_ok, max_batch * sizeof(int32_t)));
@@ -822,6 +836,26 @@ int blah2hip_clutter_set_option(blah2hip_clutter_t h, int option, int64_t value)
     if (value && (int64_t)h->nBins > 1024 * value) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins needs more indices per thread");
     h->solveK = (int)value;
     return BLAH2HIP_OK;
+  case BLAH2HIP_CLUTTER_OPT_FFT_LEN:
+  case BLAH2HIP_CLUTTER_OPT_CORR: {
+    const bool isLen = option == BLAH2HIP_CLUTTER_OPT_FFT_LEN;
+    if (isLen && value != 0 && value != 1024 && value != 2048 && value != 4096)
+      CFAIL(BLAH2HIP_ERR_INVALID, "clutter transform length: 0 (planner), 1024, 2048 or 4096");
+    if (!isLen && (value < BLAH2HIP_CLUTTER_CORR_AUTO || value > BLAH2HIP_CLUTTER_CORR_WINDOW))
+      CFAIL(BLAH2HIP_ERR_INVALID, "correlation form: BLAH2HIP_CLUTTER_CORR_AUTO, _HALF or _WINDOW");
+    const int prevLen = h->fftLenForce, prevCorr = h->corrForce;
+    (isLen ? h->fftLenForce : h->corrForce) = (int)value;
+    CHIP(hipSetDevice(h->device));
+    CHIP(hipDeviceSynchronize()); // the buffers may still be in use by enqueued work
+    const int rc = clutter_plan(h);
+    if (rc) {
+      const std::string msg = blah2hip_last_error();
+      h->fftLenForce = prevLen; h->corrForce = prevCorr;
+      (void)clutter_plan(h); // back to the previous, valid plan
+      blah2hip_set_error_(msg.c_str());
+    }
+    return rc;
+  }
   default: CFAIL(BLAH2HIP_ERR_INVALID, "unknown option");
   }
 }

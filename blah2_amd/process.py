@@ -189,6 +189,15 @@ class Ambiguity:
     def set_range_grid(self, n):
         check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_RANGE_GRID, int(n)))
 
+    def set_doppler_grid(self, n):
+        """Workgroup cap of the persistent Doppler tile kernels (0 = their residency)."""
+        check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_DOPPLER_GRID, int(n)))
+
+    def set_fft_len(self, F):
+        """Force the range transform length (1024 / 2048 / 4096; 0 = planner); re-plans the segmentation."""
+        check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_FFT_LEN, int(F)))
+        check(self._L.blah2hip_amb_get_dims(self._h, C.byref(self.dims)))
+
     def set_range_kernel(self, which):
         """0 = by transform length, ``_lib.RANGE_WAVE`` = the one-wave kernel (F = 2048 only)."""
         check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_RANGE_KERNEL, int(which)))
@@ -371,6 +380,23 @@ class WienerHopf:
     def process_dev(self, d_x, d_y, n_cpi, cpi_stride, d_y_out, d_ok=None, stream=0):
         """Enqueue on ``stream``: device complex64 planes, output may alias d_y."""
         check(self._L.blah2hip_clutter_process_dev(self._h, d_x, d_y, n_cpi, cpi_stride, d_y_out, d_ok, stream))
+
+    def _refresh_dims(self):
+        nb, fl, sl = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(self._L.blah2hip_clutter_get_dims(self._h, C.byref(nb), C.byref(fl), C.byref(sl)))
+        self.nBins, self.fft_len, self.seg_len = nb.value, fl.value, sl.value
+
+    def set_fft_len(self, F):
+        """Force the transform length of the correlation / FIR kernels (0 = planner)."""
+        check(self._L.blah2hip_clutter_set_option(self._h, _lib.CLUTTER_OPT_FFT_LEN, int(F)))
+        self._refresh_dims()
+
+    def set_corr_form(self, which):
+        """'auto' / 'half' / 'window' (``_lib.CLUTTER_CORR_*``)."""
+        if isinstance(which, str):
+            which = {"auto": _lib.CLUTTER_CORR_AUTO, "half": _lib.CLUTTER_CORR_HALF, "window": _lib.CLUTTER_CORR_WINDOW}[which]
+        check(self._L.blah2hip_clutter_set_option(self._h, _lib.CLUTTER_OPT_CORR, int(which)))
+        self._refresh_dims()
 
     def set_solve_indices_per_thread(self, k):
         check(self._L.blah2hip_clutter_set_option(self._h, _lib.CLUTTER_OPT_SOLVE_K, int(k)))

@@ -128,6 +128,12 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 #define BLAH2HIP_OPT_RANGE_KERNEL 3   /* 0 = by transform length and launch size (F = 1024: E8; 4096: E16; 2048: WAVE once a launch
                                        * has a pulse per wave slot of the chip -- 8 x CUs -- else E16, e.g. a single CPI);
                                        * BLAH2HIP_RANGE_E16 / BLAH2HIP_RANGE_WAVE force one of the two at F = 2048 */
+#define BLAH2HIP_OPT_DOPPLER_GRID 4   /* workgroup cap of the PERSISTENT Doppler tile kernels (TILE8 / TILE16 / TILEW / TILEW2); 0 = their
+                                       * residency (one or two workgroups per CU).  A small cap makes every workgroup walk many tiles --
+                                       * the steady state of the software-pipelined loops -- on a small fixture (tests) */
+#define BLAH2HIP_OPT_FFT_LEN 5        /* range transform length F in {1024, 2048, 4096}; 0 = the planner's choice (cost model).  Re-plans the
+                                       * segmentation and re-uploads the root table (blocking); BLAH2HIP_ERR_UNSUPPORTED when the lag window
+                                       * does not fit F.  Replaces the BLAH2HIP_FFT_LEN environment variable of earlier versions */
 #define BLAH2HIP_DOP_AUTO 0
 #define BLAH2HIP_DOP_TILE8 1   /* nD <= 513: 8-column tiles, one wave per column */
 #define BLAH2HIP_DOP_TILE16 2  /* nD <= 513: 16-column tiles */
@@ -145,6 +151,9 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value);
 #define BLAH2HIP_INFO_DOPPLER_FFT_LEN 3     /* chirp-z transform length M (0 = direct DFT only) */
 #define BLAH2HIP_INFO_RANGE_GRID 4
 #define BLAH2HIP_INFO_NUM_CU 5
+#define BLAH2HIP_INFO_DOPPLER_GRID 6        /* workgroups of the last Doppler launch */
+#define BLAH2HIP_INFO_DOPPLER_TILES 7       /* tiles (units of work the persistent workgroups walk) of the last Doppler launch; 0 for the
+                                             * non-persistent kernels */
 int blah2hip_amb_get_info(blah2hip_amb_t h, int key, int64_t *value);
 
 /* Ambiguity::process + Map::set_metrics on host buffers (blah2.cpp:278-279).
@@ -261,6 +270,14 @@ int blah2hip_clutter_process_dev(blah2hip_clutter_t h, const void *d_x, const vo
 /* Execution plan of the filter.  SOLVE_K: indices of the Toeplitz recursion per thread (0 = by
  * size: 1 up to 1024 taps, 2 up to 2048, 4 above; the workgroup has ceil(nBins / K) threads rounded up to a wave). */
 #define BLAH2HIP_CLUTTER_OPT_SOLVE_K 1
+/* Planner overrides (re-plan and re-allocate the handle's work buffers, blocking; they replace the BLAH2HIP_CLUTTER_FFT_LEN /
+ * BLAH2HIP_CLUTTER_CORR environment variables of earlier versions).  FFT_LEN: transform length in {1024, 2048, 4096}, 0 = planner.
+ * CORR: BLAH2HIP_CLUTTER_CORR_AUTO / _HALF (two transforms per F/2 samples; needs nBins - 1 <= F/2) / _WINDOW (three per F - nBins + 1). */
+#define BLAH2HIP_CLUTTER_OPT_FFT_LEN 2
+#define BLAH2HIP_CLUTTER_OPT_CORR 3
+#define BLAH2HIP_CLUTTER_CORR_AUTO 0
+#define BLAH2HIP_CLUTTER_CORR_HALF 1
+#define BLAH2HIP_CLUTTER_CORR_WINDOW 2
 int blah2hip_clutter_set_option(blah2hip_clutter_t h, int option, int64_t value);
 /* Derived sizes: nBins = delayMax - delayMin taps (WienerHopf.cpp:12), on-chip transform
  * length and samples per overlap-save block. */

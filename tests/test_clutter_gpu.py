@@ -41,12 +41,14 @@ def test_clutter_golden(b2, name, path):
 
 
 @pytest.mark.parametrize("fft_len", [1024, 2048, 4096])
-def test_clutter_every_transform_length(b2, fft_len, monkeypatch):
-    monkeypatch.setenv("BLAH2HIP_CLUTTER_FFT_LEN", str(fft_len))
+def test_clutter_every_transform_length(b2, fft_len):
     g = load_golden("medium")
     n = int(g["params"][1])
     dmin, dmax = (int(v) for v in g["clutter_params"])
-    ok, yf = b2.WienerHopf(dmin, dmax, n).process(g["x"], g["y"])
+    wh = b2.WienerHopf(dmin, dmax, n)
+    wh.set_fft_len(fft_len)
+    assert wh.fft_len == fft_len
+    ok, yf = wh.process(g["x"], g["y"])
     assert ok
     assert np.max(np.abs(yf - g["clutter_y"])) / np.max(np.abs(g["clutter_y"])) <= Y_TOL
 
@@ -61,31 +63,31 @@ def test_clutter_failure_contract(b2):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_clutter_golden_half_window_correlation(b2, name, monkeypatch):
+def test_clutter_golden_half_window_correlation(b2, name):
     """The half-window form of the correlations (2 transforms per F/2 samples, chosen by the planner for
     filters with many taps) forced on the small fixtures, where a workgroup's run is a few segments and
     the wrap-around product is a large share of the lags."""
-    monkeypatch.setenv("BLAH2HIP_CLUTTER_CORR", "half")
     g = load_golden(name)
     n = int(g["params"][1])
     dmin, dmax = (int(v) for v in g["clutter_params"])
-    ok, yf = b2.WienerHopf(dmin, dmax, n).process(g["x"], g["y"])
+    wh = b2.WienerHopf(dmin, dmax, n)
+    wh.set_corr_form("half")
+    ok, yf = wh.process(g["x"], g["y"])
     assert ok == bool(g["clutter_ok"])
     assert np.max(np.abs(yf - g["clutter_y"])) / np.max(np.abs(g["clutter_y"])) <= Y_TOL
 
 
 @pytest.mark.parametrize("mode,n,taps", [("auto", 300_000, 700), ("window", 300_000, 700), ("half", 300_000, 700),
                                          ("window", 1_000_000, 2047), ("half", 50_000, 300), ("half", 4_099, 1025)])
-def test_clutter_correlation_forms_agree_with_the_oracle(b2, mode, n, taps, monkeypatch):
+def test_clutter_correlation_forms_agree_with_the_oracle(b2, mode, n, taps):
     """r, b and the filtered channel from both correlation forms against the fp64 oracle: 700 taps (the
     planner itself picks the half-window form there), 2047 taps on the windowed form (cfg 3 runs the
     other one), a short CPI, and a CPI of two segments and three samples with the widest filter F = 2048 takes."""
-    if mode != "auto":
-        monkeypatch.setenv("BLAH2HIP_CLUTTER_CORR", mode)
     x, y = O.synth_iq(n, seed=n % 97 + taps, fs=1_000_000, targets=((20, 40.0, 0.05),))
     dmin, dmax = -7, taps - 7
     ok_ref, y_ref, w_ref, r_ref, b_ref = O.wiener_hopf(x, y, dmin, dmax, return_filter=True)
     wh = b2.WienerHopf(dmin, dmax, n)
+    wh.set_corr_form(mode)
     ok, yf = wh.process(x.astype(np.complex64), y.astype(np.complex64))
     assert ok and ok_ref
     _, w, r, b = wh.read_last(0)

@@ -39,15 +39,21 @@ def assert_cpi(got, met, ref, tag, cell_tol=CELL_TOL):
 
 
 def run_batch(b2, geom, B, kernel, seeds, fmt="c32", expect=None, cell_tol=CELL_TOL, targets=((37, -63.0, 0.05),),
-              range_kernel=0):
+              range_kernel=0, doppler_grid=0, range_grid=0, fft_len=0):
     """B distinct CPIs through blah2hip_amb_process_dev in ONE call; every CPI against the oracle."""
     import torch
     dmin, dmax, fmin, fmax, fs, n = geom
     amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, max_batch=B)
     if kernel != "auto":
         amb.set_doppler_kernel(kernel)
+    if fft_len:
+        amb.set_fft_len(fft_len)
     if range_kernel:
         amb.set_range_kernel(range_kernel)
+    if doppler_grid:
+        amb.set_doppler_grid(doppler_grid)
+    if range_grid:
+        amb.set_range_grid(range_grid)
     xs, ys = zip(*(O.synth_iq(n, seed=s, fs=fs, targets=targets) for s in seeds))
     nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
     out = torch.zeros((B, nD, nC), dtype=torch.complex64, device="cuda")
@@ -100,14 +106,13 @@ def test_cfg2_both_range_kernels_forced(b2, fmt, which):
     assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == k
 
 
-def test_one_wave_range_kernel_ragged_geometry(b2, monkeypatch):
+def test_one_wave_range_kernel_ragged_geometry(b2):
     """Ragged pulse length, a lag window that starts at a positive lag and a last segment of a few
     samples, single CPI and a batch."""
     from blah2_amd import _lib
-    monkeypatch.setenv("BLAH2HIP_FFT_LEN", "2048")
     geom = (1, 299, -100, 100, 1_000_000, 777_001)
     for B in (1, 2):
-        amb = run_batch(b2, geom, B, "auto", seeds=range(80, 80 + B), range_kernel=_lib.RANGE_WAVE,
+        amb = run_batch(b2, geom, B, "auto", seeds=range(80, 80 + B), range_kernel=_lib.RANGE_WAVE, fft_len=2048,
                         expect="column", targets=((40, 30.0, 0.05),))
         assert amb.dims.fft_len == 2048 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE
 

@@ -23,8 +23,8 @@ def accuracy():
     d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
     ref = O.ambiguity_process(d, x, y)
     for fft_len in (1024, 2048, 4096):
-        os.environ["BLAH2HIP_FFT_LEN"] = str(fft_len)
         amb = blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True)
+        amb.set_fft_len(fft_len)
         m = amb.process(x, y).data.astype(np.complex128)
         err = np.abs(m - ref)
         peak = np.max(np.abs(ref))
@@ -35,7 +35,6 @@ def accuracy():
               f"median {np.median(rel[strong]):.3e}; all cells max {rel.max():.3e}; "
               f"dB max {np.max(np.abs(10*np.log10(np.abs(m)) - 10*np.log10(np.abs(ref)))):.3e}", flush=True)
         amb.close()
-    os.environ.pop("BLAH2HIP_FFT_LEN", None)
 
 
 def timing():
@@ -43,8 +42,8 @@ def timing():
     dev = torch.device("cuda", 0)
     for fft_len in (1024, 2048, 4096):
         for B in [int(b) for b in os.environ.get("DIAG_B", "1,8,16").split(",")]:
-            os.environ["BLAH2HIP_FFT_LEN"] = str(fft_len)
             amb = blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, max_batch=B)
+            amb.set_fft_len(fft_len)
             ring = max(2, int(600e6 // (16 * n * B)) + 1)
             xs = [torch.view_as_complex(torch.round(300 * torch.randn((B, n, 2), device=dev))) for _ in range(ring)]
             ys = [torch.view_as_complex(torch.round(300 * torch.randn((B, n, 2), device=dev))) for _ in range(ring)]
@@ -71,7 +70,6 @@ def timing():
                   " ".join(f"{k}={v:.2f}" for k, v in per.items()), flush=True)
             amb.close()
             del xs, ys
-    os.environ.pop("BLAH2HIP_FFT_LEN", None)
 
 
 if __name__ == "__main__":
