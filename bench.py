@@ -89,6 +89,22 @@ def spawn_ranks(nproc, argv):
     return subprocess.call(cmd, env=env)
 
 
+# ----------------------------------------------------------------------------- algorithmic bytes
+def algorithmic_bytes(n, s_in, cells, B, cfar="2d"):
+    """ALGORITHMIC bytes per launch of B CPIs: what a kernel must move
+    if every input is read once and every output written once.  s_in = bytes per input sample per channel."""
+    return {
+        "range": (2 * n * s_in + cells * 8) * B,          # every input sample once + the range map once
+        "doppler": 2 * cells * 8 * B,                     # range map in, final map out
+        "clutter_corr": 2 * n * 8 * B,                    # x and y once
+        "clutter_fir": 3 * n * 8 * B,                     # x, y in; filtered y out
+        "cfar": cells * 8 * B,                            # the map once (1-D, and the fused 2-D detector)
+        "sat_rows": 2 * cells * 8 * B,                    # 2-D detector, large windows: map in, fp64 row prefixes out
+        "sat_cols": 2 * cells * 8 * B,                    # fp64 table in and out
+        "rotate": 3 * n * 8 * B,
+    }
+
+
 # ----------------------------------------------------------------------------- data
 def synth_batch(torch, n_cpi, n, seed, fs, device):
     """Seeded synthetic IQ, int16-valued like the .rspduo wire format, as complex64 planes."""
@@ -369,16 +385,7 @@ def main(argv=None):
     avg_range_s = (range_ms / max(range_n, 1)) * 1e-3
     # ALGORITHMIC bytes per launch: what a kernel must move if every
     # input is read once and every output written once
-    algo = {
-        "range": (2 * n * s_in + cells * 8) * B,          # every input sample once + the range map once
-        "doppler": 2 * cells * 8 * B,                     # range map in, final map out
-        "clutter_corr": 2 * n * 8 * B,                    # x and y once
-        "clutter_fir": 3 * n * 8 * B,                     # x, y in; filtered y out
-        "cfar": cells * 8 * B if a.cfar == "1d" else 2 * cells * 8 * B,  # map (+ the fp64 summed-area table)
-        "sat_rows": 2 * cells * 8 * B,                    # map in, fp64 row prefixes out
-        "sat_cols": 2 * cells * 8 * B,                    # fp64 table in and out
-        "rotate": 3 * n * 8 * B,
-    }
+    algo = algorithmic_bytes(n, s_in, cells, B, a.cfar)
     algo_bytes = algo["range"]
     achieved = algo_bytes / avg_range_s / 1e9 if avg_range_s > 0 else 0.0
     steps_timed = max(range_n, 1)

@@ -32,15 +32,38 @@ KERNELS = ("rangew_kernel", "range8_kernel", "range_kernel", "doppler_tilew_kern
            "db_map_kernel", "cal_")
 
 
-# kernels whose global reads are 64-byte (or shorter) pieces of 128-byte lines
-HALF_LINE_READERS = ("doppler_tile_kernel", "doppler_tilem_kernel", "doppler_tilew_kernel")
+# Kernels whose global reads are 64-byte (or shorter) pieces of 128-byte lines, BY INSTANTIATION: FETCH_SIZE counts
+# 64 B per request, so those are counted exactly (factor 1) and whole-line readers are under-counted by 2.
+# doppler_tile_kernel<16> reads whole 128-byte rows of a 16-column tile (x2), <8> the 64-byte half rows (x1);
+# the one-wave / two-wave tile kernels read 64-byte half rows, doppler_tilem_kernel<16> 32-byte quarter rows.
+HALF_LINE_READERS = ("doppler_tile_kernel<8>", "doppler_tilem_kernel<8>", "doppler_tilem_kernel<16>", "doppler_tilew_kernel",
+                     "doppler_tilew2_kernel")
+# kernels that keep their template argument in the summaries (their instantiations differ in access pattern)
+KEEP_TEMPLATE = ("doppler_tile_kernel", "doppler_tilem_kernel")
 
 
 def short(name):
     for k in KERNELS:
         if k in name:
-            return k if k != "cal_" else name.split("(")[0].replace("void ", "")
+            if k == "cal_":
+                return name.split("(")[0].replace("void ", "")
+            if k in KEEP_TEMPLATE and k + "<" in name:
+                i = name.index(k + "<")
+                return name[i:name.index(">", i) + 1].replace(" ", "")
+            return k
     return None
+
+
+def algorithmic_bytes(bench_config):
+    """Algorithmic bytes per launch of each kernel for a bench command (the same figures as bench.py's
+    roofline.kernels[]), from tools' description {"config", "batch", "fmt", "chain"}."""
+    sys.path.insert(0, ROOT)
+    import bench
+    (dmin, dmax, fmin, fmax, fs, n), _ = bench.CONFIGS[bench_config["config"]]
+    nC = dmax - dmin + 1
+    nD = 2 * int(fmax * (n / fs)) + 1  # symmetric Doppler limits, resolution fs/n (Ambiguity.cpp:25-37)
+    s_in = 8 if bench_config.get("fmt", "c32") == "c32" else 4
+    return bench.algorithmic_bytes(n, s_in, nD * nC, bench_config["batch"], bench_config.get("cfar", "2d"))
 
 
 def summarize(src, tag, prefix):
@@ -79,16 +102,32 @@ def summarize(src, tag, prefix):
             # FETCH_SIZE counts 64 B per request: a whole-line (128 B) request is under-counted by 2, a
             # half-line request (the 8-column Doppler tile reads 64 of every 128 B) is counted exactly
             # (profiles/*_pmc_calibration.json: cal_read8/16 -> 0.5, cal_read_half -> 1.0)
-            factor = 1.0 if k in HALF_LINE_READERS else 2.0
+            factor = 1.0 if any(k.startswith(h) for h in HALF_LINE_READERS) else 2.0
             fetch = factor * 1024.0 * sum(fs) / len(fs)
             write = 1024.0 * sum(ws) / len(ws)
             traffic[k] = {"fetch_bytes": fetch, "write_bytes": write, "hbm_bytes": fetch + write, "fetch_factor": factor,
                           "note": f"FETCH_SIZE KiB x{factor:g} (64 B counted per request) + WRITE_SIZE KiB (32-byte sectors)"}
     cfgp = os.path.join(src, "bench_config.json")
     out = {"round": tag, "kernels": traffic}
+    bad = []
     if os.path.exists(cfgp):
         out["bench_config"] = json.load(open(cfgp))
+        algo = algorithmic_bytes(out["bench_config"])
+        names = {"rangew_kernel": "range", "range_kernel": "range", "range8_kernel": "range", "doppler": "doppler",
+                 "clutter_corr_half_kernel": "clutter_corr", "clutter_corr_kernel": "clutter_corr",
+                 "clutter_fir_kernel": "clutter_fir", "cfar2d": "cfar", "cfar1d_kernel": "cfar"}
+        for k, t in traffic.items():
+            key = next((v for pre, v in names.items() if k.startswith(pre)), None)
+            if key and key in algo:
+                t["algorithmic_bytes"] = algo[key]
+                t["hbm_over_algorithmic"] = t["hbm_bytes"] / algo[key]
+                # a kernel cannot move fewer bytes than its inputs and outputs: that is a wrong fetch factor
+                # (3 % slack: lines the 256 MB Infinity Cache still holds are not fetched from HBM)
+                if t["hbm_bytes"] < 0.97 * algo[key]:
+                    bad.append(f"{prefix}: {k} reports {t['hbm_bytes']:.4g} B < {algo[key]:.4g} B algorithmic")
     json.dump(out, open(os.path.join(DST, f"{prefix}_traffic.json"), "w"), indent=1)
+    if bad:
+        raise SystemExit("summarize_prof: impossible traffic figure(s): " + "; ".join(bad))
     return traffic
 
 
