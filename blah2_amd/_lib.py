@@ -21,7 +21,8 @@ KERNEL_NAMES = {K_RANGE: "range", K_DOPPLER: "doppler", K_METRICS: "metrics", K_
 CK_CORR, CK_REDUCE, CK_SOLVE, CK_FIR, CK_COUNT = 0, 1, 2, 3, 4
 CLUTTER_KERNEL_NAMES = {CK_CORR: "clutter_corr", CK_REDUCE: "clutter_reduce", CK_SOLVE: "clutter_solve",
                         CK_FIR: "clutter_fir"}
-OPT_DOPPLER_KERNEL, OPT_RANGE_GRID, OPT_RANGE_KERNEL, OPT_DOPPLER_GRID, OPT_FFT_LEN = 1, 2, 3, 4, 5
+OPT_DOPPLER_KERNEL, OPT_RANGE_GRID, OPT_RANGE_KERNEL, OPT_DOPPLER_GRID, OPT_FFT_LEN, OPT_CFAR2D_KERNEL = 1, 2, 3, 4, 5, 6
+CFAR2D_AUTO, CFAR2D_TILE, CFAR2D_SAT = 0, 1, 2
 CLUTTER_OPT_SOLVE_K, CLUTTER_OPT_FFT_LEN, CLUTTER_OPT_CORR = 1, 2, 3
 CLUTTER_CORR_AUTO, CLUTTER_CORR_HALF, CLUTTER_CORR_WINDOW = 0, 1, 2
 DOP_AUTO, DOP_TILE8, DOP_TILE16, DOP_TILEM, DOP_COLUMN, DOP_DIRECT, DOP_TILEW = 0, 1, 2, 3, 4, 5, 6

@@ -2,6 +2,7 @@
 // planning, table generation and kernel launches.  gfx950 only; links against
 // libamdhip64 and nothing else.
 #include "kernels.hpp"
+#include "cfar_kernels.hpp"
 #include "timing.hpp"
 
 #include <algorithm>
@@ -100,6 +101,7 @@ struct blah2hip_amb_s {
   int lastRange = 0;                // BLAH2HIP_INFO_LAST_RANGE_KERNEL
   int rangeKernel = 0;              // BLAH2HIP_OPT_RANGE_KERNEL (0 = by transform length)
   int fftLenForce = 0;              // BLAH2HIP_OPT_FFT_LEN (0 = planner)
+  int cfar2dForce = 0;              // BLAH2HIP_OPT_CFAR2D_KERNEL
   int dopGridForce = 0;             // BLAH2HIP_OPT_DOPPLER_GRID (0 = residency of the persistent kernel)
   int dopGridLast = 0, dopTilesLast = 0; // BLAH2HIP_INFO_DOPPLER_GRID / _TILES
   struct AlphaTable { double pfa; size_t n; double *d; };
@@ -435,23 +437,50 @@ int pick_doppler(const blah2hip_amb_s *h, uint32_t n_cpi)
 }
 
 // CFAR threshold factors alpha[n] = n*(pfa^(-1/n) - 1), n = 1..maxN, evaluated with the
-// same libm pow the reference calls (CfarDetector1D.cpp:76).  One device table per
-// (pfa, maxN) the handle has seen: the first call with a new tuple uploads it (blocking);
-// afterwards the dev entry points only enqueue.
-int alpha_table(blah2hip_amb_s *h, double pfa, size_t maxN, const double **out)
+// same libm pow the reference calls (CfarDetector1D.cpp:76).  A small per-handle cache keyed by
+// (pfa, maxN), least recently used first out (a caller that adapts pfa per CPI does not grow device
+// memory): a hit only hands out the pointer; a miss allocates and uploads (blocking), which is
+// refused while `st` is being captured into a graph -- *_prepare is the call for that.
+constexpr size_t ALPHA_TABLES_MAX = 8;
+int alpha_table(blah2hip_amb_s *h, double pfa, size_t maxN, const double **out, hipStream_t st = nullptr)
 {
-  for (auto &t : h->alphaTables)
-    if (t.pfa == pfa && t.n >= maxN) { *out = t.d; return BLAH2HIP_OK; }
+  auto &T = h->alphaTables;
+  for (size_t i = 0; i < T.size(); i++)
+    if (T[i].pfa == pfa && T[i].n >= maxN) {
+      const blah2hip_amb_s::AlphaTable t = T[i];
+      T.erase(T.begin() + (long)i);
+      T.push_back(t); // most recently used last
+      *out = t.d;
+      return BLAH2HIP_OK;
+    }
+  if (st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      return fail(BLAH2HIP_ERR_INVALID, "threshold table of this (pfa, window) is not resident: call blah2hip_cfar1d_prepare / "
+                                        "blah2hip_cfar2d_prepare before capturing the stream");
+  }
   std::vector<double> alpha(maxN + 1);
   alpha[0] = std::nan("");
   for (size_t n = 1; n <= maxN; n++) alpha[n] = (double)n * (pow(pfa, -1.0 / (double)n) - 1);
+  if (T.size() >= ALPHA_TABLES_MAX) {
+    HIPCHK(hipDeviceSynchronize()); // the oldest table may still be read by enqueued work
+    (void)hipFree(T.front().d);
+    T.erase(T.begin());
+  }
   blah2hip_amb_s::AlphaTable t{pfa, maxN, nullptr};
   HIPCHK(hipMalloc(&t.d, (maxN + 1) * sizeof(double)));
   hipError_t e = hipMemcpy(t.d, alpha.data(), (maxN + 1) * sizeof(double), hipMemcpyHostToDevice);
   if (e != hipSuccess) { (void)hipFree(t.d); return fail(BLAH2HIP_ERR_HIP, std::string("alpha table upload: ") + hipGetErrorString(e)); }
-  h->alphaTables.push_back(t);
+  T.push_back(t);
   *out = t.d;
   return BLAH2HIP_OK;
+}
+
+// the one-pass tile kernel covers windows whose halo fits its LDS budget; larger ones take the summed-area table
+bool cfar2d_use_tile(const blah2hip_amb_s *h, int ngd, int ntd, int ngf, int ntf)
+{
+  if (h->cfar2dForce == BLAH2HIP_CFAR2D_SAT) return false;
+  return ngf + ntf <= C2T_MAX_HR && ngd + ntd <= C2T_MAX_HC;
 }
 
 int ensure_sat(blah2hip_amb_s *h)
@@ -656,6 +685,10 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
     if (value == BLAH2HIP_RANGE_E16 && h->r3 == 4)
       return fail(BLAH2HIP_ERR_UNSUPPORTED, "F = 1024 runs on the 8-points-per-thread kernel only");
     h->rangeKernel = (int)value;
+    return BLAH2HIP_OK;
+  case BLAH2HIP_OPT_CFAR2D_KERNEL:
+    if (value < BLAH2HIP_CFAR2D_AUTO || value > BLAH2HIP_CFAR2D_SAT) return fail(BLAH2HIP_ERR_INVALID, "2-D detector: AUTO, TILE or SAT");
+    h->cfar2dForce = (int)value;
     return BLAH2HIP_OK;
   case BLAH2HIP_OPT_DOPPLER_GRID:
     if (value < 0 || value > (1 << 20)) return fail(BLAH2HIP_ERR_INVALID, "Doppler grid outside [0, 2^20]");
@@ -979,7 +1012,7 @@ int blah2hip_cfar1d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
   hipStream_t st = (hipStream_t)stream;
   const double *d_alpha = nullptr;
   int rc;
-  if ((rc = alpha_table(h, pfa, (size_t)(2 * n_train), &d_alpha))) return rc;
+  if ((rc = alpha_table(h, pfa, (size_t)(2 * n_train), &d_alpha, st))) return rc;
   HIPCHK(hipMemsetAsync(d_count, 0, n_cpi * sizeof(uint32_t), st));
   CfarArgs a;
   a.map = d_map ? (const cf *)d_map : h->d_map;
@@ -991,6 +1024,7 @@ int blah2hip_cfar1d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
   a.nD = (int32_t)h->dims.n_doppler_bins;
   a.nDelay = (int32_t)h->dims.n_delay_bins;
   a.delayMin = h->delayMin;
+  a.delayAxis = nullptr; // the engine's own axis: delayMin + j
   a.nGuard = n_guard; a.nTrain = n_train; a.minDelay = min_delay;
   a.minDoppler = min_doppler;
   a.cap = cap;
@@ -1064,10 +1098,10 @@ int blah2hip_cfar1d_map(const float *map, uint32_t n_doppler, uint32_t n_delay, 
   alpha[0] = std::nan("");
   for (int n = 1; n <= 2 * n_train; n++) alpha[n] = n * (pow(pfa, -1.0 / n) - 1);
   const double met[2] = {noise_power, 0.0};
-  char *pool = nullptr; // one allocation: map | hits | doppler | alpha | metrics | count
+  char *pool = nullptr; // one allocation: map | hits | doppler | alpha | metrics | delay axis | count
   const size_t oMap = 0, oHits = oMap + cells * sizeof(cf), oDop = oHits + cells * sizeof(blah2hip_hit_t),
                oAlpha = oDop + n_doppler * sizeof(double), oMet = oAlpha + alpha.size() * sizeof(double),
-               oCnt = oMet + 2 * sizeof(double), total = oCnt + sizeof(uint32_t);
+               oAxis = oMet + 2 * sizeof(double), oCnt = oAxis + n_delay * sizeof(int32_t), total = oCnt + sizeof(uint32_t);
   HIPCHK(hipMalloc(&pool, total));
   std::vector<blah2hip_hit_t> hits;
   uint32_t n = 0;
@@ -1076,6 +1110,7 @@ int blah2hip_cfar1d_map(const float *map, uint32_t n_doppler, uint32_t n_delay, 
     HIPCHK(hipMemcpy(pool + oDop, doppler_axis, n_doppler * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(pool + oAlpha, alpha.data(), alpha.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(pool + oMet, met, sizeof met, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pool + oAxis, delay_axis, n_delay * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(pool + oCnt, 0, sizeof(uint32_t)));
     CfarArgs a;
     a.map = (const cf *)(pool + oMap);
@@ -1085,6 +1120,7 @@ int blah2hip_cfar1d_map(const float *map, uint32_t n_doppler, uint32_t n_delay, 
     a.hits = (blah2hip_hit_t *)(pool + oHits);
     a.count = (uint32_t *)(pool + oCnt);
     a.nD = (int32_t)n_doppler; a.nDelay = (int32_t)n_delay; a.delayMin = delay_axis[0];
+    a.delayAxis = (const int32_t *)(pool + oAxis); // x->delay[j] of a caller-built map need not be delay[0] + j (CfarDetector1D.cpp:53)
     a.nGuard = n_guard; a.nTrain = n_train; a.minDelay = min_delay; a.minDoppler = min_doppler;
     a.cap = (uint32_t)cells;
     hipLaunchKernelGGL(cfar1d_kernel, dim3(a.nD, 1), dim3(256), (size_t)a.nDelay * sizeof(double), 0, a);
@@ -1125,9 +1161,11 @@ int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
   hipStream_t st = (hipStream_t)stream;
   const int nD = (int)h->dims.n_doppler_bins, nC = (int)h->dims.n_delay_bins;
   int rc;
-  if ((rc = blah2hip_cfar2d_prepare(h, pfa, ngd, ntd, ngf, ntf))) return rc; // no-op once prepared
+  if (h->cfar2dForce == BLAH2HIP_CFAR2D_TILE && !cfar2d_use_tile(h, ngd, ntd, ngf, ntf))
+    return fail(BLAH2HIP_ERR_UNSUPPORTED, "2-D window beyond the tile kernel's halo (nGf + nTf <= 24, nGd + nTd <= 40)");
+  if (!cfar2d_use_tile(h, ngd, ntd, ngf, ntf) && (rc = ensure_sat(h))) return rc; // no-op once allocated
   const double *d_alpha = nullptr;
-  if ((rc = alpha_table(h, pfa, (size_t)(2 * (ngd + ntd) + 1) * (2 * (ngf + ntf) + 1), &d_alpha))) return rc;
+  if ((rc = alpha_table(h, pfa, (size_t)(2 * (ngd + ntd) + 1) * (2 * (ngf + ntf) + 1), &d_alpha, st))) return rc;
   HIPCHK(hipMemsetAsync(d_count, 0, n_cpi * sizeof(uint32_t), st));
   Cfar2dArgs a;
   a.map = d_map ? (const cf *)d_map : h->d_map;
@@ -1141,6 +1179,53 @@ int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
   a.ngD = ngd; a.ntD = ntd; a.ngF = ngf; a.ntF = ntf; a.minDelay = min_delay;
   a.minDoppler = min_doppler;
   a.cap = cap;
+  if (cfar2d_use_tile(h, ngd, ntd, ngf, ntf)) {
+    Cfar2dTileArgs ta;
+    ta.d = a;
+    ta.nCpi = (int32_t)n_cpi;
+    ta.rowsOut = C2T_ROWS - 2 * (ngf + ntf);
+    ta.tilesX = (nC + C2T_COLS - 1) / C2T_COLS;
+    ta.tilesY = (nD + ta.rowsOut - 1) / ta.rowsOut;
+    const int hC = ngd + ntd;
+    // the whole threshold table in LDS when it fits beside the tile (the default 17 x 9 window: 154 entries)
+    const int64_t tableN = (int64_t)(2 * (ngd + ntd) + 1) * (2 * (ngf + ntf) + 1) + 1;
+    ta.alphaLds = (tableN <= 2048 && c2t_lds_bytes(hC, (int)tableN) <= 160 * 1024) ? (int32_t)tableN : 0;
+    const size_t lds = c2t_lds_bytes(hC, ta.alphaLds);
+    const int64_t nAll = (int64_t)ta.tilesX * ta.tilesY * n_cpi;
+    const int grid = (int)std::max<int64_t>(8, (std::min<int64_t>(nAll, h->numCU) + 7) & ~7); // one persistent workgroup per CU (LDS)
+    ta.dbg = nullptr;
+#ifdef C2T_TRACE
+    static uint64_t *dbg = nullptr;
+    static int calls = 0;
+    if (!dbg) HIPCHK(hipMalloc(&dbg, 80));
+    HIPCHK(hipMemsetAsync(dbg, 0, 80, st));
+    ta.dbg = dbg;
+#endif
+    if ((rc = tic(h, BLAH2HIP_K_CFAR, st))) return rc;
+    auto launch = [&](auto kern) -> int {
+      LDSCFG(kern, lds);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * C2T_WAVES), lds, st, ta);
+      return BLAH2HIP_OK;
+    };
+    const bool two = C2T_COLS + 2 * hC <= 128;
+    if (two) rc = ta.alphaLds ? launch(cfar2d_tile_kernel<2, true>) : launch(cfar2d_tile_kernel<2, false>);
+    else rc = ta.alphaLds ? launch(cfar2d_tile_kernel<3, true>) : launch(cfar2d_tile_kernel<3, false>);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    if ((rc = toc(h, BLAH2HIP_K_CFAR, st))) return rc;
+#ifdef C2T_TRACE
+    if (++calls == 8) {
+      uint64_t hc[10];
+      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(hipMemcpy(hc, dbg, 80, hipMemcpyDeviceToHost));
+      double tot = 0;
+      for (int k = 0; k < 10; k++) tot += (double)hc[k];
+      fprintf(stderr, "[c2t trace] grid %d tiles %lld: loop+decode %.3f fill %.3f bar1 %.3f issue %.3f row sums %.3f row stores %.3f bar2 %.3f col sums %.3f tests %.3f bar3 %.3f of %.0f ticks/wave\n",
+              grid, (long long)nAll, hc[0] / tot, hc[1] / tot, hc[2] / tot, hc[3] / tot, hc[9] / tot, hc[4] / tot, hc[5] / tot, hc[8] / tot, hc[6] / tot, hc[7] / tot, tot / grid / C2T_WAVES);
+    }
+#endif
+    return BLAH2HIP_OK;
+  }
   if ((rc = tic(h, BLAH2HIP_K_SAT_ROWS, st))) return rc;
   hipLaunchKernelGGL(sat_rows_kernel, dim3(nD, n_cpi), dim3(256), 0, st, a);
   if ((rc = toc(h, BLAH2HIP_K_SAT_ROWS, st))) return rc;
@@ -1170,7 +1255,9 @@ int blah2hip_cfar2d_prepare(blah2hip_amb_t h, double pfa, int32_t ngd, int32_t n
     if (v < 0 || v > 127) return fail(BLAH2HIP_ERR_INVALID, "guard/train sizes outside [0, 127]");
   HIPCHK(hipSetDevice(h->device));
   int rc;
-  if ((rc = ensure_sat(h))) return rc;
+  if (h->cfar2dForce == BLAH2HIP_CFAR2D_TILE && !cfar2d_use_tile(h, ngd, ntd, ngf, ntf))
+    return fail(BLAH2HIP_ERR_UNSUPPORTED, "2-D window beyond the tile kernel's halo (nGf + nTf <= 24, nGd + nTd <= 40)");
+  if (!cfar2d_use_tile(h, ngd, ntd, ngf, ntf) && (rc = ensure_sat(h))) return rc;
   const double *d = nullptr;
   return alpha_table(h, pfa, (size_t)(2 * (ngd + ntd) + 1) * (2 * (ngf + ntf) + 1), &d);
 }

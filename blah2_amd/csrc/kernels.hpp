@@ -8,8 +8,7 @@
 //   doppler_dft_kernel                                                direct fallback
 //                                  (all with the per-workgroup partial sums of Map::set_metrics)
 //   metrics_kernel                 Map::set_metrics                   Map.cpp:187-206
-//   cfar1d_kernel                  CfarDetector1D::process            CfarDetector1D.cpp:23-100
-//   sat_rows / sat_cols / cfar2d   2-D CA-CFAR (BASELINE configs[2]; extension)
+//   (the detector kernels live in cfar_kernels.hpp)
 //   rotate_kernel                  Doppler-centre shift               Ambiguity.cpp:95-102
 // The clutter filter and the spectrum analyser live in clutter.hip / spectrum.hip.
 //
@@ -1176,179 +1175,6 @@ __global__ __launch_bounds__(256) void db_map_kernel(const cf *map, const double
   const cf *z = map + (size_t)cpi * cells;
   float *o = db + (size_t)cpi * cells;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += gridDim.x * blockDim.x) o[i] = db_of(z[i]) - noise;
-}
-
-// --------------------------------------------------------------------------
-// CfarDetector1D::process (CfarDetector1D.cpp:23-100): cell-averaging CFAR
-// along delay for each Doppler row with |doppler| >= minDoppler.  One
-// workgroup per row; |z|^2 of the row is staged in LDS as fp64 and the window
-// sum runs in the reference's index order (leading cells need k > 0, trailing
-// k >= 0, :61,:68).  alpha[n] = n*(pfa^(-1/n)-1) is tabulated on the host with
-// the same libm pow the reference calls (:76).  Hits are appended through a
-// per-CPI atomic counter; the host API sorts them into row-major order.
-struct CfarArgs {
-  const cf *map;         // [nCpi][nD][nDelay]
-  const double *metrics; // [nCpi][2]
-  const double *doppler; // [nD] Hz
-  const double *alpha;   // [2*nTrain+1]
-  blah2hip_hit_t *hits;  // [nCpi][cap]
-  uint32_t *count;       // [nCpi]
-  int32_t nD, nDelay, delayMin;
-  int32_t nGuard, nTrain, minDelay;
-  double minDoppler;
-  uint32_t cap;
-};
-
-__global__ void cfar1d_kernel(CfarArgs a)
-{
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *sq = reinterpret_cast<double *>(smem);
-  const int row = blockIdx.x, cpi = blockIdx.y;
-  if (fabs(a.doppler[row]) < a.minDoppler) return; // :40
-  const cf *z = a.map + ((size_t)cpi * a.nD + row) * a.nDelay;
-  for (int j = threadIdx.x; j < a.nDelay; j += blockDim.x) {
-    const cf c = z[j];
-    sq[j] = (double)c.x * (double)c.x + (double)c.y * (double)c.y; // |z*z| (:47)
-  }
-  __syncthreads();
-  const double noisePower = a.metrics[2 * cpi];
-  for (int j = threadIdx.x; j < a.nDelay; j += blockDim.x) {
-    if (j + a.delayMin < a.minDelay) continue; // :53  x->delay[j] < minDelay
-    int n = 0;
-    double tot = 0.0;
-    for (int k = j - a.nGuard - a.nTrain; k < j - a.nGuard; k++)
-      if (k > 0 && k < a.nDelay) { tot += sq[k]; n++; }
-    for (int k = j + a.nGuard + 1; k < j + a.nGuard + a.nTrain + 1; k++)
-      if (k >= 0 && k < a.nDelay) { tot += sq[k]; n++; }
-    if (n == 0) continue; // alpha = 0*inf = NaN in the reference: never exceeds
-    const double thr = a.alpha[n] * (tot / n);
-    if (sq[j] > thr) {
-      const uint32_t slot = atomicAdd(&a.count[cpi], 1u);
-      if (slot < a.cap) {
-        blah2hip_hit_t h;
-        h.row = row;
-        h.col = j;
-        h.snr = 5.0 * log10(sq[j]) - noisePower; // 10 log10|z| - noisePower (:48)
-        a.hits[(size_t)cpi * a.cap + slot] = h;
-      }
-    }
-  }
-}
-
-// --------------------------------------------------------------------------
-// 2-D cell-averaging CFAR (BASELINE.json configs[2]; the reference only has the
-// 1-D detector).  Definition: SURVEY.md section 8g / oracle cfar2d(): training
-// cells = the (2(nGd+nTd)+1) x (2(nGf+nTf)+1) rectangle minus the guard box,
-// in-bounds only, delay column 0 never trains (CfarDetector1D.cpp:61), statistic
-// |z|^2, alpha = N (pfa^(-1/N) - 1).  With nGf = nTf = 0 it is the 1-D detector.
-// Window sums come from an fp64 summed-area table built by two scan kernels.
-struct Cfar2dArgs {
-  const cf *map;         // [nCpi][nD][nDelay]
-  const double *metrics; // [nCpi][2]
-  const double *doppler; // [nD]
-  const double *alpha;   // [maxN + 1]
-  double *sat;           // [nCpi][nD + 1][nDelay + 1], row 0 and column 0 stay zero
-  blah2hip_hit_t *hits;
-  uint32_t *count;
-  int32_t nD, nDelay, delayMin;
-  int32_t ngD, ntD, ngF, ntF, minDelay;
-  double minDoppler;
-  uint32_t cap;
-};
-
-// row-wise inclusive prefix of |z|^2 (column 0 zeroed) into sat[i+1][1..]: the row is
-// walked in coalesced chunks of 256 cells; inside a chunk a wave scans with shuffles,
-// the four wave totals and the running carry are combined through LDS.
-__global__ __launch_bounds__(256) void sat_rows_kernel(Cfar2dArgs a)
-{
-  __shared__ double wtot[2][4];
-  const int row = blockIdx.x, cpi = blockIdx.y, t = threadIdx.x;
-  const int lane = t & 63, wv = t >> 6;
-  const cf *z = a.map + ((size_t)cpi * a.nD + row) * a.nDelay;
-  double *out = a.sat + ((size_t)cpi * (a.nD + 1) + row + 1) * (a.nDelay + 1) + 1;
-  double carry = 0.0;
-  int buf = 0;
-  for (int j0 = 0; j0 < a.nDelay; j0 += 256, buf ^= 1) {
-    const int j = j0 + t;
-    double val = 0.0;
-    if (j < a.nDelay && j != 0) {
-      const cf c = z[j];
-      val = (double)c.x * (double)c.x + (double)c.y * (double)c.y;
-    }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double n = __shfl_up(val, off);
-      if (lane >= off) val += n;
-    }
-    if (lane == 63) wtot[buf][wv] = val;
-    __syncthreads(); // double-buffered totals: one barrier per chunk is enough
-    double pre = carry;
-#pragma unroll
-    for (int w = 0; w < 4; w++) pre += (w < wv) ? wtot[buf][w] : 0.0;
-    if (j < a.nDelay) out[j] = val + pre;
-    carry += (wtot[buf][0] + wtot[buf][1]) + (wtot[buf][2] + wtot[buf][3]);
-  }
-}
-
-// column-wise running sum of the row prefixes -> summed-area table.  One thread
-// per column; rows are taken 16 at a time so that 16 independent loads are in
-// flight before the (serial) running sum consumes them.
-__global__ __launch_bounds__(64) void sat_cols_kernel(Cfar2dArgs a)
-{
-  const int j = blockIdx.x * 64 + threadIdx.x, cpi = blockIdx.y;
-  if (j >= a.nDelay) return;
-  const size_t W = (size_t)a.nDelay + 1;
-  double *col = a.sat + (size_t)cpi * (a.nD + 1) * W + (j + 1);
-  double run = 0.0;
-  int i = 1;
-  for (; i + 15 <= a.nD; i += 16) {
-    double v[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = col[(size_t)(i + k) * W];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      run += v[k];
-      col[(size_t)(i + k) * W] = run;
-    }
-  }
-  for (; i <= a.nD; i++) {
-    run += col[(size_t)i * W];
-    col[(size_t)i * W] = run;
-  }
-}
-
-__global__ __launch_bounds__(256) void cfar2d_kernel(Cfar2dArgs a)
-{
-  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, cpi = blockIdx.z;
-  if (j >= a.nDelay) return;
-  if (fabs(a.doppler[i]) < a.minDoppler) return;
-  if (j + a.delayMin < a.minDelay) return;
-  const int nD = a.nD, nC = a.nDelay, W = nC + 1;
-  const double *S = a.sat + (size_t)cpi * (nD + 1) * W;
-  auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
-  const int R0 = clampi(i - a.ngF - a.ntF, 0, nD), R1 = clampi(i + a.ngF + a.ntF + 1, 0, nD);
-  const int G0 = clampi(i - a.ngF, 0, nD), G1 = clampi(i + a.ngF + 1, 0, nD);
-  const int C0 = clampi(j - a.ngD - a.ntD, 0, nC), C1 = clampi(j + a.ngD + a.ntD + 1, 0, nC);
-  const int H0 = clampi(j - a.ngD, 0, nC), H1 = clampi(j + a.ngD + 1, 0, nC);
-  auto box = [&](int r0, int r1, int c0, int c1) {
-    return S[(size_t)r1 * W + c1] - S[(size_t)r0 * W + c1] - S[(size_t)r1 * W + c0] + S[(size_t)r0 * W + c0];
-  };
-  auto cols = [](int c0, int c1) { return max(c1, 1) - max(c0, 1); }; // column 0 never trains
-  const double tot = box(R0, R1, C0, C1) - box(G0, G1, H0, H1);
-  const int n = (R1 - R0) * cols(C0, C1) - (G1 - G0) * cols(H0, H1);
-  if (n <= 0) return;
-  const cf c = a.map[((size_t)cpi * nD + i) * nC + j];
-  const double sq = (double)c.x * (double)c.x + (double)c.y * (double)c.y;
-  if (sq > a.alpha[n] * (tot / n)) {
-    const uint32_t slot = atomicAdd(&a.count[cpi], 1u);
-    if (slot < a.cap) {
-      blah2hip_hit_t h;
-      h.row = i;
-      h.col = j;
-      h.snr = 5.0 * log10(sq) - a.metrics[2 * cpi];
-      a.hits[(size_t)cpi * a.cap + slot] = h;
-    }
-  }
 }
 
 } // namespace blah2

@@ -30,6 +30,7 @@ int blah2host_map_json(const float *map, uint32_t n_doppler, uint32_t n_delay, c
                        uint32_t fs, char *out, size_t cap, size_t *len)
 {
   if (!map || !delay || !doppler || n_doppler == 0 || n_delay == 0) return -1;
+  try {
   Map<std::complex<double>> m(n_doppler, n_delay);
   for (uint32_t i = 0; i < n_doppler; i++) {
     const float *row = map + 2 * (size_t)i * n_delay;
@@ -42,24 +43,29 @@ int blah2host_map_json(const float *map, uint32_t n_doppler, uint32_t n_delay, c
   std::string json = m.to_json(timestamp);
   if (fs) json = m.delay_bin_to_km(json, fs);
   return emit(json, out, cap, len);
+  } catch (...) { return -2; } // nothing may unwind through the C ABI (std::bad_alloc, ...)
 }
 
 int blah2host_detection_json(const double *delay, const double *doppler, const double *snr, uint32_t count,
                              uint64_t timestamp, uint32_t fs, char *out, size_t cap, size_t *len)
 {
   if (count && (!delay || !doppler || !snr)) return -1;
+  try {
   Detection d(std::vector<double>(delay, delay + count), std::vector<double>(doppler, doppler + count),
               std::vector<double>(snr, snr + count));
   std::string json = d.to_json(timestamp);
   if (fs) json = d.delay_bin_to_km(json, fs);
   return emit(json, out, cap, len);
+  } catch (...) { return -2; }
 }
 
 int blah2host_format_double(double v, int max_decimals, char *out, size_t cap, size_t *len)
 {
+  try {
   std::string s;
   blah2json::write_double(s, v, max_decimals);
   return emit(s, out, cap, len);
+  } catch (...) { return -2; }
 }
 
 } // extern "C"

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <iostream>
 
 // every cell starts at 1 like the reference (Map.cpp:18), so 10*log10|z| is 0
@@ -62,10 +63,15 @@ template <class T> uint32_t Map<T>::doppler_hz_to_bin(double hz)
 template <class T> uint64_t Map<T>::fingerprint() const
 {
   uint64_t h = 1469598103934665603ull;
+  static_assert(sizeof(T) % sizeof(uint64_t) == 0, "cells are whole 64-bit words");
   for (const auto &row : data) {
-    const uint64_t *w = reinterpret_cast<const uint64_t *>(row.data());
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(row.data());
     const size_t nw = row.size() * sizeof(T) / sizeof(uint64_t);
-    for (size_t i = 0; i < nw; i++) h = (h ^ w[i]) * 1099511628211ull;
+    for (size_t i = 0; i < nw; i++) {
+      uint64_t w;
+      std::memcpy(&w, p + i * sizeof(uint64_t), sizeof w); // no aliasing of complex<double> through uint64_t*
+      h = (h ^ w) * 1099511628211ull;
+    }
   }
   return h;
 }

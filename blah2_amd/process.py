@@ -193,6 +193,12 @@ class Ambiguity:
         """Workgroup cap of the persistent Doppler tile kernels (0 = their residency)."""
         check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_DOPPLER_GRID, int(n)))
 
+    def set_cfar2d_kernel(self, which):
+        """'auto' / 'tile' (one pass over the map) / 'sat' (summed-area table) for :class:`CfarDetector2D`."""
+        if isinstance(which, str):
+            which = {"auto": _lib.CFAR2D_AUTO, "tile": _lib.CFAR2D_TILE, "sat": _lib.CFAR2D_SAT}[which]
+        check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_CFAR2D_KERNEL, int(which)))
+
     def set_fft_len(self, F):
         """Force the range transform length (1024 / 2048 / 4096; 0 = planner); re-plans the segmentation."""
         check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_FFT_LEN, int(F)))

@@ -134,6 +134,11 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 #define BLAH2HIP_OPT_FFT_LEN 5        /* range transform length F in {1024, 2048, 4096}; 0 = the planner's choice (cost model).  Re-plans the
                                        * segmentation and re-uploads the root table (blocking); BLAH2HIP_ERR_UNSUPPORTED when the lag window
                                        * does not fit F.  Replaces the BLAH2HIP_FFT_LEN environment variable of earlier versions */
+#define BLAH2HIP_OPT_CFAR2D_KERNEL 6  /* 2-D detector: BLAH2HIP_CFAR2D_AUTO (the one-pass tile kernel when nGf + nTf <= 24 and nGd + nTd <= 40,
+                                       * else the summed-area table), _TILE (BLAH2HIP_ERR_UNSUPPORTED at the call for larger windows) or _SAT */
+#define BLAH2HIP_CFAR2D_AUTO 0
+#define BLAH2HIP_CFAR2D_TILE 1
+#define BLAH2HIP_CFAR2D_SAT 2
 #define BLAH2HIP_DOP_AUTO 0
 #define BLAH2HIP_DOP_TILE8 1   /* nD <= 513: 8-column tiles, one wave per column */
 #define BLAH2HIP_DOP_TILE16 2  /* nD <= 513: 16-column tiles */
@@ -223,8 +228,9 @@ int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
                         int32_t n_guard_doppler, int32_t n_train_doppler, int32_t min_delay,
                         double min_doppler, blah2hip_hit_t *d_hits, uint32_t cap, uint32_t *d_count,
                         void *stream);
-/* Allocates the summed-area table ([max_batch][nD+1][nDelay+1] doubles) and builds the
- * threshold table for this parameter tuple; blah2hip_cfar2d_dev calls it implicitly. */
+/* Builds the threshold table for this parameter tuple and, for windows beyond the one-pass tile kernel's
+ * halo (see BLAH2HIP_OPT_CFAR2D_KERNEL), allocates the summed-area table ([max_batch][nD+1][nDelay+1]
+ * doubles); blah2hip_cfar2d_dev calls it implicitly. */
 int blah2hip_cfar2d_prepare(blah2hip_amb_t h, double pfa, int32_t n_guard_delay, int32_t n_train_delay,
                             int32_t n_guard_doppler, int32_t n_train_doppler);
 int blah2hip_cfar2d_process(blah2hip_amb_t h, uint32_t cpi, double pfa, int32_t n_guard_delay,
@@ -311,9 +317,9 @@ int blah2hip_spectrum_process_dev(blah2hip_spectrum_t h, int fmt, const void *d_
 #define BLAH2HIP_K_RANGE 0
 #define BLAH2HIP_K_DOPPLER 1
 #define BLAH2HIP_K_METRICS 2
-#define BLAH2HIP_K_CFAR 3     /* cfar1d_kernel or cfar2d_kernel */
-#define BLAH2HIP_K_SAT_ROWS 4 /* 2-D CFAR: row prefix sums */
-#define BLAH2HIP_K_SAT_COLS 5 /* 2-D CFAR: column prefix sums */
+#define BLAH2HIP_K_CFAR 3     /* cfar1d_kernel, cfar2d_tile_kernel or cfar2d_kernel */
+#define BLAH2HIP_K_SAT_ROWS 4 /* 2-D CFAR through the summed-area table (large windows): row prefix sums */
+#define BLAH2HIP_K_SAT_COLS 5 /* ... column prefix sums */
 #define BLAH2HIP_K_ROTATE 6   /* Doppler-centre shift (asymmetric limits only) */
 #define BLAH2HIP_K_COUNT 8
 /* enable != 0: every dev call brackets each kernel with hipEvents */

@@ -9,7 +9,8 @@
  *
  * Strings are written into caller-owned buffers; *len receives the length needed (without the
  * terminating NUL); the return value is 0 on success, -6 (capacity) when `cap` is too small
- * (nothing usable is written then), -1 on a bad argument.
+ * (nothing usable is written then), -1 on a bad argument, -2 when the host classes threw (out of memory):
+ * no exception crosses this boundary.
  */
 #ifndef BLAH2HOST_H
 #define BLAH2HOST_H

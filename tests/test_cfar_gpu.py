@@ -134,3 +134,68 @@ def test_cfar2d_reduces_to_1d(b2):
         assert np.array_equal(d1.get_delay(), d2.get_delay())
         assert np.array_equal(d1.get_doppler(), d2.get_doppler())
         assert np.allclose(d1.get_snr(), d2.get_snr(), rtol=0, atol=1e-9)
+
+
+# ---- the one-pass tile kernel against the summed-area-table kernels and the brute-force oracle ----
+@pytest.mark.parametrize("params", [
+    (1e-4, 2, 6, 1, 3, 5, 15.0),      # the bench's window (17 x 9)
+    (1e-3, 0, 1, 0, 0, 0, 0.0),       # one-dimensional, smallest annulus: no Doppler halo at all
+    (1e-3, 0, 0, 0, 1, -10, 0.0),     # Doppler-only training (no delay halo)
+    (1e-3, 5, 27, 3, 21, -10, 0.0),   # the largest window the tile kernel takes with two loads per row: halo 32 x 24
+    (1e-3, 6, 34, 2, 4, 3, 7.0),      # three loads per row (halo 40 columns, the widest the tile kernel takes)
+    (1e-2, 1, 3, 1, 2, -10, 0.0),
+])
+def test_cfar2d_tile_kernel_equals_sat_kernel(b2, params):
+    """Forced kernels on the same device map: identical detection sets (both sum the same fp64 squares;
+    only the summation order differs), on a 201 x 111 map whose tiles are ragged in both directions."""
+    g = load_golden("medium")
+    fs, n, dmin, dmax, fmin, fmax, rh = (int(v) for v in g["params"])
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, bool(rh))
+    m = amb.process(g["x"], g["y"])
+    out = {}
+    for which in ("tile", "sat"):
+        amb.set_cfar2d_kernel(which)
+        d = b2.CfarDetector2D(*params).process(m)
+        out[which] = {(a, b): s for a, b, s in zip(d.get_delay(), d.get_doppler(), d.get_snr())}
+    got = m.data.astype(np.complex128)
+    _, _, _, margin = O.cfar2d(got, amb.delay, amb.doppler, m.noisePower, *params, return_margin=True)
+    row = {f: i for i, f in enumerate(amb.doppler)}
+    for key in set(out["tile"]) ^ set(out["sat"]):
+        i, j = row[key[1]], int(key[0] - amb.delay[0])
+        assert abs(margin[i, j] - 1) < 1e-9, (key, margin[i, j])
+    for key in set(out["tile"]) & set(out["sat"]):
+        assert out["tile"][key] == out["sat"][key]
+    assert len(out["tile"]) > 0
+
+
+def test_cfar2d_tile_kernel_vs_bruteforce_oracle(b2):
+    """The literal four-loop definition (oracle cfar2d_bruteforce) on the device's own small map, incl. delay
+    column 0 as a test cell (it never trains) and every clipped-window case."""
+    g = load_golden("small_sym")
+    fs, n, dmin, dmax, fmin, fmax, rh = (int(v) for v in g["params"])
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, bool(rh))
+    m = amb.process(g["x"], g["y"])
+    amb.set_cfar2d_kernel("tile")
+    got = m.data.astype(np.complex128)
+    for params in [(1e-2, 1, 3, 1, 2, -100, 0.0), (0.2, 0, 2, 0, 1, -100, 0.0), (1e-3, 2, 5, 2, 6, 0, 0.0)]:
+        d = b2.CfarDetector2D(*params).process(m)
+        dl, dp, sn = O.cfar2d_bruteforce(got, amb.delay, amb.doppler, m.noisePower, *params)
+        _, _, _, margin = O.cfar2d(got, amb.delay, amb.doppler, m.noisePower, *params, return_margin=True)
+        ref, dev = set(zip(dl, dp)), set(zip(d.get_delay(), d.get_doppler()))
+        row = {f: i for i, f in enumerate(amb.doppler)}
+        for key in ref ^ dev:
+            assert abs(margin[row[key[1]], int(key[0] - amb.delay[0])] - 1) < 1e-9, key
+        assert len(ref) > 0
+
+
+def test_cfar2d_window_beyond_the_tile_halo_takes_the_sat_kernels(b2):
+    g = load_golden("medium")
+    fs, n, dmin, dmax, fmin, fmax, rh = (int(v) for v in g["params"])
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, bool(rh))
+    m = amb.process(g["x"], g["y"])
+    big = (1e-3, 9, 40, 5, 20, -10, 0.0)  # halo 49 columns x 25 rows: beyond the tile kernel
+    det = check_2d(b2, amb, m, g["map"], g["metrics"][0], big)  # automatic choice: summed-area table
+    assert det.get_nDetections() > 0
+    amb.set_cfar2d_kernel("tile")
+    with pytest.raises(b2.Blah2HipError):
+        b2.CfarDetector2D(*big).process(m)
