@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(PKG, "libblah2hip.so")
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_UNDERFLOW, ERR_NO_DEVICE, ERR_CAPACITY = -1, -2, -3, -4, -5, -6
-FMT_C32, FMT_I16, FMT_F16 = 0, 1, 2
+FMT_C32, FMT_I16, FMT_F16, FMT_I16X_C32Y = 0, 1, 2, 3
 K_RANGE, K_DOPPLER, K_METRICS, K_CFAR, K_SAT_ROWS, K_SAT_COLS, K_ROTATE, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 8
 KERNEL_NAMES = {K_RANGE: "range", K_DOPPLER: "doppler", K_METRICS: "metrics", K_CFAR: "cfar",
                 K_SAT_ROWS: "sat_rows", K_SAT_COLS: "sat_cols", K_ROTATE: "rotate"}
@@ -87,6 +87,7 @@ SYMBOLS = {
     "blah2hip_clutter_process_c64": (C.c_int, [_vp, _vp, _vp, _u32, _vp, C.POINTER(C.c_int)]),
     "blah2hip_clutter_process_c32": (C.c_int, [_vp, _vp, _vp, _u32, _vp, C.POINTER(C.c_int)]),
     "blah2hip_clutter_process_dev": (C.c_int, [_vp, _vp, _vp, _u32, C.c_uint64, _vp, _vp, _vp]),
+    "blah2hip_clutter_process_dev_fmt": (C.c_int, [_vp, C.c_int, _vp, _vp, _u32, C.c_uint64, _vp, C.c_uint64, _vp, _vp]),
     "blah2hip_clutter_set_option": (C.c_int, [_vp, C.c_int, C.c_int64]),
     "blah2hip_clutter_get_dims": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "blah2hip_clutter_read_last": (C.c_int, [_vp, _u32, _vp, _vp, C.POINTER(C.c_int)]),

@@ -38,34 +38,28 @@ __device__ __forceinline__ b2_v4i make_rsrc(const void *base, int bytes)
   return d;
 }
 
-template <class In> struct BufLoad;
-template <> struct BufLoad<InC32> {
+// one channel's sample format: byte stride between samples, the raw register type and its conversion
+struct ChanC32 {
   static constexpr int STRIDE = 8;
   using raw = b2_v2f;
-  static __device__ __forceinline__ const void *xp(const InC32 &in, int64_t i) { return in.x + i; }
-  static __device__ __forceinline__ const void *yp(const InC32 &in, int64_t i) { return in.y + i; }
   template <int IMM> static __device__ __forceinline__ void ld(raw &r, b2_v4i d, int voff, int soff)
   {
     asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:%4" : "=v"(r) : "v"(voff), "s"(d), "s"(soff), "n"(IMM) : "memory");
   }
   static __device__ __forceinline__ cf cvt(raw r) { return cmake(r.x, r.y); }
 };
-template <> struct BufLoad<InI16> {
-  static constexpr int STRIDE = 8; // I1 Q1 I2 Q2
+struct ChanI16 { // one tuner's (I, Q) int16 pair inside the 8-byte I1 Q1 I2 Q2 word
+  static constexpr int STRIDE = 8;
   using raw = uint32_t;
-  static __device__ __forceinline__ const void *xp(const InI16 &in, int64_t i) { return in.iq + 4 * i; }
-  static __device__ __forceinline__ const void *yp(const InI16 &in, int64_t i) { return in.iq + 4 * i + 2; }
   template <int IMM> static __device__ __forceinline__ void ld(raw &r, b2_v4i d, int voff, int soff)
   {
     asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(r) : "v"(voff), "s"(d), "s"(soff), "n"(IMM) : "memory");
   }
   static __device__ __forceinline__ cf cvt(raw r) { return cmake((float)(int16_t)(r & 0xffffu), (float)(int16_t)(r >> 16)); }
 };
-template <> struct BufLoad<InF16> {
+struct ChanF16 {
   static constexpr int STRIDE = 4;
   using raw = uint32_t;
-  static __device__ __forceinline__ const void *xp(const InF16 &in, int64_t i) { return in.x + 2 * i; }
-  static __device__ __forceinline__ const void *yp(const InF16 &in, int64_t i) { return in.y + 2 * i; }
   template <int IMM> static __device__ __forceinline__ void ld(raw &r, b2_v4i d, int voff, int soff)
   {
     asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(r) : "v"(voff), "s"(d), "s"(soff), "n"(IMM) : "memory");
@@ -74,6 +68,33 @@ template <> struct BufLoad<InF16> {
   {
     return cmake((float)__builtin_bit_cast(_Float16, (uint16_t)(r & 0xffffu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(r >> 16)));
   }
+};
+
+// the two channels of an input format: X = reference, Y = surveillance
+template <class In> struct BufLoad;
+template <> struct BufLoad<InC32> {
+  using X = ChanC32;
+  using Y = ChanC32;
+  static __device__ __forceinline__ const void *xp(const InC32 &in, int64_t i) { return in.x + i; }
+  static __device__ __forceinline__ const void *yp(const InC32 &in, int64_t i) { return in.y + i; }
+};
+template <> struct BufLoad<InI16> {
+  using X = ChanI16;
+  using Y = ChanI16;
+  static __device__ __forceinline__ const void *xp(const InI16 &in, int64_t i) { return in.iq + 4 * i; }
+  static __device__ __forceinline__ const void *yp(const InI16 &in, int64_t i) { return in.iq + 4 * i + 2; }
+};
+template <> struct BufLoad<InF16> {
+  using X = ChanF16;
+  using Y = ChanF16;
+  static __device__ __forceinline__ const void *xp(const InF16 &in, int64_t i) { return in.x + 2 * i; }
+  static __device__ __forceinline__ const void *yp(const InF16 &in, int64_t i) { return in.y + 2 * i; }
+};
+template <> struct BufLoad<InI16C32> {
+  using X = ChanI16;
+  using Y = ChanC32;
+  static __device__ __forceinline__ const void *xp(const InI16C32 &in, int64_t i) { return in.iq + 4 * i; }
+  static __device__ __forceinline__ const void *yp(const InI16C32 &in, int64_t i) { return in.y + i; }
 };
 
 // wait until at most N of the loads issued so far are outstanding; r[0..E) are
@@ -103,14 +124,14 @@ template <int N, int E, class R> __device__ __forceinline__ void bufwait(R *r)
 
 // k-th load of a channel, byte offset voff + k*STEP: the multiple of 4096 goes to
 // soffset (SOFF: x, offsets never negative) or must already be in vbase[k*STEP/4096] (y)
-template <class In, int STEP, int E, bool SOFF, int K = 0>
-__device__ __forceinline__ void bufload_chan(typename BufLoad<In>::raw *r, b2_v4i d, const int *vbase)
+template <class Chan, int STEP, int E, bool SOFF, int K = 0>
+__device__ __forceinline__ void bufload_chan(typename Chan::raw *r, b2_v4i d, const int *vbase)
 {
   if constexpr (K < E) {
     constexpr int OFF = K * STEP;
-    if constexpr (SOFF) BufLoad<In>::template ld<(OFF & 4095)>(r[K], d, vbase[0], OFF & ~4095);
-    else BufLoad<In>::template ld<(OFF & 4095)>(r[K], d, vbase[OFF >> 12], 0);
-    bufload_chan<In, STEP, E, SOFF, K + 1>(r, d, vbase);
+    if constexpr (SOFF) Chan::template ld<(OFF & 4095)>(r[K], d, vbase[0], OFF & ~4095);
+    else Chan::template ld<(OFF & 4095)>(r[K], d, vbase[OFF >> 12], 0);
+    bufload_chan<Chan, STEP, E, SOFF, K + 1>(r, d, vbase);
   }
 }
 

@@ -735,7 +735,7 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
 {
   if (!h) return fail(BLAH2HIP_ERR_INVALID, "NULL handle");
   if (n_cpi == 0 || n_cpi > h->dims.max_batch) return fail(BLAH2HIP_ERR_INVALID, "n_cpi outside [1, max_batch]");
-  if (fmt != BLAH2HIP_FMT_C32 && fmt != BLAH2HIP_FMT_I16 && fmt != BLAH2HIP_FMT_F16)
+  if (fmt != BLAH2HIP_FMT_C32 && fmt != BLAH2HIP_FMT_I16 && fmt != BLAH2HIP_FMT_F16 && fmt != BLAH2HIP_FMT_I16X_C32Y)
     return fail(BLAH2HIP_ERR_INVALID, "unknown sample format");
   if (!d_x || (fmt != BLAH2HIP_FMT_I16 && !d_y)) return fail(BLAH2HIP_ERR_INVALID, "NULL input pointer");
   if (n_cpi > 1 && cpi_stride < h->dims.n_used) return fail(BLAH2HIP_ERR_INVALID, "cpi_stride < samples used per CPI");
@@ -772,6 +772,10 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
       InF16 in{(const _Float16 *)d_x, (const _Float16 *)d_y};
       hipLaunchKernelGGL(rotate_kernel<InF16>, grid, dim3(256), 0, st, in, xo, yo,
                          (int64_t)cpi_stride, (int64_t)plane, nrot, m2, h->fs);
+    } else if (fmt == BLAH2HIP_FMT_I16X_C32Y) {
+      InI16C32 in{(const int16_t *)d_x, (const cf *)d_y};
+      hipLaunchKernelGGL(rotate_kernel<InI16C32>, grid, dim3(256), 0, st, in, xo, yo,
+                         (int64_t)cpi_stride, (int64_t)plane, nrot, m2, h->fs);
     } else {
       InI16 in{(const int16_t *)d_x};
       hipLaunchKernelGGL(rotate_kernel<InI16>, grid, dim3(256), 0, st, in, xo, yo,
@@ -791,6 +795,9 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
       rc = launch_range(h, ra, in, st);
     } else if (fmt == BLAH2HIP_FMT_F16) {
       InF16 in{(const _Float16 *)d_x, (const _Float16 *)d_y};
+      rc = launch_range(h, ra, in, st);
+    } else if (fmt == BLAH2HIP_FMT_I16X_C32Y) {
+      InI16C32 in{(const int16_t *)d_x, (const cf *)d_y};
       rc = launch_range(h, ra, in, st);
     } else {
       InI16 in{(const int16_t *)d_x};

@@ -30,6 +30,7 @@
 
 #include "blah2hip.h"
 #include "fft_wg.hpp"
+#include "range_core.hpp"
 #include "timing.hpp"
 
 #include <algorithm>
@@ -89,8 +90,33 @@ __device__ __forceinline__ SegWalk seg_walk(int nSeg)
   return w;
 }
 
+// In: InC32 (two complex fp32 planes) or InI16 (the .rspduo words, range_core.hpp); in.lx / in.ly read sample i of
+// the reference / surveillance channel
+// One channel of a CPI as something indexable by sample: a plain `const cf *` for the fp32 planes (the kernels are then
+// token for token what they were: the correlation kernels sit at the 256-register cap, and reaching the same loads through
+// an accessor object made the register allocator spill 34 values in the inner loop), a converting view for the .rspduo words.
+struct I16Chan {
+  const int16_t *p; // first int16 of this channel's (I, Q) pair in sample 0
+  __device__ __forceinline__ cf operator[](uint32_t i) const
+  {
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(p + 4 * (size_t)i); // (I, Q) as one 4-byte load
+    return cmake((float)(int16_t)(w & 0xffffu), (float)(int16_t)(w >> 16));
+  }
+};
+template <class In> struct ChanOf;
+template <> struct ChanOf<InC32> {
+  using type = const cf *;
+  static __device__ __forceinline__ type x(const void *px, const void *, int64_t i) { return (const cf *)px + i; }
+  static __device__ __forceinline__ type y(const void *, const void *py, int64_t i) { return (const cf *)py + i; }
+};
+template <> struct ChanOf<InI16> {
+  using type = I16Chan;
+  static __device__ __forceinline__ type x(const void *px, const void *, int64_t i) { return I16Chan{(const int16_t *)px + 4 * i}; }
+  static __device__ __forceinline__ type y(const void *px, const void *, int64_t i) { return I16Chan{(const int16_t *)px + 4 * i + 2}; }
+};
+
 struct CorrArgs {
-  const cf *x, *y;
+  const void *x, *y; // InC32: the two planes; InI16: x = the interleaved buffer, y unused
   int64_t cpiStride;
   uint32_t N;
   XsMap xs;
@@ -103,7 +129,7 @@ struct CorrArgs {
 // grid (nJobs, nCpi): per segment FFT(x' = zero-padded xs segment) ONCE, then the
 // xs window (-> r) and the y window (-> b) against it; both partial correlations
 // accumulate in registers across the workgroup's segments.
-template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_kernel(CorrArgs a)
+template <int R3, class In> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_kernel(CorrArgs a)
 {
   using W = WgFft<R3>;
   constexpr int T = W::T;
@@ -112,8 +138,8 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_ker
   cf *Q = P + W::A_ELEMS;
   const int t = threadIdx.x;
   const int cpi = blockIdx.y;
-  const cf *X = a.x + (int64_t)cpi * a.cpiStride;
-  const cf *Y = a.y + (int64_t)cpi * a.cpiStride;
+  const typename ChanOf<In>::type X = ChanOf<In>::x(a.x, a.y, (int64_t)cpi * a.cpiStride);
+  const typename ChanOf<In>::type Y = ChanOf<In>::y(a.x, a.y, (int64_t)cpi * a.cpiStride);
   cf tw1[15], tw3[16];
   W::load_twiddles(t, a.tw, tw1, tw3);
 
@@ -129,8 +155,8 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_ker
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const uint32_t nw = wrapN(n0 + (uint32_t)(t + T * k), a.N); // circular window index, n0 + m < N + F
-      wv[k] = X[xs_index(nw, a.xs)];                               // xs window (mode r)
-      yw[k] = Y[nw];                                               // y window (mode b)
+      wv[k] = X[xs_index(nw, a.xs)];                      // xs window (mode r)
+      yw[k] = Y[nw];                                      // y window (mode b)
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -191,7 +217,7 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_ker
 // more product, tail (last nBins-1 samples of xs) against head (first nBins-1 of xs / y) shifted by
 // tau = nBins - 1, i.e. times W_F^(tau m), done by the last workgroup.  Mathematically identical.
 struct CorrHalfArgs {
-  const cf *x, *y;
+  const void *x, *y;
   int64_t cpiStride;
   uint32_t N;
   XsMap xs;
@@ -201,7 +227,7 @@ struct CorrHalfArgs {
   float scale;
 };
 
-template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_half_kernel(CorrHalfArgs a)
+template <int R3, class In> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_half_kernel(CorrHalfArgs a)
 {
   using W = WgFft<R3>;
   constexpr int T = W::T, L = W::F / 2;
@@ -210,8 +236,8 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_hal
   cf *Q = P + W::A_ELEMS;
   const int t = threadIdx.x;
   const int cpi = blockIdx.y;
-  const cf *X = a.x + (int64_t)cpi * a.cpiStride;
-  const cf *Y = a.y + (int64_t)cpi * a.cpiStride;
+  const typename ChanOf<In>::type X = ChanOf<In>::x(a.x, a.y, (int64_t)cpi * a.cpiStride);
+  const typename ChanOf<In>::type Y = ChanOf<In>::y(a.x, a.y, (int64_t)cpi * a.cpiStride);
   cf tw1[15], tw3[16];
   W::load_twiddles(t, a.tw, tw1, tw3);
   // (-1)^m for this thread's spectrum registers: m = q + 16 r + 256 s with q = (t + T j) / 16 and T a
@@ -231,9 +257,9 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_hal
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const uint32_t m = (uint32_t)(t + T * k);
-      const bool in = m < len;
-      const cf s = X[xs_index(in ? n0 + m : 0u, a.xs)];
-      v[k] = in ? s : cmake(0.f, 0.f);
+      const bool inr = m < len;
+      const cf s = X[xs_index(inr ? n0 + m : 0u, a.xs)];
+      v[k] = inr ? s : cmake(0.f, 0.f);
     }
 #pragma unroll
     for (int k = 8; k < 16; k++) v[k] = cmake(0.f, 0.f);
@@ -242,9 +268,9 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_hal
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const uint32_t m = (uint32_t)(t + T * k);
-      const bool in = m < len;
-      const cf s = Y[in ? n0 + m : 0u];
-      v[k] = in ? s : cmake(0.f, 0.f);
+      const bool inr = m < len;
+      const cf s = Y[inr ? n0 + m : 0u];
+      v[k] = inr ? s : cmake(0.f, 0.f);
     }
 #pragma unroll
     for (int k = 8; k < 16; k++) v[k] = cmake(0.f, 0.f);
@@ -484,7 +510,7 @@ __global__ __launch_bounds__(1024) void clutter_solve_kernel(SolveArgs a)
 
 // ---- overlap-save FIR: y_out = y - (w * xs)[0..N) ----------------------------
 struct FirArgs {
-  const cf *x, *y;
+  const void *x, *y;
   cf *yout;
   int64_t cpiStride, outStride;
   uint32_t N;
@@ -496,7 +522,7 @@ struct FirArgs {
   float scale;
 };
 
-template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_fir_kernel(FirArgs a)
+template <int R3, class In> __global__ __launch_bounds__(16 * R3, 2) void clutter_fir_kernel(FirArgs a)
 {
   using W = WgFft<R3>;
   constexpr int T = W::T;
@@ -505,8 +531,8 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_fir_kern
   cf *Q = P + W::A_ELEMS;
   const int t = threadIdx.x;
   const int cpi = blockIdx.y;
-  const cf *X = a.x + (int64_t)cpi * a.cpiStride;
-  const cf *Y = a.y + (int64_t)cpi * a.cpiStride;
+  const typename ChanOf<In>::type X = ChanOf<In>::x(a.x, a.y, (int64_t)cpi * a.cpiStride);
+  const typename ChanOf<In>::type Y = ChanOf<In>::y(a.x, a.y, (int64_t)cpi * a.cpiStride);
   cf *O = a.yout + (int64_t)cpi * a.outStride;
   const bool ok = a.ok[cpi] != 0;
   cf tw1[15], tw3[16];
@@ -539,9 +565,9 @@ template <int R3> __global__ __launch_bounds__(16 * R3, 2) void clutter_fir_kern
     for (int k = 0; k < 16; k++) {
       const int m = t + T * k;
       const int src = n0 - hist + m;
-      const bool in = src >= 0 && src < N;
-      const cf xv = X[xs_index(in ? (uint32_t)src : 0u, a.xs)];
-      v[k] = in ? xv : cmake(0.f, 0.f);
+      const bool inr = src >= 0 && src < N;
+      const cf xv = X[xs_index(inr ? (uint32_t)src : 0u, a.xs)];
+      v[k] = inr ? xv : cmake(0.f, 0.f);
       // y of the output sample this register will end up holding (n = src)
       const bool outv = (m >= hist) && (m < hist + a.segLen) && (src < N);
       yv[k] = Y[outv ? src : 0];
@@ -665,14 +691,14 @@ int clutter_plan(blah2hip_clutter_s *h)
   return BLAH2HIP_OK;
 }
 
-template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const cf *y, uint32_t nCpi,
-                                     int64_t stride, cf *yout, int64_t outStride, int32_t *ok, hipStream_t st)
+template <int R3, class In> int launch_clutter(blah2hip_clutter_s *h, const void *px, const void *py, uint32_t nCpi,
+                                               int64_t stride, cf *yout, int64_t outStride, int32_t *ok, hipStream_t st)
 {
   using W = WgFft<R3>;
   const size_t lds = (size_t)(W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
   // once per (device, kernel), see capi.hip
-  CHIP(blah2hip_ensure_lds_((const void *)clutter_corr_kernel<R3>, (int)lds));
-  CHIP(blah2hip_ensure_lds_((const void *)clutter_fir_kernel<R3>, (int)lds));
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_corr_kernel<R3, In>, (int)lds));
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_fir_kernel<R3, In>, (int)lds));
   CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<1>, 160 * 1024 - 2048));
   CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<2>, 160 * 1024 - 2048));
   CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<4>, 160 * 1024 - 2048));
@@ -692,19 +718,19 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   const int firGrid = std::min(h->firGrid, up8((2 * slots + (int)nCpi - 1) / (int)nCpi));
   CHIP(h->timer.tic(BLAH2HIP_CK_CORR, st));
   if (h->corrHalf) {
-    CHIP(blah2hip_ensure_lds_((const void *)clutter_corr_half_kernel<R3>, (int)lds));
+    CHIP(blah2hip_ensure_lds_((const void *)clutter_corr_half_kernel<R3, In>, (int)lds));
     CorrHalfArgs ha;
-    ha.x = x; ha.y = y; ha.cpiStride = stride; ha.N = h->N; ha.xs = xs;
+    ha.x = px; ha.y = py; ha.cpiStride = stride; ha.N = h->N; ha.xs = xs;
     ha.nBins = h->nBins; ha.nSeg = (int)((h->N + (uint32_t)(h->F / 2) - 1) / (uint32_t)(h->F / 2));
     ha.per = (ha.nSeg + nJobs - 1) / nJobs; ha.nJobs = nJobs;
     ha.tw = h->d_tw; ha.partial = h->d_partial; ha.scale = 1.0f / (float)h->F;
-    hipLaunchKernelGGL(clutter_corr_half_kernel<R3>, dim3(nJobs, nCpi), dim3(W::T), lds, st, ha);
+    hipLaunchKernelGGL((clutter_corr_half_kernel<R3, In>), dim3(nJobs, nCpi), dim3(W::T), lds, st, ha);
   } else {
     CorrArgs ca;
-    ca.x = x; ca.y = y; ca.cpiStride = stride; ca.N = h->N; ca.xs = xs;
+    ca.x = px; ca.y = py; ca.cpiStride = stride; ca.N = h->N; ca.xs = xs;
     ca.nBins = h->nBins; ca.segLen = h->segLen; ca.nSeg = h->nSeg; ca.nJobs = nJobs;
     ca.tw = h->d_tw; ca.partial = h->d_partial; ca.scale = 1.0f / (float)h->F;
-    hipLaunchKernelGGL(clutter_corr_kernel<R3>, dim3(nJobs, nCpi), dim3(W::T), lds, st, ca);
+    hipLaunchKernelGGL((clutter_corr_kernel<R3, In>), dim3(nJobs, nCpi), dim3(W::T), lds, st, ca);
   }
   CHIP(hipGetLastError());
   CHIP(h->timer.toc(BLAH2HIP_CK_CORR, st));
@@ -727,11 +753,11 @@ template <int R3> int launch_clutter(blah2hip_clutter_s *h, const cf *x, const c
   CHIP(h->timer.toc(BLAH2HIP_CK_SOLVE, st));
 
   FirArgs fa;
-  fa.x = x; fa.y = y; fa.yout = yout; fa.cpiStride = stride; fa.outStride = outStride; fa.N = h->N; fa.xs = xs;
+  fa.x = px; fa.y = py; fa.yout = yout; fa.cpiStride = stride; fa.outStride = outStride; fa.N = h->N; fa.xs = xs;
   fa.nBins = h->nBins; fa.segLen = h->segLen; fa.nSeg = h->nSeg; fa.w = h->d_w; fa.ok = ok; fa.tw = h->d_tw;
   fa.scale = 1.0f / (float)h->F;
   CHIP(h->timer.tic(BLAH2HIP_CK_FIR, st));
-  hipLaunchKernelGGL(clutter_fir_kernel<R3>, dim3(firGrid, nCpi), dim3(W::T), lds, st, fa);
+  hipLaunchKernelGGL((clutter_fir_kernel<R3, In>), dim3(firGrid, nCpi), dim3(W::T), lds, st, fa);
   CHIP(hipGetLastError());
   CHIP(h->timer.toc(BLAH2HIP_CK_FIR, st));
   h->lastOk = ok;
@@ -876,22 +902,39 @@ int blah2hip_clutter_get_timing(blah2hip_clutter_t h, double *ms_total, uint32_t
   return BLAH2HIP_OK;
 }
 
-int blah2hip_clutter_process_dev(blah2hip_clutter_t h, const void *d_x, const void *d_y, uint32_t n_cpi,
-                                 uint64_t cpi_stride, void *d_y_out, int32_t *d_ok, void *stream)
+int blah2hip_clutter_process_dev_fmt(blah2hip_clutter_t h, int fmt, const void *d_x, const void *d_y, uint32_t n_cpi,
+                                     uint64_t cpi_stride, void *d_y_out, uint64_t out_stride, int32_t *d_ok, void *stream)
 {
-  if (!h || !d_x || !d_y || !d_y_out) CFAIL(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (!h || !d_x || !d_y_out) CFAIL(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (fmt != BLAH2HIP_FMT_C32 && fmt != BLAH2HIP_FMT_I16) CFAIL(BLAH2HIP_ERR_INVALID, "clutter filter input: BLAH2HIP_FMT_C32 or BLAH2HIP_FMT_I16");
+  if (fmt == BLAH2HIP_FMT_C32 && !d_y) CFAIL(BLAH2HIP_ERR_INVALID, "NULL argument");
   if (n_cpi == 0 || n_cpi > h->maxBatch) CFAIL(BLAH2HIP_ERR_INVALID, "n_cpi outside [1, max_batch]");
-  if (n_cpi > 1 && cpi_stride < h->N) CFAIL(BLAH2HIP_ERR_INVALID, "cpi_stride < nSamples");
+  if (n_cpi > 1 && (cpi_stride < h->N || out_stride < h->N)) CFAIL(BLAH2HIP_ERR_INVALID, "cpi_stride / out_stride < nSamples");
   CHIP(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   int32_t *ok = d_ok ? d_ok : h->d_ok;
-  // in-place operation is safe: every output sample is read (as y) by the one
+  // in-place operation (FMT_C32, d_y_out == d_y) is safe: every output sample is read (as y) by the one
   // thread that writes it, and x is never written
-  switch (h->r3) {
-  case 4: return launch_clutter<4>(h, (const cf *)d_x, (const cf *)d_y, n_cpi, (int64_t)cpi_stride, (cf *)d_y_out, (int64_t)cpi_stride, ok, st);
-  case 8: return launch_clutter<8>(h, (const cf *)d_x, (const cf *)d_y, n_cpi, (int64_t)cpi_stride, (cf *)d_y_out, (int64_t)cpi_stride, ok, st);
-  default: return launch_clutter<16>(h, (const cf *)d_x, (const cf *)d_y, n_cpi, (int64_t)cpi_stride, (cf *)d_y_out, (int64_t)cpi_stride, ok, st);
+  const int64_t cs = (int64_t)cpi_stride, os = (int64_t)out_stride;
+  cf *yo = (cf *)d_y_out;
+  if (fmt == BLAH2HIP_FMT_I16) {
+    switch (h->r3) {
+    case 4: return launch_clutter<4, InI16>(h, d_x, nullptr, n_cpi, cs, yo, os, ok, st);
+    case 8: return launch_clutter<8, InI16>(h, d_x, nullptr, n_cpi, cs, yo, os, ok, st);
+    default: return launch_clutter<16, InI16>(h, d_x, nullptr, n_cpi, cs, yo, os, ok, st);
+    }
   }
+  switch (h->r3) {
+  case 4: return launch_clutter<4, InC32>(h, d_x, d_y, n_cpi, cs, yo, os, ok, st);
+  case 8: return launch_clutter<8, InC32>(h, d_x, d_y, n_cpi, cs, yo, os, ok, st);
+  default: return launch_clutter<16, InC32>(h, d_x, d_y, n_cpi, cs, yo, os, ok, st);
+  }
+}
+
+int blah2hip_clutter_process_dev(blah2hip_clutter_t h, const void *d_x, const void *d_y, uint32_t n_cpi,
+                                 uint64_t cpi_stride, void *d_y_out, int32_t *d_ok, void *stream)
+{
+  return blah2hip_clutter_process_dev_fmt(h, BLAH2HIP_FMT_C32, d_x, d_y, n_cpi, cpi_stride, d_y_out, cpi_stride, d_ok, stream);
 }
 
 int blah2hip_clutter_process_c32(blah2hip_clutter_t h, const float *x, const float *y, uint32_t n, float *y_out, int *ok)

@@ -56,25 +56,28 @@ template <int T, int E, class In, int EX = E>
 __device__ __forceinline__ void bufload_seg(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, cf *v, cf *yv)
 {
   using B = BufLoad<In>;
-  constexpr int STEP = T * B::STRIDE;
-  constexpr int NV = ((E - 1) * STEP >> 12) + 1;
+  using CX = typename B::X;
+  using CY = typename B::Y;
+  constexpr int STEPX = T * CX::STRIDE, STEPY = T * CY::STRIDE;
+  constexpr int NV = ((E - 1) * STEPY >> 12) + 1;
   const int s0 = s * p.segLen;
   const int cnt = min(p.segLen, p.nCorr - s0);
-  const b2_v4i xd = make_rsrc(B::xp(in, pulseBase + s0), cnt * B::STRIDE);
-  const b2_v4i yd = make_rsrc(B::yp(in, pulseBase), p.nCorr * B::STRIDE);
-  int vx[1] = {t * B::STRIDE};
+  const b2_v4i xd = make_rsrc(B::xp(in, pulseBase + s0), cnt * CX::STRIDE);
+  const b2_v4i yd = make_rsrc(B::yp(in, pulseBase), p.nCorr * CY::STRIDE);
+  int vx[1] = {t * CX::STRIDE};
   int vy[NV];
 #pragma unroll
-  for (int j = 0; j < NV; j++) vy[j] = (s0 + p.delayMin + t) * B::STRIDE + j * 4096; // may be negative: reads as zero
-  typename B::raw xr[EX], yr[E];
-  bufload_chan<In, STEP, EX, true>(xr, xd, vx);
-  bufload_chan<In, STEP, E, false>(yr, yd, vy);
+  for (int j = 0; j < NV; j++) vy[j] = (s0 + p.delayMin + t) * CY::STRIDE + j * 4096; // may be negative: reads as zero
+  typename CX::raw xr[EX];
+  typename CY::raw yr[E];
+  bufload_chan<CX, STEPX, EX, true>(xr, xd, vx);
+  bufload_chan<CY, STEPY, E, false>(yr, yd, vy);
   bufwait<E, EX>(xr);
 #pragma unroll
-  for (int k = 0; k < EX; k++) v[k] = B::cvt(xr[k]);
+  for (int k = 0; k < EX; k++) v[k] = CX::cvt(xr[k]);
   bufwait<0, E>(yr);
 #pragma unroll
-  for (int k = 0; k < E; k++) yv[k] = B::cvt(yr[k]);
+  for (int k = 0; k < E; k++) yv[k] = CY::cvt(yr[k]);
 }
 
 // ILV: the x and y transforms advance together through their own exchange buffers
@@ -236,29 +239,32 @@ __device__ __forceinline__ void bufload_seg_w(const In &in, const RangePlan &p, 
 {
   static_assert((NX == 24 || NX == 32) && (NY == 28 || NY == 32), "");
   using B = BufLoad<In>;
-  constexpr int STEP = 64 * B::STRIDE;
-  constexpr int NV = (31 * STEP >> 12) + 1;
+  using CX = typename B::X;
+  using CY = typename B::Y;
+  constexpr int STEPX = 64 * CX::STRIDE, STEPY = 64 * CY::STRIDE;
+  constexpr int NV = (31 * STEPY >> 12) + 1;
   const int s0 = s * p.segLen;
   const int cnt = min(p.segLen, p.nCorr - s0);
-  const b2_v4i xd = make_rsrc(B::xp(in, pulseBase + s0), cnt * B::STRIDE);
-  const b2_v4i yd = make_rsrc(B::yp(in, pulseBase), p.nCorr * B::STRIDE);
-  int vx[1] = {t * B::STRIDE};
+  const b2_v4i xd = make_rsrc(B::xp(in, pulseBase + s0), cnt * CX::STRIDE);
+  const b2_v4i yd = make_rsrc(B::yp(in, pulseBase), p.nCorr * CY::STRIDE);
+  int vx[1] = {t * CX::STRIDE};
   int vy[NV];
 #pragma unroll
-  for (int j = 0; j < NV; j++) vy[j] = (s0 + p.delayMin + t) * B::STRIDE + j * 4096; // may be negative: reads as zero
-  typename B::raw xr[NX], yr[NY];
-  bufload_chan<In, STEP, NX, true>(xr, xd, vx);
-  bufload_chan<In, STEP, NY, false>(yr, yd, vy);
+  for (int j = 0; j < NV; j++) vy[j] = (s0 + p.delayMin + t) * CY::STRIDE + j * 4096; // may be negative: reads as zero
+  typename CX::raw xr[NX];
+  typename CY::raw yr[NY];
+  bufload_chan<CX, STEPX, NX, true>(xr, xd, vx);
+  bufload_chan<CY, STEPY, NY, false>(yr, yd, vy);
   bufwait<NY + NX - 16, 16>(xr);
   if constexpr (NX == 32) bufwait<NY, 16>(xr + 16);
   else bufwait<NY, 8>(xr + 16);
 #pragma unroll
-  for (int k = 0; k < NX; k++) v[k] = B::cvt(xr[k]);
+  for (int k = 0; k < NX; k++) v[k] = CX::cvt(xr[k]);
   bufwait<NY - 16, 16>(yr);
   if constexpr (NY == 32) bufwait<0, 16>(yr + 16);
   else { bufwait<4, 8>(yr + 16); bufwait<0, 4>(yr + 24); }
 #pragma unroll
-  for (int k = 0; k < NY; k++) yv[k] = B::cvt(yr[k]);
+  for (int k = 0; k < NY; k++) yv[k] = CY::cvt(yr[k]);
 }
 
 // lags z[t + 64*c] of one pulse into the tiled range map: lane t owns position t & 15 of tile

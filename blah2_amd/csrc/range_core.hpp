@@ -45,6 +45,7 @@ struct InC32 {
   const cf *y;
   B2_HD cf lx(int64_t i) const { return x[i]; }
   B2_HD cf ly(int64_t i) const { return y[i]; }
+  B2_HD InC32 at(int64_t i) const { return InC32{x + i, y + i}; } // the same channels, sample i first
 };
 
 // .rspduo wire layout: int16 I1 Q1 I2 Q2 per sample pair
@@ -53,6 +54,17 @@ struct InI16 {
   const int16_t *iq;
   B2_HD cf lx(int64_t i) const { return cmake((float)iq[4 * i], (float)iq[4 * i + 1]); }
   B2_HD cf ly(int64_t i) const { return cmake((float)iq[4 * i + 2], (float)iq[4 * i + 3]); }
+  B2_HD InI16 at(int64_t i) const { return InI16{iq + 4 * i}; }
+};
+
+// Reference channel straight from the .rspduo words, surveillance channel from a complex fp32 plane: what the
+// ambiguity stage reads behind the clutter filter of a replay (the filter leaves x untouched and writes the
+// filtered y as fp32, WienerHopf.cpp:156-160), without a conversion pass over x.
+struct InI16C32 {
+  const int16_t *iq;
+  const cf *y;
+  B2_HD cf lx(int64_t i) const { return cmake((float)iq[4 * i], (float)iq[4 * i + 1]); }
+  B2_HD cf ly(int64_t i) const { return y[i]; }
 };
 
 // load_seg_* / mask_seg_* below DEFINE the segment windows (clamped index, then a

@@ -387,6 +387,12 @@ class WienerHopf:
         """Enqueue on ``stream``: device complex64 planes, output may alias d_y."""
         check(self._L.blah2hip_clutter_process_dev(self._h, d_x, d_y, n_cpi, cpi_stride, d_y_out, d_ok, stream))
 
+    def process_dev_fmt(self, fmt, d_x, d_y, n_cpi, cpi_stride, d_y_out, out_stride, d_ok=None, stream=0):
+        """Enqueue on ``stream`` with the input in format ``fmt`` (FMT_C32 planes, or FMT_I16: d_x = the interleaved
+        .rspduo buffer); the filtered channel is written as a complex64 plane with ``out_stride`` samples per CPI."""
+        check(self._L.blah2hip_clutter_process_dev_fmt(self._h, fmt, d_x, d_y, n_cpi, cpi_stride, d_y_out, out_stride,
+                                                       d_ok, stream))
+
     def _refresh_dims(self):
         nb, fl, sl = C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(self._L.blah2hip_clutter_get_dims(self._h, C.byref(nb), C.byref(fl), C.byref(sl)))

@@ -3,23 +3,39 @@
 The reference replays a capture by pushing int16 I1 Q1 I2 Q2 samples into the
 two IqData FIFOs (src/capture/rspduo/RspDuo.cpp:150-179) and the processing
 thread cuts non-overlapping CPIs of nSamples out of them (blah2.cpp:254-258):
-CPI k is exactly file bytes [k*nSamples*8, (k+1)*nSamples*8).  Ambiguity,
-WienerHopf, CfarDetector1D and Map::set_metrics carry no state from one CPI to
-the next, so whole CPIs shard round-robin over the ranks with NO data-path
-collective; only the per-CPI results (two doubles + the detection list) are
-gathered to rank 0, which emits them in file order.
+CPI k is exactly file bytes [k*nSamples*8, (k+1)*nSamples*8); each CPI's
+products are emitted as soon as it is done, in order (blah2.cpp:299-321).
+Ambiguity, WienerHopf, CfarDetector1D and Map::set_metrics carry no state from
+one CPI to the next, so the capture shards over the ranks with NO data-path
+collective.
 
-`processor` is any callable ``(int16 array [B, nSamples, 4]) -> list of B
-result dicts``; :func:`gpu_processor` builds the real one on the HIP engine.
-The sharding / gathering logic itself has no GPU dependency and is covered by
-the world_size=2 gloo tests.
+The unit of work is a BATCH of `batch` consecutive CPIs (one contiguous read,
+one launch of the device chain).  Batch b belongs to rank b mod world; a ROUND
+is `world` consecutive batches.  Only the per-CPI results (two doubles + the
+detection list, and the map when JSON is wanted) travel: after each round the
+ranks' results are gathered to rank 0, which emits them in file order -- so
+output streams while the capture is still being processed and every rank
+holds one round of results at most.
+
+On a rank the batches flow through a pipeline (:class:`GpuChain`): reader
+threads fill a ring of pinned host buffers straight from the file (pread), a
+copy stream uploads batch k+1 and brings back the results of batch k-1 while
+the kernels of batch k run on the compute stream; HIP events order the three.
+At 16 MB of int16 per 1 s CPI the GPU needs 9 us for what PCIe needs 290 us to
+deliver: a replay is bound by the host link, and the pipeline's job is to keep
+that link busy (tools/replay_bench.py measures both).
+
+`processor` is a :class:`GpuChain`, or -- for the CPU tests of the sharding,
+which has no GPU dependency -- any callable ``(int16 array [B, nSamples, 4])
+-> list of B result dicts``.
 """
 from __future__ import annotations
 
 import json
 import os
 import sys
-from typing import Callable, List, Optional
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, Iterator, List, Optional, Tuple
 
 import numpy as np
 
@@ -27,7 +43,7 @@ BYTES_PER_SAMPLE = 8  # int16 I1 Q1 I2 Q2
 
 
 class RspduoFile:
-    """Memory-mapped .rspduo capture, indexed by CPI."""
+    """A .rspduo capture, indexed by CPI (memory-mapped for random access; :meth:`read_into` for streaming)."""
 
     def __init__(self, path: str, n_samples: int):
         self.path = path
@@ -35,6 +51,7 @@ class RspduoFile:
         size = os.path.getsize(path)
         self.n_cpis = size // (self.n_samples * BYTES_PER_SAMPLE)
         self._mm = np.memmap(path, dtype="<i2", mode="r") if size else np.zeros(0, dtype="<i2")
+        self._fd = None
 
     def cpi(self, k: int) -> np.ndarray:
         if not 0 <= k < self.n_cpis:
@@ -45,133 +62,284 @@ class RspduoFile:
     def batch(self, ks) -> np.ndarray:
         return np.stack([self.cpi(k) for k in ks]) if len(ks) else np.zeros((0, self.n_samples, 4), dtype=np.int16)
 
+    def read_into(self, k0: int, count: int, dst: np.ndarray, pool: Optional[ThreadPoolExecutor] = None, parts: int = 16):
+        """CPIs k0 .. k0+count-1 (contiguous in the file) into the first bytes of ``dst`` (any writable buffer, e.g. a
+        pinned one) with pread, split over ``pool``'s threads: a page-cache copy runs at ~10 GB/s per thread, PCIe
+        takes 50+."""
+        if self._fd is None:
+            self._fd = os.open(self.path, os.O_RDONLY)
+        nbytes = count * self.n_samples * BYTES_PER_SAMPLE
+        off0 = k0 * self.n_samples * BYTES_PER_SAMPLE
+        mv = memoryview(dst).cast("B")[:nbytes]
+
+        def rd(a, b):
+            pos = a
+            while pos < b:
+                got = os.preadv(self._fd, [mv[pos:b]], off0 + pos)
+                if got <= 0:
+                    raise IOError(f"short read from {self.path} at {off0 + pos}")
+                pos += got
+
+        if pool is None or parts <= 1 or nbytes < (1 << 22):
+            rd(0, nbytes)
+            return
+        step = -(-nbytes // parts)
+        step += -step % 4096
+        futs = [pool.submit(rd, a, min(a + step, nbytes)) for a in range(0, nbytes, step)]
+        for f in futs:
+            f.result()
+
+    def close(self):
+        if self._fd is not None:
+            os.close(self._fd)
+            self._fd = None
+
 
 def shard_cpis(n_cpis: int, rank: int, world: int) -> List[int]:
-    """Round-robin: rank r owns CPIs r, r+world, r+2*world, ..."""
+    """Round-robin over single CPIs (batch = 1): rank r owns CPIs r, r+world, r+2*world, ..."""
     return list(range(rank, n_cpis, world))
 
 
-def replay(capture: RspduoFile, processor: Callable, batch: int = 1, dist=None,
-           limit: Optional[int] = None) -> Optional[List[dict]]:
-    """Processes every CPI of ``capture`` exactly once across the ranks of
-    ``dist`` (a torch.distributed module with an initialised default group, or
-    None for a single process).  Returns the per-CPI results in file order on
-    rank 0 and None elsewhere."""
+def shard_batches(n_cpis: int, batch: int, rank: int, world: int) -> List[Tuple[int, int]]:
+    """(first CPI, count) of the batches rank ``rank`` owns: batch b = CPIs [b*batch, (b+1)*batch) goes to rank b % world."""
+    n_batches = -(-n_cpis // batch) if n_cpis else 0
+    return [(b * batch, min(batch, n_cpis - b * batch)) for b in range(rank, n_batches, world)]
+
+
+def _iter_local(capture: RspduoFile, processor, mine) -> Iterator[List[dict]]:
+    """Results of this rank's batches, one list per batch, in order."""
+    if hasattr(processor, "run_batches"):  # the pipelined device chain
+        yield from processor.run_batches(capture, mine)
+        return
+    for k0, cnt in mine:
+        out = processor(capture.batch(range(k0, k0 + cnt)))
+        if len(out) != cnt:
+            raise RuntimeError("processor returned a different number of results than CPIs")
+        yield [dict(r, cpi=k0 + i) for i, r in enumerate(out)]
+
+
+def replay(capture: RspduoFile, processor, batch: int = 1, dist=None, limit: Optional[int] = None,
+           emit: Optional[Callable[[dict], None]] = None) -> Optional[List[dict]]:
+    """Processes every CPI of ``capture`` exactly once across the ranks of ``dist`` (a torch.distributed module with an
+    initialised default group, or None for a single process).
+
+    With ``emit``: rank 0 calls ``emit(result)`` for every CPI in file order, round by round, while later rounds are still
+    being processed (bounded memory), and the function returns the number of CPIs on rank 0.  Without: the results are
+    collected and returned as a list on rank 0 (tests, small captures).  Other ranks return None."""
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
     n = capture.n_cpis if limit is None else min(limit, capture.n_cpis)
-    mine = shard_cpis(n, rank, world)
-    local = []
-    for i in range(0, len(mine), batch):
-        ks = mine[i:i + batch]
-        out = processor(capture.batch(ks))
-        if len(out) != len(ks):
-            raise RuntimeError("processor returned a different number of results than CPIs")
-        for k, r in zip(ks, out):
-            local.append(dict(r, cpi=k))
-    if dist is None:
-        return local
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(local, gathered, dst=0)
-    # a counter every rank agrees on (the throughput figure's numerator)
-    import torch
-    cnt = torch.tensor([len(local)], dtype=torch.int64)
-    if dist.get_backend() == "nccl":
-        cnt = cnt.cuda()
-    dist.all_reduce(cnt)
-    if int(cnt.item()) != n:
-        raise RuntimeError(f"replay processed {int(cnt.item())} CPIs, expected {n}")
+    mine = shard_batches(n, batch, rank, world)
+    n_batches = -(-n // batch) if n else 0
+    n_rounds = -(-n_batches // world) if n_batches else 0
+    collected: Optional[List[dict]] = [] if (emit is None and rank == 0) else None
+    expect = 0
+    done = 0
+
+    def deliver(results: List[dict]):
+        nonlocal expect, done
+        for r in results:
+            if r["cpi"] != expect:
+                raise RuntimeError(f"replay order: CPI {r['cpi']} arrived where {expect} was due")
+            expect += 1
+            done += 1
+            if emit is not None:
+                emit(r)
+            else:
+                collected.append(r)
+
+    local = _iter_local(capture, processor, mine)
+    for g in range(n_rounds):
+        own = next(local) if g * world + rank < n_batches else []
+        if dist is None:
+            deliver(own)
+            continue
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(own, gathered, dst=0)  # one round: `world` batches, rank order = file order
+        if rank == 0:
+            for part in gathered:
+                deliver(part)
+    if dist is not None:
+        # a counter every rank agrees on (the throughput figure's numerator)
+        import torch
+        cnt = torch.tensor([sum(c for _, c in mine)], dtype=torch.int64)
+        if dist.get_backend() == "nccl":
+            cnt = cnt.cuda()
+        dist.all_reduce(cnt)
+        if int(cnt.item()) != n:
+            raise RuntimeError(f"replay processed {int(cnt.item())} CPIs, expected {n}")
     if rank != 0:
         return None
-    merged = sorted((r for part in gathered for r in part), key=lambda r: r["cpi"])
-    assert [r["cpi"] for r in merged] == list(range(n))
-    return merged
+    if done != n:
+        raise RuntimeError(f"replay emitted {done} CPIs, expected {n}")
+    return done if emit is not None else collected
 
 
-def gpu_processor(cfg: dict, device: int = 0, batch: int = 1, want_map: bool = False):
-    """blah2.cpp:268-287 on the HIP engine for batches of CPIs, device resident from the int16 upload
-    to the hit lists: clutter filter (optional) -> ambiguity -> metrics -> CFAR (blah2hip_cfar1d_dev),
-    then Centroid and Interpolate (host arithmetic on a handful of detections) when ``nCentroid`` is
-    configured.  ``cfg`` carries the keys of the reference's config.yml ``process`` section plus
-    ``fs`` and ``n_samples``.  One D2H copy of {metrics, hit records, ok flags} per batch; the maps
-    come back only with ``want_map`` (the --json mode needs them, blah2.cpp:304).
+class GpuChain:
+    """blah2.cpp:268-287 on the HIP engine for batches of CPIs, device resident from the int16 upload to the hit lists:
+    clutter filter (optional; reads the .rspduo words directly) -> ambiguity -> metrics -> CFAR (blah2hip_cfar1d_dev),
+    then Centroid and Interpolate (host arithmetic on a handful of detections) when ``nCentroid`` is configured.  ``cfg``
+    carries the keys of the reference's config.yml ``process`` section plus ``fs`` and ``n_samples``.
 
-    A CPI whose clutter filter fails (normal equations not positive definite) is SKIPPED like the
-    reference does (``if (!filter->process(x, y)) continue;`` blah2.cpp:270-273): its result is
-    ``{"skipped": True}``."""
-    import torch
+    A ring of ``depth`` slots, each with a pinned host batch, its device copy, device result buffers and their pinned
+    host copies.  For batch k: reader threads fill the slot's host buffer; the COPY stream uploads it; the COMPUTE stream
+    (after the upload's event) runs the chain into the slot's result buffers; the copy stream (after the compute event)
+    brings {metrics, ok flags, hit counts, the first ``hit_copy`` hit records per CPI, and the map when wanted} back.
+    Batch k+1's read and upload and batch k-1's download overlap batch k's kernels.
 
-    import blah2_amd
-    amb_c, det_c, clu_c = cfg["ambiguity"], cfg.get("detection", {}), cfg.get("clutter", {})
-    fs, n = int(cfg["fs"]), int(cfg["n_samples"])
-    amb = blah2_amd.Ambiguity(amb_c["delayMin"], amb_c["delayMax"], amb_c["dopplerMin"], amb_c["dopplerMax"],
-                              fs, n, True, device=device, max_batch=batch)
-    nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
-    wh = None
-    if clu_c.get("enable", False):
-        wh = blah2_amd.WienerHopf(clu_c["delayMin"], clu_c["delayMax"], n, device=device, max_batch=batch)
-    cfar = centroid = interp = None
-    if det_c.get("enable", False):
-        cfar = blah2_amd.CfarDetector1D(det_c["pfa"], det_c["nGuard"], det_c["nTrain"], det_c["minDelay"],
-                                        det_c["minDoppler"])
-        if "nCentroid" in det_c:  # blah2.cpp:176-181
-            t_cpi = n / fs
-            centroid = blah2_amd.Centroid(det_c["nCentroid"], det_c["nCentroid"], 1 / t_cpi)
-            interp = blah2_amd.Interpolate(True, True)
-    dev = torch.device("cuda", device)
-    cap = int(det_c.get("capacity", min(nD * nC, 1 << 16)))
-    out = torch.zeros((batch, nD, nC), dtype=torch.complex64, device=dev)
-    met = torch.zeros((batch, 2), dtype=torch.float64, device=dev)
-    okf = torch.ones(batch, dtype=torch.int32, device=dev)
-    hits = torch.zeros((batch, cap, 2), dtype=torch.float64, device=dev)  # blah2hip_hit_t records, 16 bytes
-    cnt = torch.zeros(batch, dtype=torch.int32, device=dev)
+    A CPI whose clutter filter fails (normal equations not positive definite) is SKIPPED like the reference does
+    (``if (!filter->process(x, y)) continue;`` blah2.cpp:270-273): its result is ``{"skipped": True}``."""
 
-    def run(iq: np.ndarray):
-        B = iq.shape[0]
-        st = torch.cuda.current_stream(dev).cuda_stream
-        d = torch.from_numpy(np.ascontiguousarray(iq)).to(dev)
-        if wh is None:
-            amb.process_dev(blah2_amd.FMT_I16, d.data_ptr(), 0, B, n, out.data_ptr(), met.data_ptr(), st)
-        else:
-            f = d.to(torch.float32)
-            x = torch.view_as_complex(f[..., 0:2].contiguous())
-            y = torch.view_as_complex(f[..., 2:4].contiguous())
-            wh.process_dev(x.data_ptr(), y.data_ptr(), B, n, y.data_ptr(), okf.data_ptr(), st)
-            amb.process_dev(blah2_amd.FMT_C32, x.data_ptr(), y.data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
-        if cfar is not None:
-            cfar.process_dev(amb, B, hits.data_ptr(), cap, cnt.data_ptr(), out.data_ptr(), met.data_ptr(), st)
-        # one synchronising round of copies per batch
-        met_h = met[:B].cpu().numpy()
-        ok_h = okf[:B].cpu().numpy() if wh is not None else np.ones(B, dtype=np.int32)
-        need_map = want_map or interp is not None
+    def __init__(self, cfg: dict, device: int = 0, batch: int = 1, want_map: bool = False, depth: int = 3,
+                 reader_threads: int = 16, hit_copy: int = 4096):
+        import torch
+
+        import blah2_amd
+        self.torch, self.b2 = torch, blah2_amd
+        amb_c, det_c, clu_c = cfg["ambiguity"], cfg.get("detection", {}), cfg.get("clutter", {})
+        self.fs, self.n = int(cfg["fs"]), int(cfg["n_samples"])
+        n, B = self.n, int(batch)
+        self.batch, self.depth, self.want_map = B, max(2, int(depth)), bool(want_map)
+        self.amb = blah2_amd.Ambiguity(amb_c["delayMin"], amb_c["delayMax"], amb_c["dopplerMin"], amb_c["dopplerMax"],
+                                       self.fs, n, True, device=device, max_batch=B)
+        nD, nC = self.amb.get_n_doppler_bins(), self.amb.get_n_delay_bins()
+        self.wh = None
+        if clu_c.get("enable", False):
+            self.wh = blah2_amd.WienerHopf(clu_c["delayMin"], clu_c["delayMax"], n, device=device, max_batch=B)
+        self.cfar = self.centroid = self.interp = None
+        if det_c.get("enable", False):
+            self.cfar = blah2_amd.CfarDetector1D(det_c["pfa"], det_c["nGuard"], det_c["nTrain"], det_c["minDelay"],
+                                                 det_c["minDoppler"])
+            if "nCentroid" in det_c:  # blah2.cpp:176-181
+                self.centroid = blah2_amd.Centroid(det_c["nCentroid"], det_c["nCentroid"], 1 / (n / self.fs))
+                self.interp = blah2_amd.Interpolate(True, True)
+        self.need_map = self.want_map or self.interp is not None
+        dev = self.dev = torch.device("cuda", device)
+        self.cap = int(det_c.get("capacity", min(nD * nC, 1 << 16)))
+        self.hit_copy = min(self.cap, int(hit_copy))
+        self.compute = torch.cuda.Stream(device=dev)
+        self.copy = torch.cuda.Stream(device=dev)
+        self.pool = ThreadPoolExecutor(max_workers=max(1, reader_threads))
+        self.reader_threads = max(1, reader_threads)
+        # the filtered surveillance channel (one buffer: the compute stream is in order)
+        self.yf = torch.empty((B, n), dtype=torch.complex64, device=dev) if self.wh is not None else None
+        self.slots = []
+        for _ in range(self.depth):
+            s = {
+                "h_iq": torch.empty((B, n, 4), dtype=torch.int16).pin_memory(),
+                "d_iq": torch.empty((B, n, 4), dtype=torch.int16, device=dev),
+                "d_met": torch.zeros((B, 2), dtype=torch.float64, device=dev),
+                "d_ok": torch.ones(B, dtype=torch.int32, device=dev),
+                "d_hits": torch.zeros((B, self.cap, 2), dtype=torch.float64, device=dev),  # blah2hip_hit_t records, 16 bytes
+                "d_cnt": torch.zeros(B, dtype=torch.int32, device=dev),
+                "d_map": torch.zeros((B, nD, nC), dtype=torch.complex64, device=dev),
+                "h_met": torch.zeros((B, 2), dtype=torch.float64).pin_memory(),
+                "h_ok": torch.ones(B, dtype=torch.int32).pin_memory(),
+                "h_hits": torch.zeros((B, self.hit_copy, 2), dtype=torch.float64).pin_memory(),
+                "h_cnt": torch.zeros(B, dtype=torch.int32).pin_memory(),
+                "h_map": torch.zeros((B, nD, nC), dtype=torch.complex64).pin_memory() if self.need_map else None,
+                "uploaded": torch.cuda.Event(), "computed": torch.cuda.Event(), "downloaded": torch.cuda.Event(),
+            }
+            self.slots.append(s)
+
+    # -- the three stages of one batch -------------------------------------------------
+    def _read(self, capture: RspduoFile, slot: dict, k0: int, cnt: int):
+        capture.read_into(k0, cnt, slot["h_iq"].numpy(), self.pool, self.reader_threads)
+
+    def _submit(self, slot: dict, cnt: int):
+        torch, b2, n, amb = self.torch, self.b2, self.n, self.amb
+        with torch.cuda.stream(self.copy):
+            slot["d_iq"][:cnt].copy_(slot["h_iq"][:cnt], non_blocking=True)
+            slot["uploaded"].record(self.copy)
+        with torch.cuda.stream(self.compute):
+            self.compute.wait_event(slot["uploaded"])
+            st = self.compute.cuda_stream
+            iq = slot["d_iq"].data_ptr()
+            if self.wh is None:
+                amb.process_dev(b2.FMT_I16, iq, 0, cnt, n, slot["d_map"].data_ptr(), slot["d_met"].data_ptr(), st)
+            else:
+                self.wh.process_dev_fmt(b2.FMT_I16, iq, None, cnt, n, self.yf.data_ptr(), n, slot["d_ok"].data_ptr(), st)
+                amb.process_dev(b2.FMT_I16X_C32Y, iq, self.yf.data_ptr(), cnt, n, slot["d_map"].data_ptr(),
+                                slot["d_met"].data_ptr(), st)
+            if self.cfar is not None:
+                self.cfar.process_dev(amb, cnt, slot["d_hits"].data_ptr(), self.cap, slot["d_cnt"].data_ptr(),
+                                      slot["d_map"].data_ptr(), slot["d_met"].data_ptr(), st)
+            slot["computed"].record(self.compute)
+        with torch.cuda.stream(self.copy):
+            self.copy.wait_event(slot["computed"])
+            slot["h_met"][:cnt].copy_(slot["d_met"][:cnt], non_blocking=True)
+            if self.wh is not None:
+                slot["h_ok"][:cnt].copy_(slot["d_ok"][:cnt], non_blocking=True)
+            if self.cfar is not None:
+                slot["h_cnt"][:cnt].copy_(slot["d_cnt"][:cnt], non_blocking=True)
+                slot["h_hits"][:cnt].copy_(slot["d_hits"][:cnt, :self.hit_copy], non_blocking=True)
+            if self.need_map:
+                slot["h_map"][:cnt].copy_(slot["d_map"][:cnt], non_blocking=True)
+            slot["downloaded"].record(self.copy)
+
+    def _collect(self, slot: dict, k0: int, cnt: int) -> List[dict]:
+        b2, amb = self.b2, self.amb
+        slot["downloaded"].synchronize()
+        met_h = slot["h_met"].numpy()
+        ok_h = slot["h_ok"].numpy() if self.wh is not None else np.ones(cnt, dtype=np.int32)
         res = []
-        if cfar is not None:
-            cnt_h = cnt[:B].cpu().numpy()
-            kmax = int(cnt_h.max()) if B else 0
-            if kmax > cap:
-                raise blah2_amd.Blah2HipError(blah2_amd._lib.ERR_CAPACITY, f"{kmax} detections in one CPI, capacity {cap}")
-            hits_h = hits[:B, :max(kmax, 1)].cpu().numpy().view(blah2_amd.HIT_DTYPE).reshape(B, -1)
-        map_h = out[:B].cpu().numpy() if need_map else None
-        for b in range(B):
+        for b in range(cnt):
             if not ok_h[b]:
-                res.append({"skipped": True})
+                res.append({"skipped": True, "cpi": k0 + b})
                 continue
-            r = {"noisePower": float(met_h[b, 0]), "maxPower": float(met_h[b, 1])}
-            if cfar is not None:
-                det = blah2_amd.hits_to_detection(amb, hits_h[b], int(cnt_h[b]), cap)
-                if centroid is not None:
-                    det = centroid.process(det)
-                    m = blah2_amd.Map(amb, map_h[b], amb.delay, amb.doppler, r["noisePower"], r["maxPower"], b)
-                    det = interp.process(det, m)
-                r.update(delay=det.get_delay().tolist(), doppler=det.get_doppler().tolist(),
-                         snr=det.get_snr().tolist())
-            if want_map:
-                r["map"] = map_h[b]
+            r = {"noisePower": float(met_h[b, 0]), "maxPower": float(met_h[b, 1]), "cpi": k0 + b}
+            if self.cfar is not None:
+                k = int(slot["h_cnt"][b])
+                if k > self.cap:
+                    raise b2.Blah2HipError(b2._lib.ERR_CAPACITY, f"{k} detections in one CPI, capacity {self.cap}")
+                if k > self.hit_copy:  # rare: more hits than the pipelined copy carries -- fetch this CPI's records now
+                    recs = slot["d_hits"][b, :k].cpu().numpy()
+                else:
+                    recs = slot["h_hits"][b, :max(k, 1)].numpy()
+                det = b2.hits_to_detection(amb, recs.view(b2.HIT_DTYPE).reshape(-1), k, self.cap)
+                if self.centroid is not None:
+                    det = self.centroid.process(det)
+                    m = b2.Map(amb, slot["h_map"][b].numpy(), amb.delay, amb.doppler, r["noisePower"], r["maxPower"], b)
+                    det = self.interp.process(det, m)
+                r.update(delay=det.get_delay().tolist(), doppler=det.get_doppler().tolist(), snr=det.get_snr().tolist())
+            if self.want_map:
+                r["map"] = slot["h_map"][b].numpy().copy()
             res.append(r)
         return res
 
-    run.amb = amb
-    return run
+    def run_batches(self, capture: RspduoFile, batches) -> Iterator[List[dict]]:
+        """The pipeline over this rank's batches: yields each batch's results in order.  Up to ``depth`` batches are in
+        flight; batch i's slot is reused by batch i + depth only after batch i has been collected."""
+        batches = list(batches)
+        D = self.depth
+        for i in range(min(D - 1, len(batches))):  # fill
+            self._read(capture, self.slots[i % D], *batches[i])
+            self._submit(self.slots[i % D], batches[i][1])
+        for i, (k0, cnt) in enumerate(batches):
+            j = i + D - 1
+            if j < len(batches):  # its slot was collected in iteration i - 1
+                self._read(capture, self.slots[j % D], *batches[j])
+                self._submit(self.slots[j % D], batches[j][1])
+            yield self._collect(self.slots[i % D], k0, cnt)
+
+    def __call__(self, iq: np.ndarray) -> List[dict]:
+        """One batch, synchronously, from a host array [B, nSamples, 4] (tests; a caller that has the samples in memory)."""
+        cnt = iq.shape[0]
+        slot = self.slots[0]
+        slot["h_iq"][:cnt].copy_(self.torch.from_numpy(np.ascontiguousarray(iq)))
+        self._submit(slot, cnt)
+        out = self._collect(slot, 0, cnt)
+        for r in out:
+            r.pop("cpi", None)
+        return out
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+
+
+def gpu_processor(cfg: dict, device: int = 0, batch: int = 1, want_map: bool = False, **kw) -> GpuChain:
+    """The device chain for :func:`replay` (kept under its old name)."""
+    return GpuChain(cfg, device, batch, want_map, **kw)
 
 
 def frames_for(result: dict, amb, fs: int, timestamp: int):
@@ -222,33 +390,38 @@ def main(argv=None):
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch
         import torch.distributed as dist_
-        torch.cuda.set_device(local)
-        dist_.init_process_group("nccl")
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+        dist_.init_process_group("nccl" if torch.cuda.device_count() >= int(os.environ["WORLD_SIZE"]) else "gloo")
         dist = dist_
-    proc = gpu_processor(cfg, local, a.batch, want_map=a.json)
-    res = replay(RspduoFile(a.capture, n), proc, a.batch, dist, a.limit)
-    if res is not None:
-        socks = {}
-        if a.json and a.connect:
-            ip = y["network"]["ip"]
-            ip = "127.0.0.1" if ip == "0.0.0.0" else ip
-            for name in ("map", "detection"):
-                socks[name] = socket.create_connection((ip, int(y["network"]["ports"][name])))
-        t_cpi_ms = int(round(1000.0 * n / fs))
-        for r in res:
-            if r.get("skipped"):
-                continue
-            if not a.json:
-                sys.stdout.write(json.dumps(r) + "\n")
-                continue
-            # replay has no wall clock: CPI k is stamped k * tCpi in ms (blah2.cpp uses the capture time in ms)
-            for name, doc in frames_for(r, proc.amb, fs, r["cpi"] * t_cpi_ms).items():
-                if socks:
-                    send_frame(socks[name], doc)
-                else:
-                    sys.stdout.write(doc + "\n")
-        for s in socks.values():
-            s.close()
+    import torch
+    proc = gpu_processor(cfg, local % max(1, torch.cuda.device_count()), a.batch, want_map=a.json)
+    rank0 = dist is None or dist.get_rank() == 0
+    socks = {}
+    if rank0 and a.json and a.connect:
+        ip = y["network"]["ip"]
+        ip = "127.0.0.1" if ip == "0.0.0.0" else ip
+        for name in ("map", "detection"):
+            socks[name] = socket.create_connection((ip, int(y["network"]["ports"][name])))
+    t_cpi_ms = int(round(1000.0 * n / fs))
+
+    def emit(r):  # rank 0, file order, as the rounds complete
+        if r.get("skipped"):
+            return
+        if not a.json:
+            sys.stdout.write(json.dumps(r) + "\n")
+            return
+        # replay has no wall clock: CPI k is stamped k * tCpi in ms (blah2.cpp uses the capture time in ms)
+        for name, doc in frames_for(r, proc.amb, fs, r["cpi"] * t_cpi_ms).items():
+            if socks:
+                send_frame(socks[name], doc)
+            else:
+                sys.stdout.write(doc + "\n")
+        sys.stdout.flush()
+
+    replay(RspduoFile(a.capture, n), proc, a.batch, dist, a.limit, emit=emit)
+    for s in socks.values():
+        s.close()
+    proc.close()
     if dist is not None:
         dist.destroy_process_group()
 

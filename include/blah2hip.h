@@ -59,6 +59,9 @@ extern "C" {
 #define BLAH2HIP_FMT_C32 0 /* two planes of complex fp32: x = reference, y = surveillance */
 #define BLAH2HIP_FMT_I16 1 /* one buffer, int16 I1 Q1 I2 Q2 per sample (.rspduo, RspDuo.cpp:512-526) */
 #define BLAH2HIP_FMT_F16 2 /* two planes of (re,im) IEEE half pairs; widened to fp32 on load, fp32 accumulate */
+#define BLAH2HIP_FMT_I16X_C32Y 3 /* reference channel from the .rspduo buffer (tuner 1 of I1 Q1 I2 Q2), surveillance channel from a
+                                  * complex fp32 plane: the ambiguity stage behind blah2hip_clutter_process_dev_fmt(FMT_I16), which
+                                  * leaves x untouched and writes the filtered y as fp32 (WienerHopf.cpp:156-160) */
 
 typedef struct blah2hip_amb_s *blah2hip_amb_t;
 typedef struct blah2hip_clutter_s *blah2hip_clutter_t;
@@ -273,6 +276,12 @@ int blah2hip_clutter_process_c32(blah2hip_clutter_t h, const float *x, const flo
 int blah2hip_clutter_process_dev(blah2hip_clutter_t h, const void *d_x, const void *d_y,
                                  uint32_t n_cpi, uint64_t cpi_stride, void *d_y_out, int32_t *d_ok,
                                  void *stream);
+/* The same with the INPUT in format fmt: BLAH2HIP_FMT_C32 (d_x, d_y planes) or BLAH2HIP_FMT_I16 (d_x = the interleaved
+ * .rspduo buffer I1 Q1 I2 Q2, d_y ignored: the correlation and FIR kernels read the int16 words directly,
+ * RspDuo.cpp:512-526).  The filtered surveillance channel is always written as a complex fp32 plane, CPI c at
+ * d_y_out + c * out_stride samples (for FMT_C32 it may alias d_y with out_stride = cpi_stride).  Enqueues only. */
+int blah2hip_clutter_process_dev_fmt(blah2hip_clutter_t h, int fmt, const void *d_x, const void *d_y, uint32_t n_cpi,
+                                     uint64_t cpi_stride, void *d_y_out, uint64_t out_stride, int32_t *d_ok, void *stream);
 /* Execution plan of the filter.  SOLVE_K: indices of the Toeplitz recursion per thread (0 = by
  * size: 1 up to 1024 taps, 2 up to 2048, 4 above; the workgroup has ceil(nBins / K) threads rounded up to a wave). */
 #define BLAH2HIP_CLUTTER_OPT_SOLVE_K 1

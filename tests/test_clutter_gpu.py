@@ -94,3 +94,40 @@ def test_clutter_correlation_forms_agree_with_the_oracle(b2, mode, n, taps):
     assert np.max(np.abs(r - r_ref)) / np.abs(r_ref[0]) <= 1e-5
     assert np.max(np.abs(b - b_ref)) / np.max(np.abs(b_ref)) <= 1e-5
     assert np.max(np.abs(yf.astype(np.complex128) - y_ref)) / np.max(np.abs(y_ref)) <= Y_TOL
+
+
+@pytest.mark.parametrize("n,taps,corr", [(300_000, 410, "auto"), (300_000, 700, "half"), (1_000_000, 2047, "auto"), (100_000, 60, "auto")])
+def test_clutter_int16_wire_format_equals_fp32_planes(b2, n, taps, corr):
+    """blah2hip_clutter_process_dev_fmt(FMT_I16): the correlation and FIR kernels read the .rspduo words (I1 Q1 I2 Q2,
+    RspDuo.cpp:512-526) directly.  int16 -> fp32 is exact, so r, b, the taps and the filtered channel must equal the
+    fp32-plane path's on the same values bit for bit (same kernels, same order of operations), and the oracle within
+    the usual gate; every transform length and both correlation forms are reached by the parameter sets."""
+    import torch
+    B = 2
+    xs, ys = zip(*(O.synth_iq(n, seed=900 + c, fs=1_000_000, targets=((20, 40.0, 0.05),)) for c in range(B)))
+    dmin, dmax = -7, taps - 7
+    iq = np.stack([np.stack([x.real, x.imag, y.real, y.imag], axis=-1) for x, y in zip(xs, ys)]).astype(np.int16)
+    d_iq = torch.from_numpy(iq).cuda()
+    dx = torch.from_numpy(np.stack(xs).astype(np.complex64)).cuda()
+    dy = torch.from_numpy(np.stack(ys).astype(np.complex64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for fmt in ("c32", "i16"):
+        wh = b2.WienerHopf(dmin, dmax, n, max_batch=B)
+        wh.set_corr_form(corr)
+        yo = torch.zeros((B, n + 3), dtype=torch.complex64, device="cuda")  # an output stride that differs from the input's
+        ok = torch.zeros(B, dtype=torch.int32, device="cuda")
+        if fmt == "c32":
+            wh.process_dev_fmt(b2.FMT_C32, dx.data_ptr(), dy.data_ptr(), B, n, yo.data_ptr(), n + 3, ok.data_ptr(), st)
+        else:
+            wh.process_dev_fmt(b2.FMT_I16, d_iq.data_ptr(), None, B, n, yo.data_ptr(), n + 3, ok.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert ok.cpu().tolist() == [1] * B
+        outs[fmt] = (yo.cpu().numpy()[:, :n], [wh.read_last(c) for c in range(B)])
+    for c in range(B):
+        assert np.array_equal(outs["c32"][0][c], outs["i16"][0][c])
+        for u, v in zip(outs["c32"][1][c][1:], outs["i16"][1][c][1:]):
+            assert np.array_equal(u, v)
+        ok_ref, y_ref = O.wiener_hopf(xs[c], ys[c], dmin, dmax)[:2]
+        assert ok_ref
+        assert np.max(np.abs(outs["i16"][0][c].astype(np.complex128) - y_ref)) / np.max(np.abs(y_ref)) <= Y_TOL

@@ -82,3 +82,87 @@ def test_two_rank_replay_gloo(tmp_path, n_cpis, batch):
     assert got[:, 0].tolist() == list(range(n_cpis))            # file order, each CPI once
     assert np.allclose(got[:, 1], [w["noisePower"] for w in want])
     assert np.allclose(got[:, 2], [w["maxPower"] for w in want])
+
+
+@pytest.mark.parametrize("n,batch,world", [(0, 2, 2), (1, 2, 2), (9, 2, 2), (8, 4, 2), (7, 3, 3), (5, 1, 8)])
+def test_batches_partition_all_cpis_contiguously(n, batch, world):
+    parts = [R.shard_batches(n, batch, r, world) for r in range(world)]
+    flat = sorted(b for p in parts for b in p)
+    assert [k for k0, c in flat for k in range(k0, k0 + c)] == list(range(n))
+    assert all(c == batch for _, c in flat[:-1])  # only the last batch may be short
+    for r, p in enumerate(parts):  # batch b on rank b % world
+        assert all((k0 // batch) % world == r for k0, _ in p)
+
+
+def test_single_process_replay_streams_in_order(tmp_path):
+    """emit() is called per CPI in file order WHILE later batches are still unprocessed (bounded memory, like the
+    reference's per-CPI sends, blah2.cpp:299-321)."""
+    p = str(tmp_path / "a.rspduo")
+    make_capture(p, 7)
+    f = R.RspduoFile(p, N_SAMPLES)
+    calls = []
+
+    def counting(iq):
+        calls.append(len(iq))
+        return stub(iq)
+
+    seen = []
+    n = R.replay(f, counting, batch=2, emit=lambda r: seen.append((r["cpi"], len(calls))))
+    assert n == 7 and [c for c, _ in seen] == list(range(7))
+    assert seen[0][1] == 1 and seen[2][1] == 2 and seen[6][1] == 4  # CPI 0 is out after the first batch, not after the last
+
+
+def test_read_into_matches_the_memory_map(tmp_path):
+    from concurrent.futures import ThreadPoolExecutor
+    p = str(tmp_path / "a.rspduo")
+    a = make_capture(p, 6)
+    f = R.RspduoFile(p, N_SAMPLES)
+    dst = np.zeros((4, N_SAMPLES, 4), dtype=np.int16)
+    with ThreadPoolExecutor(3) as pool:
+        f.read_into(1, 3, dst, pool, parts=3)
+    assert np.array_equal(dst[:3].reshape(-1, 4), a[N_SAMPLES:4 * N_SAMPLES]) and not dst[3].any()
+    f.close()
+
+
+def _stream_worker(rank, world, port, path, n_cpis, batch, out_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def counting(iq):
+            calls.append(len(iq))
+            return stub(iq)
+
+        seen = []
+        res = R.replay(R.RspduoFile(path, N_SAMPLES), counting, batch=batch, dist=dist,
+                       emit=lambda r: seen.append((r["cpi"], r["noisePower"], len(calls))))
+        if rank == 0:
+            assert res == n_cpis
+            np.save(out_path, np.array(seen))
+        else:
+            assert res is None and not seen
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_streaming_gather_gloo(tmp_path):
+    """world_size 2, per-round gather: rank 0 emits CPIs 0..3 (round 0 = batch 0 of rank 0 + batch 1 of rank 1) after ONE
+    of its own batches, in file order, and the whole capture exactly once."""
+    import torch.multiprocessing as mp
+    n_cpis, batch = 11, 2
+    p = str(tmp_path / "c.rspduo")
+    make_capture(p, n_cpis)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "seen.npy")
+    mp.spawn(_stream_worker, args=(2, port, p, n_cpis, batch, out), nprocs=2, join=True)
+    seen = np.load(out)
+    f = R.RspduoFile(p, N_SAMPLES)
+    want = stub(f.batch(list(range(n_cpis))))
+    assert seen[:, 0].tolist() == list(range(n_cpis))
+    assert np.allclose(seen[:, 1], [w["noisePower"] for w in want])
+    assert seen[0, 2] == 1 and seen[3, 2] == 1 and seen[4, 2] == 2  # round g is out after rank 0's g+1-th batch

@@ -189,3 +189,37 @@ def _expected_doppler(b2, geom):
     if d.n_doppler_bins <= 1025:
         return "tilew" if 2 * -(-d.n_delay_bins // 8) >= 128 else "column"
     return "tilem" if 2 * -(-d.n_delay_bins // 4) >= 128 else "column"
+
+
+@pytest.mark.parametrize("geom,fft_len", [(CFG2, 2048), ((-24, 2023, -64, 64, 1_260_000, 1_260_000), 4096),
+                                          ((-10, 100, -100, 100, 1_000_000, 100_000), 1024), ((-10, 400, -300, 200, 2_000_000, 1_000_000), 0)])
+def test_mixed_format_int16_reference_fp32_surveillance(b2, geom, fft_len):
+    """BLAH2HIP_FMT_I16X_C32Y -- x from the .rspduo words, y from an fp32 plane (the ambiguity stage behind the int16
+    clutter filter): every range kernel (one per transform length; F = 2048 both forms) and the rotate kernel
+    (asymmetric Doppler limits) against the fp32-plane path on the same values: identical maps."""
+    import torch
+    from blah2_amd import _lib
+    dmin, dmax, fmin, fmax, fs, n = geom
+    B = 9 if fft_len == 2048 else 2  # nine CPIs of cfg 2 reach the one-wave kernel's launch size
+    xs, ys = zip(*(O.synth_iq(n, seed=700 + c, fs=fs, targets=((37, -13.0, 0.05),)) for c in range(B)))
+    iq = np.stack([np.stack([x.real, x.imag, y.real, y.imag], axis=-1) for x, y in zip(xs, ys)]).astype(np.int16)
+    d_iq = torch.from_numpy(iq).cuda()
+    dx = torch.from_numpy(np.stack(xs).astype(np.complex64)).cuda()
+    dy = torch.from_numpy(np.stack(ys).astype(np.complex64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, max_batch=B)
+    nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
+    maps = []
+    for fmt, px in ((b2.FMT_C32, dx), (b2.FMT_I16X_C32Y, d_iq)):
+        out = torch.zeros((B, nD, nC), dtype=torch.complex64, device="cuda")
+        amb.process_dev(fmt, px.data_ptr(), dy.data_ptr(), B, n, out.data_ptr(), None, st)
+        torch.cuda.synchronize()
+        maps.append(out.cpu().numpy())
+        if fft_len:
+            assert amb.dims.fft_len == fft_len
+    if fft_len == 2048:
+        assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE
+    assert np.array_equal(maps[0], maps[1])
+    d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
+    ref = O.ambiguity_process(d, xs[B - 1], ys[B - 1])
+    assert np.max(np.abs(maps[1][B - 1] - ref)) / np.max(np.abs(ref)) <= PEAK_TOL
