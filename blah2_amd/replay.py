@@ -62,7 +62,7 @@ class RspduoFile:
     def batch(self, ks) -> np.ndarray:
         return np.stack([self.cpi(k) for k in ks]) if len(ks) else np.zeros((0, self.n_samples, 4), dtype=np.int16)
 
-    def read_into(self, k0: int, count: int, dst: np.ndarray, pool: Optional[ThreadPoolExecutor] = None, parts: int = 16):
+    def read_into(self, k0: int, count: int, dst: np.ndarray, pool: Optional[ThreadPoolExecutor] = None, parts: int = 8):
         """CPIs k0 .. k0+count-1 (contiguous in the file) into the first bytes of ``dst`` (any writable buffer, e.g. a
         pinned one) with pread, split over ``pool``'s threads: a page-cache copy runs at ~10 GB/s per thread, PCIe
         takes 50+."""
@@ -191,7 +191,7 @@ class GpuChain:
     (``if (!filter->process(x, y)) continue;`` blah2.cpp:270-273): its result is ``{"skipped": True}``."""
 
     def __init__(self, cfg: dict, device: int = 0, batch: int = 1, want_map: bool = False, depth: int = 3,
-                 reader_threads: int = 16, hit_copy: int = 4096):
+                 reader_threads: int = 8, hit_copy: int = 4096):
         import torch
 
         import blah2_amd

@@ -75,32 +75,34 @@ def main():
     base = {"fs": fs, "n_samples": n,
             "ambiguity": {"delayMin": dmin, "delayMax": dmax, "dopplerMin": fmin, "dopplerMax": fmax},
             "detection": {"enable": True, "pfa": 1e-5, "nGuard": 2, "nTrain": 6, "minDelay": 5, "minDoppler": 15.0}}
-    for name, clutter, depth, threads in (("ambiguity+cfar", False, 3, 16), ("ambiguity+cfar, depth 2", False, 2, 16),
+    for name, clutter, depth, threads in (("ambiguity+cfar", False, 3, 8), ("clutter+ambiguity+cfar", True, 3, 8),
+                                          ("ambiguity+cfar, depth 2", False, 2, 8),
                                           ("ambiguity+cfar, 1 reader thread", False, 3, 1),
                                           ("ambiguity+cfar, 4 reader threads", False, 3, 4),
-                                          ("ambiguity+cfar, 8 reader threads", False, 3, 8),
-                                          ("ambiguity+cfar, 32 reader threads", False, 3, 32),
-                                          ("clutter+ambiguity+cfar", True, 3, 16)):
+                                          ("ambiguity+cfar, 16 reader threads", False, 3, 16)):
         cfg = dict(base, clutter={"enable": clutter, "delayMin": dmin, "delayMax": dmax})
         chain = R.GpuChain(cfg, 0, a.batch, depth=depth, reader_threads=threads)
         cap = R.RspduoFile(path, n)
-        R.replay(cap, chain, a.batch, limit=min(a.cpis, 2 * a.batch), emit=lambda r: None)  # warm-up (clock ramp, page cache)
-        cnt = [0]
-        first = [None]
-        t0 = time.perf_counter()
+        R.replay(cap, chain, a.batch, emit=lambda r: None)  # one untimed pass (clock ramp, first touch of the pinned ring)
+        passes = []
+        for _ in range(3):
+            cnt = [0]
+            first = [None]
+            t0 = time.perf_counter()
 
-        def emit(r):
-            if first[0] is None:
-                first[0] = time.perf_counter() - t0
-            cnt[0] += 1
+            def emit(r):
+                if first[0] is None:
+                    first[0] = time.perf_counter() - t0
+                cnt[0] += 1
 
-        R.replay(cap, chain, a.batch, emit=emit)
-        el = time.perf_counter() - t0
+            R.replay(cap, chain, a.batch, emit=emit)
+            passes.append((time.perf_counter() - t0, first[0], cnt[0]))
         chain.close()
         cap.close()
-        run = {"chain": name, "cpis_per_s": cnt[0] / el, "frac_of_pcie_bound": cnt[0] / el / bound, "seconds": el,
-               "first_result_after_s": first[0], "depth": depth, "reader_threads": threads,
-               "effective_GBps": cnt[0] * bytes_per_cpi / el / 1e9}
+        el, first_s, n_done = sorted(passes)[1]  # the median pass
+        run = {"chain": name, "cpis_per_s": n_done / el, "frac_of_pcie_bound": n_done / el / bound, "seconds": el,
+               "first_result_after_s": first_s, "depth": depth, "reader_threads": threads,
+               "effective_GBps": n_done * bytes_per_cpi / el / 1e9, "passes_s": [p_[0] for p_ in passes]}
         print(json.dumps(run), flush=True)
         res["runs"].append(run)
     # two ranks on the one GPU (gloo), in-order emission through the per-round gather
