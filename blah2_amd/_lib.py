@@ -99,6 +99,17 @@ SYMBOLS = {
     "blah2hip_spectrum_process_c64": (C.c_int, [_vp, _vp, _u32, _vp]),
     "blah2hip_spectrum_process_c32": (C.c_int, [_vp, _vp, _u32, _vp]),
     "blah2hip_spectrum_process_dev": (C.c_int, [_vp, C.c_int, _vp, _u32, C.c_uint64, _vp, _vp]),
+    "blah2hip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "blah2hip_ctx_destroy": (C.c_int, [_vp]),
+    "blah2hip_ctx_stream": (_vp, [_vp]),
+    "blah2hip_ctx_sync": (C.c_int, [_vp]),
+    "blah2hip_ctx_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "blah2hip_ctx_free": (C.c_int, [_vp, _vp]),
+    "blah2hip_ctx_malloc_host": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "blah2hip_ctx_free_host": (C.c_int, [_vp, _vp]),
+    "blah2hip_ctx_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "blah2hip_ctx_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "blah2hip_amb_result_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "blah2hip_amb_set_timing": (C.c_int, [_vp, C.c_int]),
     "blah2hip_amb_get_timing": (C.c_int, [_vp, _vp, _vp]),
 }

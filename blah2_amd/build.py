@@ -67,7 +67,7 @@ def build_host(force=False, verbose=True):
     deps = srcs + _sources(HOST, (".h",)) + [os.path.join(ROOT, "include", "blah2hip.h"), LIB]
     if not force and not _newer(HOSTLIB, deps):
         return HOSTLIB
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"),
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"),
            "-I", HOST, *srcs, "-o", HOSTLIB, "-L", PKG, "-lblah2hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print("[blah2_amd.build]", " ".join(cmd), flush=True)
@@ -85,7 +85,7 @@ def build_host_test(force=False, verbose=True):
         return None
     if not force and not _newer(HOSTTEST, [src, HOSTLIB, LIB]):
         return HOSTTEST
-    cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", HOST, src, "-o", HOSTTEST,
+    cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", HOST, src, "-o", HOSTTEST,
            "-L", PKG, "-lblah2host", "-lblah2hip", "-Wl,-rpath,$ORIGIN/../.."]
     if verbose:
         print("[blah2_amd.build]", " ".join(cmd), flush=True)

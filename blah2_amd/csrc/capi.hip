@@ -1405,6 +1405,101 @@ int blah2hip_interpolate(const double *delay, const double *doppler, const doubl
   return BLAH2HIP_OK;
 }
 
+// ---------------------------------------------------------- device context --
+struct blah2hip_ctx_s {
+  int device = 0;
+  hipStream_t stream = nullptr;
+};
+
+int blah2hip_ctx_create(int device, blah2hip_ctx_t *out)
+{
+  if (!out) return fail(BLAH2HIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(BLAH2HIP_ERR_NO_DEVICE, "no HIP device visible (the HIP path is the only path)");
+  if (device < 0 || device >= ndev) return fail(BLAH2HIP_ERR_INVALID, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  auto *c = new blah2hip_ctx_s;
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return fail(BLAH2HIP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+  *out = c;
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_ctx_destroy(blah2hip_ctx_t c)
+{
+  if (!c) return BLAH2HIP_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  delete c;
+  return BLAH2HIP_OK;
+}
+
+void *blah2hip_ctx_stream(blah2hip_ctx_t c) { return c ? (void *)c->stream : nullptr; }
+
+int blah2hip_ctx_sync(blah2hip_ctx_t c)
+{
+  if (!c) return fail(BLAH2HIP_ERR_INVALID, "NULL context");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_ctx_malloc(blah2hip_ctx_t c, size_t bytes, void **dptr)
+{
+  if (!c || !dptr) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMalloc(dptr, bytes));
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_ctx_free(blah2hip_ctx_t c, void *dptr)
+{
+  if (!c) return fail(BLAH2HIP_ERR_INVALID, "NULL context");
+  if (dptr) { HIPCHK(hipSetDevice(c->device)); HIPCHK(hipFree(dptr)); }
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_ctx_malloc_host(blah2hip_ctx_t c, size_t bytes, void **hptr)
+{
+  if (!c || !hptr) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_ctx_free_host(blah2hip_ctx_t c, void *hptr)
+{
+  if (!c) return fail(BLAH2HIP_ERR_INVALID, "NULL context");
+  if (hptr) HIPCHK(hipHostFree(hptr));
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_ctx_h2d(blah2hip_ctx_t c, void *dptr, const void *hptr, size_t bytes)
+{
+  if (!c || !dptr || !hptr) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, c->stream));
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_ctx_d2h(blah2hip_ctx_t c, void *hptr, const void *dptr, size_t bytes)
+{
+  if (!c || !dptr || !hptr) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_amb_result_ptrs(blah2hip_amb_t h, const void **d_map, const double **d_metrics)
+{
+  if (!h) return fail(BLAH2HIP_ERR_INVALID, "NULL handle");
+  if (d_map) *d_map = h->d_map;
+  if (d_metrics) *d_metrics = h->d_metrics;
+  return BLAH2HIP_OK;
+}
+
 // ---------------------------------------------------------------- clutter --
 // implemented in clutter.hip; it reports errors through this internal hook so
 // that blah2hip_last_error() covers both translation units

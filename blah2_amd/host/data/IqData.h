@@ -1,6 +1,14 @@
 // IqData: bounded FIFO of complex<double> samples shared between the capture
 // and processing threads.  Same public surface as the reference's
 // src/data/IqData.h:16-100 so blah2.cpp compiles against it unchanged.
+//
+// Inside it is a ring buffer, not the reference's std::deque (only get_data() hands a deque out, as a copy, like
+// the reference's): push_back / pop_front are O(1) without node allocations, and the processing classes can take the
+// front samples as (at most two) contiguous spans -- blah2.cpp:264-287 runs Spectrum, WienerHopf and Ambiguity on the
+// same x, y, and the GPU classes narrow and upload each channel ONCE per CPI (util/DeviceContext.h).  The front of the
+// FIFO may also live on the device only: WienerHopf replaces y's samples (WienerHopf.cpp:156-160) by the filtered
+// channel it has just computed in HBM, Ambiguity consumes them there, and the host copy is written only if somebody
+// reads those samples through this class first.
 #ifndef BLAH2HIP_HOST_IQDATA_H
 #define BLAH2HIP_HOST_IQDATA_H
 
@@ -9,7 +17,15 @@
 #include <mutex>
 #include <stdint.h>
 #include <string>
+#include <utility>
 #include <vector>
+
+// where the samples at the front of an IqData live while they are on the device only
+struct IqDeviceFront {
+  virtual ~IqDeviceFront() {}
+  // writes samples [first, first + count) of the device-resident front into dst
+  virtual void read(uint32_t first, uint32_t count, std::complex<double> *dst) = 0;
+};
 
 class IqData
 {
@@ -32,21 +48,46 @@ public:
   void update_frequency(std::vector<double> frequency);
   std::string to_json(uint64_t timestamp);
 
-  // extension used by the GPU classes: move up to `count` front samples into
-  // a contiguous interleaved (re,im) buffer; throws like pop_front on underflow.
+  // ---- extensions used by the GPU classes ---------------------------------------------------
+  // move up to `count` front samples into a contiguous interleaved (re,im) buffer; throws like pop_front on underflow
   void pop_front_block(double *dst, uint32_t count);
-  // extension: read back what update_spectrum / update_frequency stored (the
-  // reference only exposes them through to_json)
+  // what `count` calls of pop_front() leave behind, without reading the samples (O(1)); on underflow the FIFO is
+  // emptied and the same exception is thrown
+  void drop_front(uint32_t count);
+  // drops everything behind the first `count` samples (WienerHopf.cpp:156-160 clears y and refills it with nSamples)
+  void keep_front(uint32_t count);
+  // samples [first, first + count) as interleaved fp32 (re,im), the conversion blah2hip's fp32 kernels start from.
+  // The caller guarantees first + count <= get_length() and that the range is not device-only.
+  void copy_front_c32(uint32_t first, uint32_t count, float *dst) const;
+  // a counter that changes with every change of the samples (the device cache's validity check)
+  uint64_t generation() const { return gen; }
+  // the first `count` samples now live on the device (`src` reads them back on demand; it must outlive that state,
+  // DeviceContext owns it); the host copies of those samples are stale until materialised
+  void set_device_front(uint32_t count, IqDeviceFront *src);
+  uint32_t device_front_count() const { return devCount; }
+  // read back what update_spectrum / update_frequency stored (the reference only exposes them through to_json)
   const std::vector<std::complex<double>> &get_spectrum() const { return spectrum; }
   const std::vector<double> &get_frequency() const { return frequency; }
+  // called when an IqData dies, so that a cache keyed by its address can forget it
+  static void (*destroyed_hook)(IqData *);
 
 private:
   uint32_t n;
   std::mutex mutex_lock;
-  std::deque<std::complex<double>> *data;
+  std::vector<std::complex<double>> ring; // storage, grows up to n
+  size_t head = 0, count = 0;
+  uint64_t gen = 0;
+  uint32_t devCount = 0;          // front samples whose truth is on the device
+  uint32_t devSkip = 0;           // samples of that device view already consumed or evicted in front of them
+  IqDeviceFront *devSrc = nullptr;
   double min = 0, max = 0, mean = 0;
   std::vector<std::complex<double>> spectrum;
   std::vector<double> frequency;
+
+  void grow();
+  void materialise(); // device-only front samples -> host
+  // the (at most two) contiguous spans of samples [first, first + cnt)
+  void spans(size_t first, size_t cnt, std::pair<const std::complex<double> *, size_t> out[2]) const;
 };
 
 #endif

@@ -58,20 +58,34 @@ template <class T> uint32_t Map<T>::doppler_hz_to_bin(double hz)
   return 0;
 }
 
-// A cheap fingerprint of the cells (every cell's bit pattern, FNV-1a style over 64-bit words):
-// tells whether `data` is still what the engine delivered.
+// A fingerprint of the cells (every cell's bit pattern): tells whether `data` is still what the engine delivered.
+// Four independent multiply-xor chains per row (the single FNV chain it replaces was latency-bound: one dependent
+// multiply per 8 bytes, 0.34 ms per pass over a 513 x 411 map), folded with the row index so that swapped rows differ.
 template <class T> uint64_t Map<T>::fingerprint() const
 {
-  uint64_t h = 1469598103934665603ull;
   static_assert(sizeof(T) % sizeof(uint64_t) == 0, "cells are whole 64-bit words");
+  uint64_t h = 1469598103934665603ull;
+  uint64_t r = 0;
   for (const auto &row : data) {
     const unsigned char *p = reinterpret_cast<const unsigned char *>(row.data());
     const size_t nw = row.size() * sizeof(T) / sizeof(uint64_t);
-    for (size_t i = 0; i < nw; i++) {
-      uint64_t w;
-      std::memcpy(&w, p + i * sizeof(uint64_t), sizeof w); // no aliasing of complex<double> through uint64_t*
-      h = (h ^ w) * 1099511628211ull;
+    uint64_t a0 = 0x9e3779b97f4a7c15ull, a1 = 0xc2b2ae3d27d4eb4full, a2 = 0x165667b19e3779f9ull, a3 = 0x27d4eb2f165667c5ull;
+    size_t i = 0;
+    for (; i + 4 <= nw; i += 4) {
+      uint64_t w[4];
+      std::memcpy(w, p + i * sizeof(uint64_t), sizeof w); // no aliasing of complex<double> through uint64_t*
+      a0 = (a0 ^ w[0]) * 0x100000001b3ull;
+      a1 = (a1 ^ w[1]) * 0x100000001b3ull;
+      a2 = (a2 ^ w[2]) * 0x100000001b3ull;
+      a3 = (a3 ^ w[3]) * 0x100000001b3ull;
     }
+    for (; i < nw; i++) {
+      uint64_t w;
+      std::memcpy(&w, p + i * sizeof(uint64_t), sizeof w);
+      a0 = (a0 ^ w) * 0x100000001b3ull;
+    }
+    const uint64_t rowh = (a0 ^ (a1 >> 7)) + (a2 ^ (a3 << 9)) + (a1 * 31) + a3;
+    h = (h ^ (rowh + ++r)) * 1099511628211ull;
   }
   return h;
 }

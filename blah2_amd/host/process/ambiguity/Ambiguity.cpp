@@ -1,6 +1,7 @@
 #include "process/ambiguity/Ambiguity.h"
 
 #include "blah2hip.h"
+#include "util/DeviceContext.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -38,13 +39,18 @@ Ambiguity::Ambiguity(int32_t delayMin, int32_t delayMax, int32_t dopplerMin, int
   map->delay.assign(delay.begin(), delay.end());
   map->doppler.assign(doppler.begin(), doppler.end());
 
-  const size_t used = (size_t)nCorr * nDopplerBins;
-  bufX.resize(2 * used);
-  bufY.resize(2 * used);
-  mapF.resize(2 * (size_t)nDopplerBins * nDelayBins);
+  DeviceContext &dc = DeviceContext::get();
+  mapF = (float *)dc.alloc_pinned(2 * (size_t)nDopplerBins * nDelayBins * sizeof(float));
+  metF = (double *)dc.alloc_pinned(2 * sizeof(double));
 }
 
-Ambiguity::~Ambiguity() { blah2hip_amb_destroy(engine); }
+Ambiguity::~Ambiguity()
+{
+  DeviceContext &dc = DeviceContext::get();
+  dc.free_pinned(mapF);
+  dc.free_pinned(metF);
+  blah2hip_amb_destroy(engine);
+}
 
 Map<std::complex<double>> *Ambiguity::process(IqData *x, IqData *y)
 {
@@ -54,23 +60,45 @@ Map<std::complex<double>> *Ambiguity::process(IqData *x, IqData *y)
   // consumes, the ones left in the FIFO are rotated here so that x ends up in
   // the state the reference leaves it in.
   const uint32_t total = x->get_length();
-  // Ambiguity.cpp:105-112: pops nCorr samples of each channel per pulse
+  // Ambiguity.cpp:105-112 pops nCorr samples of each channel per pulse.  The samples are consumed where they are
+  // resident -- uploaded once per CPI and shared with SpectrumAnalyser / WienerHopf, or, for y behind the clutter
+  // filter, already in HBM -- and the FIFOs drop them without reading (util/DeviceContext.h).
   nSamples = used;
-  x->pop_front_block(bufX.data(), used); // throws "Attempting to pop from an empty deque"
-  y->pop_front_block(bufY.data(), used);
+  if (x->get_length() < used || y->get_length() < used) { // the reference's pops empty the FIFOs, then throw
+    x->drop_front(used);
+    y->drop_front(used);
+  }
+  DeviceContext &dc = DeviceContext::get();
+  const void *dx = dc.resident(x, used);
+  const void *dy = dc.resident(y, used);
+  if (blah2hip_amb_process_dev(engine, BLAH2HIP_FMT_C32, dx, dy, 1, used, nullptr, nullptr, dc.stream()) != BLAH2HIP_OK)
+    throw std::runtime_error(std::string("Ambiguity::process: ") + blah2hip_last_error());
+  const void *dMap = nullptr;
+  const double *dMet = nullptr;
+  blah2hip_amb_result_ptrs(engine, &dMap, &dMet);
+  dc.d2h(mapF, dMap, 2 * (size_t)nDopplerBins * nDelayBins * sizeof(float));
+  dc.d2h(metF, dMet, 2 * sizeof(double));
+  x->drop_front(used);
+  dc.consumed(x, used);
+  y->drop_front(used);
+  dc.consumed(y, used);
   if (dopplerMiddle != 0 && total > used) {
     const std::complex<double> j(0, 1);
     for (uint32_t i = used; i < total; i++)
       x->push_back(x->pop_front() * std::exp(1.0 * j * 2.0 * M_PI * dopplerMiddle * ((double)i / fs)));
   }
-  double metrics[2] = {0, 0};
-  if (blah2hip_amb_process_c64(engine, bufX.data(), bufY.data(), used, mapF.data(), metrics) != BLAH2HIP_OK)
-    throw std::runtime_error(std::string("Ambiguity::process: ") + blah2hip_last_error());
-  for (uint32_t i = 0; i < nDopplerBins; i++) {
-    const float *row = mapF.data() + 2 * (size_t)i * nDelayBins;
-    std::vector<Complex> &dst = map->data[i];
-    for (uint32_t k = 0; k < nDelayBins; k++) dst[k] = Complex(row[2 * k], row[2 * k + 1]);
-  }
+  dc.sync();
+  const double metrics[2] = {metF[0], metF[1]};
+  const float *mf = mapF;
+  const uint32_t nDel = nDelayBins;
+  Map<Complex> *mp = map.get();
+  dc.parallel_for(nDopplerBins, 32, [mf, nDel, mp](size_t r0, size_t r1) {
+    for (size_t i = r0; i < r1; i++) {
+      const float *row = mf + 2 * i * nDel;
+      std::vector<Complex> &dst = mp->data[i];
+      for (uint32_t k = 0; k < nDel; k++) dst[k] = Complex(row[2 * k], row[2 * k + 1]);
+    }
+  });
   map->bind_engine(engine, 0, metrics[0], metrics[1]);
   return map.get();
 }

@@ -49,8 +49,8 @@ private:
   double dopplerMiddle, cpi;
   uint32_t nfft;
   std::unique_ptr<Map<Complex>> map;
-  std::vector<double> bufX, bufY; // interleaved (re,im) staging for the C ABI
-  std::vector<float> mapF;        // complex fp32 map as the device wrote it
+  float *mapF = nullptr;   // pinned: complex fp32 map as the device wrote it
+  double *metF = nullptr;  // pinned: noisePower, maxPower
 };
 
 #endif

@@ -2,6 +2,7 @@
 
 #include "blah2hip.h"
 #include "process/ambiguity/Ambiguity.h"
+#include "util/DeviceContext.h"
 
 #include <iostream>
 #include <stdexcept>
@@ -11,33 +12,40 @@ WienerHopf::WienerHopf(int32_t delayMin, int32_t delayMax, uint32_t _nSamples) :
 {
   if (blah2hip_clutter_create(delayMin, delayMax, _nSamples, Ambiguity::default_device(), 1, &engine) != BLAH2HIP_OK)
     throw std::runtime_error(std::string("WienerHopf: ") + blah2hip_last_error());
-  bufX.resize(2 * (size_t)nSamples);
-  bufY.resize(2 * (size_t)nSamples);
-  bufOut.resize(2 * (size_t)nSamples);
+  DeviceContext &dc = DeviceContext::get();
+  dOk = (int32_t *)dc.alloc_device(sizeof(int32_t));
+  hOk = (int32_t *)dc.alloc_pinned(sizeof(int32_t));
 }
 
-WienerHopf::~WienerHopf() { blah2hip_clutter_destroy(engine); }
+WienerHopf::~WienerHopf()
+{
+  DeviceContext &dc = DeviceContext::get();
+  dc.free_device(dOk);
+  dc.free_pinned(hOk);
+  blah2hip_clutter_destroy(engine);
+}
 
 bool WienerHopf::process(IqData *x, IqData *y)
 {
-  // the reference copies both deques (WienerHopf.cpp:61-62) and indexes the
-  // first nSamples entries; x is left untouched
-  const std::deque<std::complex<double>> xd = x->get_data(), yd = y->get_data();
-  if (xd.size() < nSamples || yd.size() < nSamples)
+  // the reference copies both deques (WienerHopf.cpp:61-62) and indexes the first nSamples entries; x is left untouched.
+  // Both channels are (made) resident on the device -- uploaded once per CPI, shared with SpectrumAnalyser and Ambiguity.
+  if (x->get_length() < nSamples || y->get_length() < nSamples)
     throw std::runtime_error("WienerHopf::process: fewer samples than nSamples in the buffers");
-  for (uint32_t i = 0; i < nSamples; i++) {
-    bufX[2 * i] = xd[i].real(); bufX[2 * i + 1] = xd[i].imag();
-    bufY[2 * i] = yd[i].real(); bufY[2 * i + 1] = yd[i].imag();
-  }
-  int ok = 0;
-  if (blah2hip_clutter_process_c64(engine, bufX.data(), bufY.data(), nSamples, bufOut.data(), &ok) != BLAH2HIP_OK)
+  DeviceContext &dc = DeviceContext::get();
+  const void *dx = dc.resident(x, nSamples);
+  const void *dy = dc.resident(y, nSamples);
+  void *dyf = dc.front_buffer(y, nSamples);
+  if (blah2hip_clutter_process_dev_fmt(engine, BLAH2HIP_FMT_C32, dx, dy, 1, nSamples, dyf, nSamples, dOk, dc.stream()) != BLAH2HIP_OK)
     throw std::runtime_error(std::string("WienerHopf::process: ") + blah2hip_last_error());
-  if (!ok) {
+  dc.d2h(hOk, dOk, sizeof(int32_t));
+  dc.sync();
+  if (!*hOk) {
     std::cerr << "Chol decomposition failed, skip clutter filter" << std::endl; // WienerHopf.cpp:114
     return false;
   }
-  // WienerHopf.cpp:156-160
-  y->clear();
-  for (uint32_t i = 0; i < nSamples; i++) y->push_back({bufOut[2 * i], bufOut[2 * i + 1]});
+  // WienerHopf.cpp:156-160 clears y and pushes the nSamples filtered values: y then holds exactly those.  They stay in
+  // HBM as the new front of y (Ambiguity consumes them there); the host copy is written only if somebody reads y first.
+  y->keep_front(nSamples);
+  dc.adopt_front(y, nSamples);
   return true;
 }

@@ -26,7 +26,7 @@ public:
 private:
   blah2hip_clutter_s *engine = nullptr;
   uint32_t nSamples;
-  std::vector<double> bufX, bufY, bufOut;
+  int32_t *dOk = nullptr, *hOk = nullptr; // device flag and its pinned host copy
 };
 
 #endif

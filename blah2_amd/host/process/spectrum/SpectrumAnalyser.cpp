@@ -2,6 +2,7 @@
 
 #include "blah2hip.h"
 #include "process/ambiguity/Ambiguity.h"
+#include "util/DeviceContext.h"
 
 #include <stdexcept>
 #include <string>
@@ -11,20 +12,31 @@ SpectrumAnalyser::SpectrumAnalyser(uint32_t _n, double _bandwidth) : n(_n), band
   if (blah2hip_spectrum_create(n, bandwidth, Ambiguity::default_device(), 1, &engine) != BLAH2HIP_OK)
     throw std::runtime_error(std::string("SpectrumAnalyser: ") + blah2hip_last_error());
   blah2hip_spectrum_get_dims(engine, &decimation, &nSpectrum, &nfft);
-  bufX.resize(2 * (size_t)nfft);
-  bufS.resize(2 * (size_t)nSpectrum);
+  DeviceContext &dc = DeviceContext::get();
+  dSpec = (double *)dc.alloc_device(2 * (size_t)nSpectrum * sizeof(double));
+  hSpec = (double *)dc.alloc_pinned(2 * (size_t)nSpectrum * sizeof(double));
 }
 
-SpectrumAnalyser::~SpectrumAnalyser() { blah2hip_spectrum_destroy(engine); }
+SpectrumAnalyser::~SpectrumAnalyser()
+{
+  DeviceContext &dc = DeviceContext::get();
+  dc.free_device(dSpec);
+  dc.free_pinned(hSpec);
+  blah2hip_spectrum_destroy(engine);
+}
 
 void SpectrumAnalyser::process(IqData *x)
 {
-  // SpectrumAnalyser.cpp:33-37: a copy of the FIFO, first nfft entries
-  const std::deque<std::complex<double>> data = x->get_data();
-  if (data.size() < nfft) throw std::runtime_error("SpectrumAnalyser::process: fewer samples than nfft in the buffer");
-  for (uint64_t i = 0; i < nfft; i++) { bufX[2 * i] = data[i].real(); bufX[2 * i + 1] = data[i].imag(); }
-  if (blah2hip_spectrum_process_c64(engine, bufX.data(), (uint32_t)nfft, bufS.data()) != BLAH2HIP_OK)
+  // SpectrumAnalyser.cpp:33-37 reads the first nfft entries of a copy of the FIFO: here the channel is (made) resident on
+  // the device once per CPI and shared with WienerHopf and Ambiguity (util/DeviceContext.h)
+  if (x->get_length() < nfft) throw std::runtime_error("SpectrumAnalyser::process: fewer samples than nfft in the buffer");
+  DeviceContext &dc = DeviceContext::get();
+  const void *dx = dc.resident(x, (uint32_t)nfft);
+  if (blah2hip_spectrum_process_dev(engine, BLAH2HIP_FMT_C32, dx, 1, nfft, dSpec, dc.stream()) != BLAH2HIP_OK)
     throw std::runtime_error(std::string("SpectrumAnalyser::process: ") + blah2hip_last_error());
+  dc.d2h(hSpec, dSpec, 2 * (size_t)nSpectrum * sizeof(double));
+  dc.sync();
+  const double *bufS = hSpec;
   std::vector<std::complex<double>> spectrum(nSpectrum);
   for (uint32_t k = 0; k < nSpectrum; k++) spectrum[k] = {bufS[2 * k], bufS[2 * k + 1]};
   x->update_spectrum(spectrum);

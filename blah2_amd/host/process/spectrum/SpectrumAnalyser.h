@@ -30,7 +30,8 @@ private:
   uint32_t decimation = 0;
   uint32_t nSpectrum = 0;
   uint64_t nfft = 0;
-  std::vector<double> bufX, bufS;
+  double *dSpec = nullptr; // device: nSpectrum complex fp64
+  double *hSpec = nullptr; // pinned host copy
 };
 
 #endif

@@ -158,6 +158,92 @@ int main()
     auto detOwn = CfarDetector1D(1e-3, 1, 4, 0, 15.0).process(&own);
     CHECK(detOwn->get_nDetections() == 1 && detOwn->get_delay()[0] == 18.0 && detOwn->get_doppler()[0] == 40.0);
   }
+  // The device-resident chain (util/DeviceContext.h): (i) WienerHopf leaves the filtered channel in HBM as the front of y;
+  // reading y through the FIFO first (get_data) brings it to the host and must not change what Ambiguity computes
+  // (the device values are fp32, their host copies exact); (ii) the sequence of blah2.cpp:264-287 at BASELINE configs[1]
+  // (2 MS/s, 1 s CPI), timed per CPI.
+  {
+    const uint32_t n = 200000, fsl = 1000000;
+    std::mt19937 gen(11);
+    std::normal_distribution<> g(0.0, 300.0);
+    std::vector<std::complex<double>> xs(n), ys(n);
+    for (uint32_t i = 0; i < n; i++) {
+      xs[i] = {std::round(g(gen)), std::round(g(gen))};
+      std::complex<double> t = 0.8 * xs[i] + std::complex<double>(0.1 * g(gen), 0.1 * g(gen));
+      if (i >= 21) t += 0.05 * xs[i - 21] * std::exp(std::complex<double>(0, 2 * M_PI * 40.0 * i / fsl));
+      ys[i] = {std::round(t.real()), std::round(t.imag())};
+    }
+    std::vector<std::vector<std::complex<double>>> maps[2];
+    double noise[2] = {0, 0};
+    for (int pass = 0; pass < 2; pass++) {
+      IqData x{n}, y{n};
+      for (uint32_t i = 0; i < n; i++) { x.push_back(xs[i]); y.push_back(ys[i]); }
+      WienerHopf filter(-10, 100, n);
+      Ambiguity ambiguity(-10, 100, -100, 100, fsl, n, true);
+      CHECK(filter.process(&x, &y));
+      CHECK(y.get_length() == n && y.device_front_count() == n);
+      if (pass == 1) {
+        const auto yd = y.get_data(); // materialises
+        CHECK(yd.size() == n && y.device_front_count() == 0);
+        double e_in = 0, e_out = 0;
+        for (uint32_t i = 0; i < n; i++) { e_in += std::norm(ys[i]); e_out += std::norm(yd[i]); }
+        CHECK(e_out < 0.1 * e_in); // the direct path is cancelled
+        CHECK(x.get_data()[12345] == xs[12345]); // x untouched
+      }
+      auto map = ambiguity.process(&x, &y);
+      map->set_metrics();
+      maps[pass] = map->data;
+      noise[pass] = map->noisePower;
+      CHECK(x.get_length() == n - ambiguity.get_n_samples() && y.get_length() == x.get_length());
+    }
+    CHECK(maps[0] == maps[1] && noise[0] == noise[1]);
+  }
+  {
+    const uint32_t fs2 = 2000000, n2 = 2000000;
+    const int nCpi = 4;
+    SpectrumAnalyser spectrumAnalyser(n2, 2000);
+    WienerHopf filter(-10, 400, n2);
+    Ambiguity ambiguity(-10, 400, -256, 256, fs2, n2, true);
+    CfarDetector1D cfar(1e-5, 2, 6, 5, 15.0);
+    IqData x{n2}, y{n2};
+    std::mt19937 gen(5);
+    std::uniform_int_distribution<int> u(-300, 300);
+    std::vector<std::complex<double>> xs(n2);
+    double t_seq = 0, t_part[5] = {0, 0, 0, 0, 0};
+    size_t nDet = 0;
+    for (int c = 0; c < nCpi; c++) {
+      for (auto &v : xs) v = {(double)u(gen), (double)u(gen)};
+      for (uint32_t i = 0; i < n2; i++) { // blah2.cpp:254-258 (extract_buffer: the reference's own loop, not timed here)
+        x.push_back(xs[i]);
+        std::complex<double> t = 0.8 * xs[i] + std::complex<double>(u(gen) * 0.1, u(gen) * 0.1);
+        if (i >= 37) t += 0.05 * xs[i - 37] * std::exp(std::complex<double>(0, 2 * M_PI * (-63.0) * i / fs2));
+        y.push_back({std::round(t.real()), std::round(t.imag())});
+      }
+      auto tic = std::chrono::steady_clock::now();
+      auto lap = [&](int k) {
+        const auto now = std::chrono::steady_clock::now();
+        if (c) t_part[k] += std::chrono::duration<double, std::milli>(now - tic).count();
+        tic = now;
+      };
+      const auto t0 = tic;
+      spectrumAnalyser.process(&x); lap(0);           // :264
+      CHECK(filter.process(&x, &y)); lap(1);          // :270
+      auto map = ambiguity.process(&x, &y); lap(2);   // :278
+      map->set_metrics(); lap(3);                     // :279
+      auto det = cfar.process(map); lap(4);           // :285
+      if (c) t_seq += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      nDet = det->get_nDetections();
+      bool found = false;
+      for (size_t i = 0; i < nDet; i++)
+        if (det->get_delay()[i] == 37.0 && std::fabs(det->get_doppler()[i] + 63.0) < 1.01) found = true;
+      CHECK(found);
+      CHECK(x.get_length() == n2 - ambiguity.get_n_samples());
+    }
+    std::printf("sequence blah2.cpp:264-287 at 2 MS/s x 1 s (Spectrum, WienerHopf 410 taps, Ambiguity 513 x 411, set_metrics, CFAR): "
+                "%.2f ms/CPI  [spectrum %.2f, filter %.2f, ambiguity %.2f, set_metrics %.2f, cfar %.2f]; %zu detections\n",
+                t_seq / (nCpi - 1), t_part[0] / (nCpi - 1), t_part[1] / (nCpi - 1), t_part[2] / (nCpi - 1), t_part[3] / (nCpi - 1),
+                t_part[4] / (nCpi - 1), nDet);
+  }
   std::printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
   return failures ? 1 : 0;
 }

@@ -322,6 +322,26 @@ int blah2hip_spectrum_process_c32(blah2hip_spectrum_t h, const float *x, uint32_
 int blah2hip_spectrum_process_dev(blah2hip_spectrum_t h, int fmt, const void *d_x, uint32_t n_cpi,
                                   uint64_t cpi_stride, double *d_out, void *stream);
 
+/* ---- device context for host bindings ------------------------------------
+ * What a host-language binding needs of the HIP runtime to keep a CPI resident on the device across the calls
+ * of blah2.cpp:264-287 (Spectrum -> WienerHopf -> Ambiguity -> CFAR on the same x, y) without linking it: one
+ * stream, pinned staging memory, device buffers and asynchronous copies.  blah2_amd/host/util/DeviceContext
+ * builds the per-process sample cache of the drop-in classes on it. */
+typedef struct blah2hip_ctx_s *blah2hip_ctx_t;
+int blah2hip_ctx_create(int device, blah2hip_ctx_t *out);
+int blah2hip_ctx_destroy(blah2hip_ctx_t c);
+void *blah2hip_ctx_stream(blah2hip_ctx_t c);                  /* the hipStream_t the dev entry points take */
+int blah2hip_ctx_sync(blah2hip_ctx_t c);                      /* waits for everything enqueued on the stream */
+int blah2hip_ctx_malloc(blah2hip_ctx_t c, size_t bytes, void **dptr);
+int blah2hip_ctx_free(blah2hip_ctx_t c, void *dptr);
+int blah2hip_ctx_malloc_host(blah2hip_ctx_t c, size_t bytes, void **hptr); /* pinned */
+int blah2hip_ctx_free_host(blah2hip_ctx_t c, void *hptr);
+int blah2hip_ctx_h2d(blah2hip_ctx_t c, void *dptr, const void *hptr, size_t bytes); /* enqueues on the stream */
+int blah2hip_ctx_d2h(blah2hip_ctx_t c, void *hptr, const void *dptr, size_t bytes); /* enqueues on the stream */
+/* device pointers of a handle's internal results of the last blah2hip_amb_process_dev with NULL outputs:
+ * map [max_batch][n_doppler][n_delay] complex fp32 and metrics [max_batch][2] doubles */
+int blah2hip_amb_result_ptrs(blah2hip_amb_t h, const void **d_map, const double **d_metrics);
+
 /* ---- per-kernel timing (HIP events on the launch stream) ---------------- */
 #define BLAH2HIP_K_RANGE 0
 #define BLAH2HIP_K_DOPPLER 1
