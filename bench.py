@@ -172,6 +172,47 @@ def cpu_baseline(args_amb, budget_s=20.0):
     return res
 
 
+# ----------------------------------------------------------------------------- host-buffer boundary
+def e2e_host(cfg, local, np, blah2_amd):
+    """One CPI handed over in HOST buffers (the PCIe-inclusive figures, never `value`): ms per CPI through
+    blah2hip_amb_process_c32 (pageable complex64 in, map out), _c64 (complex128 narrowed into pinned staging), and
+    through the C++ drop-in classes -- the whole sequence of blah2.cpp:264-287 (Spectrum, WienerHopf, Ambiguity,
+    set_metrics, CFAR on IqData FIFOs) at BASELINE configs[1], timed by blah2_amd/host/test/test_ambiguity --sequence."""
+    import re
+    dmin, dmax, fmin, fmax, fs, n = cfg
+    amb = blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local)
+    rng = np.random.default_rng(1)
+    x64 = np.round(300 * (rng.standard_normal(n) + 1j * rng.standard_normal(n)))
+    y64 = np.round(0.8 * x64 + 30 * (rng.standard_normal(n) + 1j * rng.standard_normal(n)))
+    x32, y32 = x64.astype(np.complex64), y64.astype(np.complex64)
+    out = {}
+    for key, (xa, ya) in (("c32_ms", (x32, y32)), ("c64_ms", (x64, y64))):
+        for _ in range(3):
+            amb.process(xa, ya)
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            amb.process(xa, ya)
+        out[key] = (time.perf_counter() - t0) / reps * 1e3
+    amb.close()
+    exe = os.path.join(ROOT, "blah2_amd", "host", "test", "test_ambiguity")
+    out["classes_ms"] = None
+    if os.path.exists(exe):
+        try:
+            p = subprocess.run([exe, "--sequence"], capture_output=True, text=True, timeout=120,
+                               env=dict(os.environ, BLAH2HIP_DEVICE=str(local)))
+            m = re.search(r"CFAR\): ([0-9.]+) ms/CPI\s+\[spectrum ([0-9.]+), filter ([0-9.]+), ambiguity ([0-9.]+), set_metrics ([0-9.]+), cfar ([0-9.]+)\]", p.stdout)
+            if m and p.returncode == 0:
+                v = [float(g) for g in m.groups()]
+                out["classes_ms"] = v[0]
+                out["classes_stages_ms"] = dict(zip(("spectrum", "filter", "ambiguity", "set_metrics", "cfar"), v[1:]))
+        except Exception as e:  # the figure is informative; a missing binary must not void the bench line
+            out["classes_error"] = str(e)
+    out["note"] = ("host-buffer boundary, one CPI per call; classes_ms = SpectrumAnalyser + WienerHopf (410 taps) + Ambiguity + "
+                   "set_metrics + CfarDetector1D through the C++ drop-in classes (blah2.cpp:264-287), 2 x 2 M complex<double> in IqData")
+    return out
+
+
 # ----------------------------------------------------------------------------- parity gate
 def parity_check(np, O, cfg, fmt, chain, cfar, n_doppler, x_h, y_h, got_map, got_met, got_hits=None, amb=None):
     """One CPI of the timed batch against the fp64 oracle.  x_h / y_h: the exact values the device read."""
@@ -509,6 +550,8 @@ def main(argv=None):
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg)
+            if a.config == "cfg2":
+                res["e2e_host"] = e2e_host(cfg, local, np, blah2_amd)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()  # rank 0 has been checking parity: every rank leaves the group together

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdio>
 #include <random>
+#include <string>
 #include <stdexcept>
 
 static int failures = 0;
@@ -33,8 +34,15 @@ static void random_iq(IqData &iq, unsigned seed)
   for (uint32_t i = 0; i < iq.get_n(); ++i) iq.push_back({dist(gen), dist(gen)});
 }
 
-int main()
+static void sequence_at_cfg2();
+
+int main(int argc, char **argv)
 {
+  if (argc > 1 && std::string(argv[1]) == "--sequence") { // bench.py: only the timed sequence of blah2.cpp:264-287
+    sequence_at_cfg2();
+    std::printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
+    return failures ? 1 : 0;
+  }
   // TestHammingNumber.cpp:15-17
   CHECK(next_hamming(104) == 108);
   CHECK(next_hamming(3322) == 3375);
@@ -198,6 +206,13 @@ int main()
     }
     CHECK(maps[0] == maps[1] && noise[0] == noise[1]);
   }
+  sequence_at_cfg2();
+  std::printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
+  return failures ? 1 : 0;
+}
+
+static void sequence_at_cfg2()
+{
   {
     const uint32_t fs2 = 2000000, n2 = 2000000;
     const int nCpi = 4;
@@ -244,6 +259,4 @@ int main()
                 t_seq / (nCpi - 1), t_part[0] / (nCpi - 1), t_part[1] / (nCpi - 1), t_part[2] / (nCpi - 1), t_part[3] / (nCpi - 1),
                 t_part[4] / (nCpi - 1), nDet);
   }
-  std::printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
-  return failures ? 1 : 0;
 }

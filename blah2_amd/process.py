@@ -33,6 +33,19 @@ class Map:
         self.doppler = doppler
         self.noisePower = noise_power
         self.maxPower = max_power
+        # which device copy this map mirrors: the engine's process-call counter and a fingerprint of the cells
+        # (like Map::fingerprint of the C++ class): the detectors run on the engine's copy only while both still match
+        self._gen = getattr(owner, "_gen", None)
+        self._fp = self._fingerprint()
+
+    def _fingerprint(self):
+        w = np.ascontiguousarray(self.data).view(np.uint64).ravel()
+        return (int(np.bitwise_xor.reduce(w)) if w.size else 0, int(w[::7].sum(dtype=np.uint64)) if w.size else 0, self.data.shape)
+
+    def device_copy_is_current(self) -> bool:
+        """True while the engine's device copy is still this map: no later process call on the engine and no change of
+        ``data`` by the caller."""
+        return self._owner is not None and self._gen == getattr(self._owner, "_gen", None) and self._fp == self._fingerprint()
 
     def get_nRows(self):
         return self.data.shape[0]
@@ -81,12 +94,14 @@ class Ambiguity:
                                        1 if roundHamming else 0, n_doppler_bins, device, max_batch, C.byref(h)))
         self._h = h
         self._L = L
+        self.device = device
         self.dims = AmbDims()
         check(L.blah2hip_amb_get_dims(h, C.byref(self.dims)))
         self.delay = np.zeros(self.dims.n_delay_bins, dtype=np.int32)
         self.doppler = np.zeros(self.dims.n_doppler_bins, dtype=np.float64)
         check(L.blah2hip_amb_get_axes(h, _ptr(self.delay), _ptr(self.doppler)))
         self._n_samples = n
+        self._gen = 0  # process calls so far: a Map remembers which one produced it
 
     # -- lifetime -----------------------------------------------------------
     def close(self):
@@ -148,6 +163,7 @@ class Ambiguity:
             raise RuntimeError("Attempting to pop from an empty deque")
         check(rc)
         self._n_samples = self.dims.n_used  # Ambiguity.cpp:105
+        self._gen += 1
         return self._result(out, met)
 
     def process_i16(self, iq):
@@ -161,12 +177,14 @@ class Ambiguity:
             raise RuntimeError("Attempting to pop from an empty deque")
         check(rc)
         self._n_samples = self.dims.n_used
+        self._gen += 1
         return self._result(out, met)
 
     def process_dev(self, fmt, d_x, d_y, n_cpi, cpi_stride, d_map=None, d_metrics=None, stream=0):
         """Enqueue the device-resident chain on ``stream`` (raw pointers/ints)."""
         check(self._L.blah2hip_amb_process_dev(self._h, fmt, d_x, d_y, n_cpi, cpi_stride, d_map,
                                                d_metrics, stream))
+        self._gen += 1
 
     def read_last(self, cpi=0):
         nD, nC = self.dims.n_doppler_bins, self.dims.n_delay_bins
@@ -238,6 +256,10 @@ class CfarDetector1D:
         self.minDelay, self.minDoppler = int(minDelay), float(minDoppler)
 
     def process(self, x: Map) -> Detection:
+        """CfarDetector1D::process on ``x.data`` (CfarDetector1D.cpp:23-100).  While ``x`` is still the map the engine holds
+        on the device (no later process call, cells untouched) it runs there without an upload; any other Map -- built or
+        modified by the caller, or outlived by a newer CPI -- is uploaded and runs through the same kernel
+        (blah2hip_cfar1d_map), like the C++ class does."""
         amb = x._owner
         cells = x.data.size
         cap = cells
@@ -245,9 +267,19 @@ class CfarDetector1D:
         f = np.zeros(cap)
         s = np.zeros(cap)
         n = C.c_uint32(0)
-        check(amb._L.blah2hip_cfar1d_process(amb._h, x._cpi_index, self.pfa, self.nGuard, self.nTrain,
-                                             self.minDelay, self.minDoppler, _ptr(d), _ptr(f), _ptr(s),
-                                             cap, C.byref(n)))
+        if x.device_copy_is_current():
+            check(amb._L.blah2hip_cfar1d_process(amb._h, x._cpi_index, self.pfa, self.nGuard, self.nTrain,
+                                                 self.minDelay, self.minDoppler, _ptr(d), _ptr(f), _ptr(s),
+                                                 cap, C.byref(n)))
+        else:
+            L = _lib.load()
+            m = np.ascontiguousarray(x.data, dtype=np.complex64)
+            dax = np.ascontiguousarray(x.delay, dtype=np.int32)
+            fax = np.ascontiguousarray(x.doppler, dtype=np.float64)
+            dev = amb.device if amb is not None else 0
+            check(L.blah2hip_cfar1d_map(_ptr(m), m.shape[0], m.shape[1], _ptr(dax), _ptr(fax), float(x.noisePower), self.pfa,
+                                        self.nGuard, self.nTrain, self.minDelay, self.minDoppler, dev, _ptr(d), _ptr(f),
+                                        _ptr(s), cap, C.byref(n)))
         k = n.value
         return Detection(d[:k].copy(), f[:k].copy(), s[:k].copy())
 
@@ -286,6 +318,9 @@ class CfarDetector2D:
 
     def process(self, x: Map) -> Detection:
         amb = x._owner
+        if not x.device_copy_is_current():
+            raise ValueError("CfarDetector2D.process: this Map is no longer the engine's device copy (a later process call, or "
+                             "its cells were changed); the 2-D detector has no host-map entry point")
         cap = x.data.size
         d, f, s = np.zeros(cap), np.zeros(cap), np.zeros(cap)
         n = C.c_uint32(0)

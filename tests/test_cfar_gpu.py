@@ -199,3 +199,31 @@ def test_cfar2d_window_beyond_the_tile_halo_takes_the_sat_kernels(b2):
     amb.set_cfar2d_kernel("tile")
     with pytest.raises(b2.Blah2HipError):
         b2.CfarDetector2D(*big).process(m)
+
+
+def test_python_detector_follows_the_map_it_is_given(b2):
+    """Like the C++ classes (Map::fingerprint): CfarDetector1D.process runs on the engine's device copy only while the Map
+    still IS that copy.  A Map kept across a later process call, or whose cells the caller changed, is uploaded and
+    evaluated as given (CfarDetector1D.cpp:23-100 reads x->data); the 2-D detector, which has no host-map entry, refuses."""
+    g = load_golden("medium")
+    fs, n, dmin, dmax, fmin, fmax, rh = (int(v) for v in g["params"])
+    pfa, ng, nt, md, mdop = g["det_params"][:5]
+    det = b2.CfarDetector1D(pfa, int(ng), int(nt), int(md), mdop)
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, bool(rh))
+    m1 = amb.process(g["x"], g["y"])
+    assert m1.device_copy_is_current()
+    d1 = det.process(m1)
+    assert np.array_equal(d1.get_delay(), g["cfar"][0])
+    m2 = amb.process(g["y"], g["x"])  # another CPI: the device now holds m2
+    assert not m1.device_copy_is_current() and m2.device_copy_is_current()
+    d1b = det.process(m1)             # evaluated on m1's own cells (uploaded), not on the device's m2
+    assert np.array_equal(d1b.get_delay(), d1.get_delay()) and np.array_equal(d1b.get_doppler(), d1.get_doppler())
+    assert np.allclose(d1b.get_snr(), d1.get_snr(), atol=1e-9)
+    with pytest.raises(ValueError):
+        b2.CfarDetector2D(pfa, 1, 3, 1, 2, int(md), mdop).process(m1)
+    # cells changed by the caller: one cell lifted far above its neighbours must now be reported
+    i, j = 7, 60
+    m2.data[i, j] = 1e4 * np.abs(m2.data).max()
+    assert not m2.device_copy_is_current()
+    d2 = det.process(m2)
+    assert (float(m2.delay[j]), float(m2.doppler[i])) in set(zip(d2.get_delay(), d2.get_doppler()))
