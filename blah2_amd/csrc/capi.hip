@@ -347,9 +347,55 @@ template <class In> int launch_rangew_t(blah2hip_amb_s *h, const RangeArgs &a, I
 // F = 2048 (cfg 2 x 128): 16-point 1192, 8-point lane form 1363-1372 (4 or 3 waves per SIMD); F = 4096
 // (cfg 3 x 8): 568 vs 707.  The 8-point transform executes 26 % more VALU instructions per point
 // (radix 8-8-8-4 twiddles + the lane butterflies) and the kernel follows that count, not its occupancy.
+// F = 4096 on the two-wave kernel
+bool use_wave2_range(const blah2hip_amb_s *h, int nPulses)
+{
+  if (h->r3 != 16 || h->rangeKernel == BLAH2HIP_RANGE_E16) return false;
+  // Only on request.  Measured (round 3, cfg 3 x 32, same box, interleaved): 63.8 us/CPI against 60.6-61.3 for the
+  // workgroup kernel.  A wave of the pair spends what a wave of the one-wave kernel spends per 32-point-per-lane
+  // transform (10.9 k cycles per transform incl. its share of the loads, s_memtime trace), but a 4096-point transform
+  // is two of those -- 22 wave-transforms per pulse either way; the single exchange does not buy what the second
+  // twiddle multiply and the pair's barriers cost.
+  (void)nPulses;
+  return h->rangeKernel == BLAH2HIP_RANGE_WAVE2;
+}
+
+template <class In> int launch_rangew2_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
+{
+  const size_t lds = Wave2Fft::LDS_BYTES;
+  const bool xhalf = a.plan.segLen <= 16 * 128;
+  auto kern = xhalf ? rangew2_kernel<In, true> : rangew2_kernel<In, false>;
+  LDSCFG(kern, lds);
+  const int grid = std::min<int>(a.nPulses, range_grid_cap(h, lds, 2, 8)); // four pairs per CU (LDS; 2 waves per SIMD)
+#ifdef RANGEW_TRACE
+  static uint64_t *dbg = nullptr;
+  static int calls = 0;
+  if (!dbg) HIPCHK(hipMalloc(&dbg, 64));
+  HIPCHK(hipMemsetAsync(dbg, 0, 64, st));
+  RangeArgs a2 = a;
+  a2.dbg = dbg;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(Wave2Fft::NT), lds, st, a2, in);
+  if (++calls == 8) {
+    uint64_t hcnt[6];
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(hcnt, dbg, 48, hipMemcpyDeviceToHost));
+    double tot = 0;
+    for (int k = 0; k < 6; k++) tot += (double)hcnt[k];
+    fprintf(stderr, "[rangew2 trace] grid %d pulses %d: other %.3f load %.3f X %.3f Y %.3f inv %.3f store %.3f of %.0f ticks/wave\n", grid, a.nPulses,
+            hcnt[0] / tot, hcnt[1] / tot, hcnt[2] / tot, hcnt[3] / tot, hcnt[4] / tot, hcnt[5] / tot, tot / grid / 2);
+  }
+#else
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(Wave2Fft::NT), lds, st, a, in);
+#endif
+  HIPCHK(hipGetLastError());
+  h->lastRange = BLAH2HIP_RANGE_WAVE2;
+  return BLAH2HIP_OK;
+}
+
 template <class In> int launch_range(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
 {
   if (use_wave_range(h, a.nPulses)) return launch_rangew_t(h, a, in, st);
+  if (use_wave2_range(h, a.nPulses)) return launch_rangew2_t(h, a, in, st);
   switch (h->r3) {
   case 4: return launch_range8_t<2>(h, a, in, st);
   case 8: return launch_range_t<8>(h, a, in, st);
@@ -678,8 +724,10 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
     h->rangeGridForce = (int)value;
     return BLAH2HIP_OK;
   case BLAH2HIP_OPT_RANGE_KERNEL:
-    if (value != 0 && value != BLAH2HIP_RANGE_WAVE && value != BLAH2HIP_RANGE_E16)
-      return fail(BLAH2HIP_ERR_INVALID, "range kernel: 0 (by transform length), BLAH2HIP_RANGE_E16 or BLAH2HIP_RANGE_WAVE");
+    if (value != 0 && value != BLAH2HIP_RANGE_WAVE && value != BLAH2HIP_RANGE_E16 && value != BLAH2HIP_RANGE_WAVE2)
+      return fail(BLAH2HIP_ERR_INVALID, "range kernel: 0 (by transform length), BLAH2HIP_RANGE_E16, _WAVE or _WAVE2");
+    if (value == BLAH2HIP_RANGE_WAVE2 && h->r3 != 16)
+      return fail(BLAH2HIP_ERR_UNSUPPORTED, "the two-wave range kernel is a 4096-point transform");
     if (value == BLAH2HIP_RANGE_WAVE && h->r3 != 8)
       return fail(BLAH2HIP_ERR_UNSUPPORTED, "the one-wave range kernel is a 2048-point transform");
     if (value == BLAH2HIP_RANGE_E16 && h->r3 == 4)

@@ -10,6 +10,7 @@
 #include "../../blah2_amd/csrc/range_core.hpp"
 #include "../../blah2_amd/csrc/fft_wg8.hpp"
 #include "../../blah2_amd/csrc/fft_wave.hpp"
+#include "../../blah2_amd/csrc/fft_wave2.hpp"
 
 #include <cmath>
 #include <complex>
@@ -218,6 +219,77 @@ int test_fft_wave()
   return (e32 < 2e-5 && err / peak < 2e-6 && ierr < 2e-6) ? 0 : 1;
 }
 
+// two-wave 4096-point transform (fft_wave2.hpp): 2 x 64 lanes x 32 points; both lane exchanges emulated on lane pairs
+template <int SIGN, int NZ = 32> void wave2_transform(std::vector<cf> &v, const std::vector<cf> &tw, std::vector<cf> &X)
+{
+  using W = Wave2Fft;
+  std::vector<W::Tw> w(128);
+  std::vector<cf> table(W::TW_ELEMS);
+  for (int t = 0; t < 128; t++) W::fill_table(t, 128, tw.data(), table.data());
+  for (int t = 0; t < 128; t++) W::load_twiddles(t >> 6, t & 63, tw.data(), table.data(), w[t]);
+  for (int t = 0; t < 128; t++) W::s1<SIGN, NZ>(&v[t * 32], w[t]);
+  for (int wv = 0; wv < 2; wv++)
+    for (int l = 0; l < 32; l++) WaveFft::sw_host(&v[(wv * 64 + l) * 32], &v[(wv * 64 + l + 32) * 32]);
+  for (int t = 0; t < 128; t++) W::b1<SIGN>(&v[t * 32], w[t]);
+  for (int wv = 0; wv < 2; wv++)
+    for (int l = 0; l < 64; l++)
+      if (!(l & 16)) WaveFft::sw_host(&v[(wv * 64 + l) * 32], &v[(wv * 64 + l + 16) * 32]); // v_permlane16_swap: same pattern on rows
+  for (int t = 0; t < 128; t++) W::b2<SIGN>(t >> 6, t & 63, &v[t * 32], w[t], X.data());
+  for (int t = 0; t < 128; t++) W::s3<SIGN>(t >> 6, t & 63, &v[t * 32], X.data());
+}
+
+int test_fft_wave2()
+{
+  using W = Wave2Fft;
+  constexpr int F = W::F;
+  std::mt19937 gen(4242);
+  std::uniform_real_distribution<float> dist(-1.f, 1.f);
+  std::vector<cf> in(F), tw(F), X(W::X_ELEMS);
+  for (auto &c : in) c = cmake(dist(gen), dist(gen));
+  for (int k = 0; k < F; k++) { double a = -2.0 * M_PI * k / F; tw[k] = cmake((float)std::cos(a), (float)std::sin(a)); }
+  auto T_of = [](int t) { return W::logical(t >> 6, t & 63); };
+  double worst = 0, worst_inv = 0, worst_nz = 0;
+  for (int nz : {32, 16}) {
+    std::vector<cf> src = in;
+    if (nz == 16) for (int n = 2048; n < F; n++) src[n] = cmake(0.f, 0.f);
+    std::vector<cf> v(F);
+    for (int t = 0; t < 128; t++)
+      for (int k = 0; k < 32; k++) v[t * 32 + k] = (nz == 16 && k >= 16) ? cmake(77.f, -55.f) /* never read */ : src[T_of(t) + 128 * k];
+    if (nz == 16) wave2_transform<-1, 16>(v, tw, X); else wave2_transform<-1>(v, tw, X);
+    // reference spectrum by fp64 FFT-free evaluation on a subset of bins would be slow: use the full O(N^2) sum in fp64
+    std::vector<cd> ref(F);
+    double peak = 0;
+    for (int m = 0; m < F; m++) {
+      cd acc = 0;
+      for (int n = 0; n < (nz == 16 ? 2048 : F); n++) {
+        const double a = -2.0 * M_PI * (double)(((long)m * n) % F) / F;
+        acc += cd(src[n].x, src[n].y) * cd(std::cos(a), std::sin(a));
+      }
+      ref[m] = acc;
+      peak = std::max(peak, std::abs(acc));
+    }
+    double err = 0;
+    for (int t = 0; t < 128; t++)
+      for (int a = 0; a < 32; a++) {
+        const cf g = v[t * 32 + a];
+        err = std::max(err, std::abs(cd(g.x, g.y) - ref[T_of(t) + 128 * a]));
+      }
+    if (nz == 32) {
+      worst = err / peak;
+      wave2_transform<+1>(v, tw, X);
+      for (int t = 0; t < 128; t++)
+        for (int c = 0; c < 32; c++) {
+          const cf g = v[t * 32 + c], e = in[T_of(t) + 128 * c];
+          worst_inv = std::max(worst_inv, (double)std::abs(cd(g.x / F - e.x, g.y / F - e.y)));
+        }
+    } else {
+      worst_nz = err / peak;
+    }
+  }
+  std::printf("WAVE2 F=%d fwd_rel_err=%.3e inv_abs_err=%.3e nz16_rel_err=%.3e\n", F, worst, worst_inv, worst_nz);
+  return (worst < 2e-6 && worst_inv < 2e-6 && worst_nz < 2e-6) ? 0 : 1;
+}
+
 // the pruned 16-point DFT of the zero-padded reference segments against the full one
 int test_dft16_nz9()
 {
@@ -325,7 +397,7 @@ int test_range(int nCorr, int nD, int dMin, int dMax, int nSeg, int segLen, unsi
 int main(int argc, char **argv)
 {
   if (argc >= 2 && !std::strcmp(argv[1], "fft"))
-    return test_fft<4>() | test_fft<8>() | test_fft<16>() | test_fft8<2>() | test_fft8<4>() | test_fft8<8>() | test_fft_wave() | test_dft16_nz9();
+    return test_fft<4>() | test_fft<8>() | test_fft<16>() | test_fft8<2>() | test_fft8<4>() | test_fft8<8>() | test_fft_wave() | test_fft_wave2() | test_dft16_nz9();
   if (argc >= 10 && !std::strcmp(argv[1], "range")) {
     const int R3 = std::atoi(argv[2]);
     const int a[7] = {std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]),

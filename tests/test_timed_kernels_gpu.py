@@ -223,3 +223,29 @@ def test_mixed_format_int16_reference_fp32_surveillance(b2, geom, fft_len):
     d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
     ref = O.ambiguity_process(d, xs[B - 1], ys[B - 1])
     assert np.max(np.abs(maps[1][B - 1] - ref)) / np.max(np.abs(ref)) <= PEAK_TOL
+
+
+@pytest.mark.parametrize("geom,fmt,xhalf", [((-24, 2023, -64, 64, 1_260_000, 1_260_000), "c32", True),
+                                            ((-24, 2023, -64, 64, 1_260_000, 1_260_000), "i16", True),
+                                            ((-10, 89, -20, 20, 123_000, 123_000), "c32", False),
+                                            ((1, 299, -100, 100, 1_000_000, 777_001), "c32", False)])
+def test_two_wave_range_kernel(b2, geom, fmt, xhalf):
+    """rangew2_kernel (a pair of waves per pulse on the two-wave 4096-point transform: v_permlane32_swap and
+    v_permlane16_swap radix-2 steps, one LDS exchange), forced, three CPIs per launch: the half-zero reference
+    segments of the configs[2] shape (16 of 32 x loads, pruned first step), full segments, a ragged pulse length with
+    a lag window that starts at a positive lag, and the int16 wire format."""
+    from blah2_amd import _lib
+    amb = run_batch(b2, geom, 3, "auto", seeds=(120, 121, 122), fmt=fmt, fft_len=4096, range_kernel=_lib.RANGE_WAVE2,
+                    expect=_expected_doppler3(geom), targets=((37, -13.0, 0.05),), cell_tol=2e-4)
+    assert amb.dims.fft_len == 4096 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE2
+    assert (amb.dims.seg_len <= 2048) == xhalf
+
+
+def _expected_doppler3(geom):
+    dmin, dmax, fmin, fmax, fs, n = geom
+    d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
+    if d.n_doppler_bins <= 513:
+        if 3 * -(-d.n_delay_bins // 16) >= 256:
+            return "tile16"
+        return "tile8" if 3 * -(-d.n_delay_bins // 8) >= 128 else "column"
+    return "tilew" if 3 * -(-d.n_delay_bins // 8) >= 128 else "column"
