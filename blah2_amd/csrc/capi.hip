@@ -459,6 +459,7 @@ bool doppler_kernel_applicable(const blah2hip_amb_s *h, int which)
   case BLAH2HIP_DOP_TILE16: return h->dopR3 == 4;
   case BLAH2HIP_DOP_TILEM: return (h->dopR3 == 8 && nD <= DopM<8>::MAX_ND) || (h->dopR3 == 16 && nD <= DopM<16>::MAX_ND);
   case BLAH2HIP_DOP_TILEW: return h->dopR3 == 8 && nD <= DOPW_MAX_ND;
+  case BLAH2HIP_DOP_TILEW2: return h->dopR3 == 16 && nD <= DOPW2_MAX_ND;
   case BLAH2HIP_DOP_COLUMN: return h->dopR3 != 0;
   case BLAH2HIP_DOP_DIRECT: return true;
   default: return false;
@@ -478,6 +479,7 @@ int pick_doppler(const blah2hip_amb_s *h, uint32_t n_cpi)
   if (h->dopR3 == 4 && (int)n_cpi * ((nDelay + 15) / 16) >= h->numCU) return BLAH2HIP_DOP_TILE16;
   if (fills && h->dopR3 == 4) return BLAH2HIP_DOP_TILE8;
   if (fills && doppler_kernel_applicable(h, BLAH2HIP_DOP_TILEW)) return BLAH2HIP_DOP_TILEW;
+  if (fills && doppler_kernel_applicable(h, BLAH2HIP_DOP_TILEW2)) return BLAH2HIP_DOP_TILEW2;
   if (fills && doppler_kernel_applicable(h, BLAH2HIP_DOP_TILEM)) return BLAH2HIP_DOP_TILEM;
   return BLAH2HIP_DOP_COLUMN;
 }
@@ -919,6 +921,21 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     hipLaunchKernelGGL(doppler_tilew_kernel, dim3(wgs), dim3(64 * DOPW_NCOL), lds, st, da, (int)n_cpi, (uint64_t *)nullptr);
 #endif
     nPartsUsed = grid;
+    break;
+  }
+  case BLAH2HIP_DOP_TILEW2: {
+    const int tiles = (int)((nDelay + DOPW2_NCOL - 1) / DOPW2_NCOL);
+    const int groups = (int)((nDelay + 15) / 16);
+    const size_t lds = (size_t)DOPW2_LDS_ELEMS * sizeof(cf);
+    LDSCFG(doppler_tilew2_kernel, lds);
+    // persistent: one workgroup per CU (LDS); a multiple of 32 (the four quarters of a 16-column tile on one XCD)
+    const int64_t want = (int64_t)groups * n_cpi * 4;
+    int wgs = (int)std::min<int64_t>(want, h->dopGridForce ? h->dopGridForce : h->numCU);
+    wgs = std::max(32, (wgs + 31) & ~31);
+    if (!h->dopGridForce && wgs > h->numCU) wgs = std::max(32, h->numCU & ~31);
+    dopGrid = wgs; dopTiles = groups * (int)n_cpi * 4;
+    hipLaunchKernelGGL(doppler_tilew2_kernel, dim3(wgs), dim3(128 * DOPW2_NCOL), lds, st, da, (int)n_cpi);
+    nPartsUsed = tiles;
     break;
   }
   case BLAH2HIP_DOP_TILEM: {

@@ -1023,6 +1023,188 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
 #endif
 }
 
+// Tile variant for 1025 < nD <= 2049 on the TWO-WAVE 4096-point transform (fft_wave2.hpp): the structure of
+// doppler_tilew_kernel one size up.  Four columns per 512-thread workgroup, a pair of waves per column; LDS = the two
+// stage-twiddle factor tables + 4 exchange regions (which are also the columns' staging areas) + the chirp = 158.5 KB,
+// one PERSISTENT workgroup per CU, software-pipelined over its quarter tiles: the kernel spectrum (natural order,
+// 32 KB, shared by every workgroup) is requested from L2 before the forward transform, the next tile's cells after
+// the spectrum product, this tile's row stores drain while the next is filled.  Barriers are workgroup-wide (the four
+// columns advance together), two per transform + four around the transposes.
+// Replaces doppler_tilem_kernel<16> (four-wave columns on the workgroup transform, one tile per workgroup, nothing
+// overlapped: 9 % of the HBM peak at cfg 5, and 1.89 x the algorithmic traffic -- its four quarter-tile workgroups of
+// a 128-byte line ran on four different XCDs).  Here the tile walk is XCD-aware: the four quarters of a 16-column tile
+// go to four workgroups of ONE XCD that are dispatched together, so a line is fetched from HBM once and the 32-byte
+// row pieces of the final map merge in that XCD's L2.
+constexpr int DOPW2_NCOL = 4;
+constexpr int DOPW2_MAX_ND = 2049;
+constexpr int DOPW2_RS = Wave2Fft::X_ELEMS + 2; // region stride: the transposing accesses of phases 1 and 4 spread over the banks
+constexpr int DOPW2_CHIRP_ELEMS = 17 * 128;     // rows T + 128*k, k < 17
+constexpr int DOPW2_LDS_ELEMS = Wave2Fft::TW_ELEMS + DOPW2_NCOL * DOPW2_RS + DOPW2_CHIRP_ELEMS;
+__global__ __launch_bounds__(128 * DOPW2_NCOL, 2) void doppler_tilew2_kernel(DopplerArgs a, int nCpi)
+{
+  using W = Wave2Fft;
+  constexpr int NCOL = DOPW2_NCOL, NT = 128 * NCOL;
+  constexpr int NR = 17;  // rows T + 128*k, k < 17, cover nD <= 2049 + 126
+  constexpr int NRP = 9;  // tile cell PAIRS (two neighbouring columns, 16 bytes) per thread: nD * 2 / 512 <= 8.01
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double wsum[2 * NCOL];
+  __shared__ float wmax[2 * NCOL];
+  cf *table = reinterpret_cast<cf *>(smem);
+  cf *regions = table + W::TW_ELEMS;
+  const int tid = threadIdx.x;
+  const int col = __builtin_amdgcn_readfirstlane(tid >> 7);      // column of the quarter tile = wave pair
+  const int wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 1); // wave inside the pair
+  const int lane = tid & 63;
+  const int T = W::logical(wave, lane);
+  const int nD = a.nD;
+  const int tilesPerCpi = (a.nDelay + NCOL - 1) / NCOL;
+  const int groupsPerCpi = (a.nDelay + 15) / 16; // 16-column tiles = groups of four quarter tiles
+  const int nGroupsAll = groupsPerCpi * nCpi;
+  cf *region = regions + col * DOPW2_RS;
+
+  cf *chirpL = regions + NCOL * DOPW2_RS;
+  for (int i = tid; i < DOPW2_CHIRP_ELEMS; i += NT) chirpL[i] = a.chirp[min(i, nD - 1)];
+  W::fill_table(tid, NT, a.tw, table);
+  W::Tw tw;
+  W::load_twiddles(wave, lane, a.tw, table, tw);
+
+  // XCD-aware walk: workgroup b = xcd + 8 (4 j + r) takes quarter r of group (j 8 + xcd), then every (gridDim/32)*8-th group
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int quarter = slot & 3;
+  const int gStep = (gridDim.x >> 5) * 8;
+  int grp = (slot >> 2) * 8 + xcd;
+
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 nt[NRP];
+  const int pairs = nD * (NCOL / 2);
+  auto tile_of = [&](int g, int &cpi, int &sub) {
+    cpi = g / groupsPerCpi;
+    sub = (g - cpi * groupsPerCpi) * 4 + quarter; // quarter-tile index inside the CPI (may lie beyond the last column)
+  };
+  auto tile_load = [&](int g) {
+    int cpi, sub;
+    tile_of(g, cpi, sub);
+    const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, min(sub, tilesPerCpi - 1) * NCOL);
+    const int tl = relaunder(tid);
+#pragma unroll
+    for (int j = 0; j < NRP; j++) {
+      const int idx = tl + NT * j;
+      const int pc = idx & (NCOL / 2 - 1), row = idx >> 1;
+      nt[j] = *reinterpret_cast<const f4 *>(Rt + (idx < pairs ? row * 16 + 2 * pc : 0));
+    }
+  };
+  if (grp < nGroupsAll) tile_load(grp);
+  for (; grp < nGroupsAll; grp += gStep) {
+    int cpi, sub;
+    tile_of(grp, cpi, sub);
+    const bool live = sub < tilesPerCpi; // the last group of a CPI may have fewer than four quarters
+    const int col0 = sub * NCOL;
+    // phase 1: the tile, transposed into the per-column regions
+    {
+      const int tl = relaunder(tid);
+#pragma unroll
+      for (int j = 0; j < NRP; j++) {
+        const int idx = tl + NT * j;
+        const int pc = idx & (NCOL / 2 - 1), row = idx >> 1;
+        if (idx < pairs) {
+          regions[(2 * pc) * DOPW2_RS + row] = cmake(nt[j].x, nt[j].y);
+          regions[(2 * pc + 1) * DOPW2_RS + row] = cmake(nt[j].z, nt[j].w);
+        }
+      }
+    }
+    __syncthreads();
+
+    // phase 2: this pair's column -> registers (DC removal + chirp), the kernel spectrum requested, forward transform,
+    // x spectrum, the next tile requested, inverse transform
+    cf v[32];
+    const cf r0 = region[0];
+    {
+      const int t2 = relaunder(T);
+#pragma unroll
+      for (int k = 0; k < NR; k++) {
+        const int i = t2 + 128 * k;
+        const cf rv = region[min(i, nD - 1)];
+        const cf pch = cmul(csub(rv, r0), chirpL[i]);
+        v[k] = cmake(i < nD ? pch.x : 0.f, i < nD ? pch.y : 0.f);
+      }
+    }
+#pragma unroll
+    for (int k = NR; k < 32; k++) v[k] = cmake(0.f, 0.f);
+    cf bf[32];
+    {
+      const cf *bfp = a.bfn + relaunder(T);
+#pragma unroll
+      for (int e = 0; e < 32; e++) bf[e] = bfp[128 * e];
+    }
+    __syncthreads(); // both waves of a pair have taken their rows out of the region: it becomes the exchange buffer
+    W::transform<-1>(wave, lane, v, tw, region);
+#pragma unroll
+    for (int e = 0; e < 32; e++) v[e] = cmul(v[e], bf[e]);
+    if (grp + gStep < nGroupsAll) tile_load(grp + gStep);
+    W::transform<+1>(wave, lane, v, tw, region);
+
+    // phase 3: rotate rows by nD/2+1 and park the column back in its region
+    {
+      const int t3 = relaunder(T);
+#pragma unroll
+      for (int c = 0; c < NR; c++) {
+        const int k = t3 + 128 * c;
+        cf d = cmul(v[c], chirpL[k]);
+        if (c == 0 && t3 == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
+        int o = k - (nD / 2 + 1);
+        if (o < 0) o += nD;
+        region[k < nD ? o : DOPW2_RS - 1] = d; // rows beyond nD go to a spare slot: no branch per row
+      }
+    }
+    __syncthreads();
+
+    // phase 4: coalesced row-segment stores + Map::set_metrics partials
+    double lsum = 0.0;
+    float lmax = 0.f;
+    cf *mapb = a.map + (size_t)cpi * nD * a.nDelay + col0;
+    const int ncol = live ? min(NCOL, a.nDelay - col0) : 0;
+    {
+      const int tl4 = relaunder(tid);
+      const bool wide = (a.nDelay & 1) == 0; // 16-byte row pieces need the rows to start 16-byte aligned
+#pragma unroll
+      for (int j = 0; j < NRP; j++) {
+        const int idx = tl4 + NT * j;
+        const int pc = idx & (NCOL / 2 - 1), o = idx >> 1;
+        const bool ok0 = idx < pairs && 2 * pc < ncol, ok1 = idx < pairs && 2 * pc + 1 < ncol;
+        const cf d0 = regions[(2 * pc) * DOPW2_RS + min(o, nD - 1)];
+        const cf d1 = regions[(2 * pc + 1) * DOPW2_RS + min(o, nD - 1)];
+        cf *dst = mapb + (size_t)o * a.nDelay + 2 * pc;
+        if (wide && ok1) {
+          f4 q = {d0.x, d0.y, d1.x, d1.y};
+          *reinterpret_cast<f4 *>(dst) = q;
+        } else {
+          if (ok0) dst[0] = d0;
+          if (ok1) dst[1] = d1;
+        }
+        const float db0 = db_of(d0), db1 = db_of(d1);
+        lsum += (ok0 ? (double)db0 : 0.0) + (ok1 ? (double)db1 : 0.0);
+        lmax = ok0 ? fmaxf(lmax, db0) : lmax;
+        lmax = ok1 ? fmaxf(lmax, db1) : lmax;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lsum += __shfl_xor(lsum, off);
+      lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    }
+    if (lane == 0) { const int wl = relaunder(tid) >> 6; wsum[wl] = lsum; wmax[wl] = lmax; }
+    __syncthreads(); // also: every thread has taken its rows out of the regions
+    if (tid == 0 && live) {
+      double sacc = 0.0;
+      float m = 0.f; // Map.cpp:193: the running max starts at 0
+      for (int i = 0; i < 2 * NCOL; i++) { sacc += wsum[i]; m = fmaxf(m, wmax[i]); }
+      const size_t part = (size_t)cpi * tilesPerCpi + sub;
+      a.partSum[part] = sacc;
+      a.partMax[part] = m;
+    }
+  }
+}
+
 // Tile variant for multi-wave columns: 513 < nD <= 1025 (M = 2048, R3 = 8: a column is a
 // 128-thread, two-wave transform, 8 columns per 1024-thread workgroup) and 1025 < nD <= 2049
 // (M = 4096, R3 = 16: 256 threads per column, 4 columns per workgroup).  Same phases as

@@ -149,6 +149,7 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 #define BLAH2HIP_DOP_COLUMN 4  /* nD <= 2049: one column per workgroup (small launches) */
 #define BLAH2HIP_DOP_DIRECT 5  /* any nD: direct DFT */
 #define BLAH2HIP_DOP_TILEW 6   /* 513 < nD <= 1025: one-wave 2048-point columns, 8 per workgroup */
+#define BLAH2HIP_DOP_TILEW2 7  /* 1025 < nD <= 2049: two-wave 4096-point columns, 4 per workgroup */
 #define BLAH2HIP_RANGE_E16 1   /* 16 points per thread, one workgroup per pulse (F = 4096; F = 2048 on request) */
 #define BLAH2HIP_RANGE_E8 2    /* 8 points per thread, last stage across lanes (F = 1024) */
 #define BLAH2HIP_RANGE_WAVE 3  /* one wave per pulse, 32 points per lane, no barriers (F = 2048) */

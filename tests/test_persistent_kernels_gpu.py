@@ -86,3 +86,20 @@ def test_cfg3_geometry_x2_natural_grid(b2):
                     targets=((37, -63.0, 0.05), (1500, 300.0, 0.05)), cell_tol=2e-4)
     grid, tiles = amb.info(_lib.INFO_DOPPLER_GRID), amb.info(_lib.INFO_DOPPLER_TILES)
     assert tiles == 512 and tiles > grid
+
+
+@pytest.mark.parametrize("fmax,n,nD", [(513, 2_054_000, 1027), (800, 3_202_000, 1601), (1024, 4_098_000, 2049)])
+@pytest.mark.parametrize("ndelay", [300, 304])
+def test_two_wave_tile_kernel(b2, fmax, n, nD, ndelay):
+    """doppler_tilew2_kernel (1025 < nD <= 2049: a pair of waves per column on the two-wave 4096-point transform, four
+    columns per persistent workgroup, XCD-aware walk over the quarter tiles), forced, on 32 workgroups: three CPIs x 19
+    sixteen-column groups x 4 quarters = 228 quarter tiles, seven iterations per workgroup, ragged last group (300 = 18
+    x 16 + 12: its fourth quarter does not exist) and both store widths (odd / even delay counts)."""
+    from blah2_amd import _lib
+    geom = (-7, ndelay - 8, -fmax, fmax, n, n)
+    amb = run_batch(b2, geom, 3, "tilew2", seeds=(95 + nD, 96 + nD, 97 + nD), targets=((37, -13.0, 0.05),), cell_tol=2e-4,
+                    doppler_grid=32)
+    assert amb.get_n_doppler_bins() == nD and amb.get_n_delay_bins() == ndelay
+    assert amb.info(_lib.INFO_DOPPLER_FFT_LEN) == 4096
+    grid, tiles = _assert_steady(amb)
+    assert grid == 32 and tiles == 3 * 19 * 4

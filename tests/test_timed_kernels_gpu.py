@@ -188,7 +188,7 @@ def _expected_doppler(b2, geom):
         return "tile8" if 2 * -(-d.n_delay_bins // 8) >= 128 else "column"
     if d.n_doppler_bins <= 1025:
         return "tilew" if 2 * -(-d.n_delay_bins // 8) >= 128 else "column"
-    return "tilem" if 2 * -(-d.n_delay_bins // 4) >= 128 else "column"
+    return "tilew2" if 2 * -(-d.n_delay_bins // 4) >= 128 else "column"
 
 
 @pytest.mark.parametrize("geom,fft_len", [(CFG2, 2048), ((-24, 2023, -64, 64, 1_260_000, 1_260_000), 4096),
