@@ -311,7 +311,8 @@ template <class In> int launch_rangew_t(blah2hip_amb_s *h, const RangeArgs &a, I
 {
   const size_t lds = (size_t)(WaveFft::TW_ELEMS + RANGEW_WAVES * WaveFft::X_ELEMS) * sizeof(cf);
   const bool shortw = a.plan.segLen <= 24 * 64 && a.plan.segLen + a.plan.nDelay - 1 <= 28 * 64 && a.plan.nDelay <= 7 * 64;
-  auto kern = shortw ? rangew_kernel<In, true> : rangew_kernel<In, false>;
+  const bool out7 = a.plan.nDelay <= 7 * 64;
+  auto kern = shortw ? rangew_kernel<In, true, true> : (out7 ? rangew_kernel<In, false, true> : rangew_kernel<In, false, false>);
   LDSCFG(kern, lds);
   const int grid = std::min<int>((a.nPulses + RANGEW_WAVES - 1) / RANGEW_WAVES, range_grid_cap(h, lds, RANGEW_WAVES, 4 * RANGEW_WAVES_PER_SIMD));
 #ifdef RANGEW_TRACE

@@ -303,9 +303,10 @@ __device__ __forceinline__ void store_lags_w(cf *out, const RangePlan &p, int cp
 // SHORTW: windows short enough for the pruned form, segLen <= 24*64 and segLen + nDelay - 1 <= 28*64 (cfg 2:
 // x' has 1300 and y' needs 1709 of 2048 samples): x' = 0 from 24*64 on, y' is not needed from 28*64 on --
 // 12 of 64 loads are not issued and the first 32-point step of both transforms skips the zero inputs.
-// A template parameter, not a branch: both forms in one loop body spill.  The same instantiation (short
-// windows imply nDelay <= 7*64) computes only the 7 wanted outputs per lane of the inverse transform.
-template <class In, bool SHORTW>
+// A template parameter, not a branch: both forms in one loop body spill.
+// OUT7: nDelay <= 7*64 -- the inverse transform computes only the 7 wanted outputs per lane (always with SHORTW, whose
+// window bound implies it; also for long segments with few lags, cfg 5: segLen 1627, nDelay 411).
+template <class In, bool SHORTW, bool OUT7 = SHORTW>
 __global__ __launch_bounds__(64 * RANGEW_WAVES, RANGEW_WAVES_PER_SIMD) void rangew_kernel(RangeArgs a, In in)
 {
   using W = WaveFft;
@@ -352,12 +353,12 @@ __global__ __launch_bounds__(64 * RANGEW_WAVES, RANGEW_WAVES_PER_SIMD) void rang
       for (int e = 0; e < 32; e++) acc[e] = cmacc(acc[e], yv[e], v[e]);
     }
     RW_T(0)
-    W::template transform<+1, 32, SHORTW>(t, acc, w, X);
+    W::template transform<+1, 32, OUT7>(t, acc, w, X);
 #ifdef RANGEW_TRACE
     asm volatile("" : "+v"(acc[0].x));
 #endif
     RW_T(4)
-    store_lags_w<SHORTW ? 7 : 32>(a.out, p, cpi, i, t, acc);
+    store_lags_w<OUT7 ? 7 : 32>(a.out, p, cpi, i, t, acc);
     RW_T(5)
   }
 #ifdef RANGEW_TRACE

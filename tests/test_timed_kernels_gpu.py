@@ -249,3 +249,15 @@ def _expected_doppler3(geom):
             return "tile16"
         return "tile8" if 3 * -(-d.n_delay_bins // 8) >= 128 else "column"
     return "tilew" if 3 * -(-d.n_delay_bins // 8) >= 128 else "column"
+
+
+@pytest.mark.parametrize("geom,out7", [((-7, 292, -50, 50, 171_700, 171_700), True), ((-7, 492, -50, 50, 151_500, 151_500), False)])
+def test_one_wave_range_kernel_long_segments(b2, geom, out7):
+    """The unpruned instantiations of rangew_kernel (segLen > 24*64: every load issued): with few lags the inverse still
+    computes only the seven wanted outputs per lane (the configs[4] shape: segLen 1627, 411 lags), with more all 32."""
+    from blah2_amd import _lib
+    amb = run_batch(b2, geom, 2, "auto", seeds=(140, 141), range_kernel=_lib.RANGE_WAVE, fft_len=2048,
+                    expect="column", targets=((37, -13.0, 0.05),))
+    assert amb.dims.fft_len == 2048 and amb.dims.seg_len > 1536
+    assert (amb.get_n_delay_bins() <= 448) == out7
+    assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE
