@@ -453,15 +453,27 @@ def main(argv=None):
     # passes of this same command (tools/summarize_prof.py -> profiles/*_traffic.json)
     traffic, traffic_src = None, None
     import glob
+    prof_names = {"range": ("rangew2_kernel", "rangew_kernel", "range_kernel", "range8_kernel"), "doppler": ("doppler_",),
+                  "metrics": ("metrics_kernel",), "cfar": ("cfar2d_tile_kernel", "cfar2d_kernel", "cfar1d_kernel"),
+                  "sat_rows": ("sat_rows_kernel",), "sat_cols": ("sat_cols_kernel",), "rotate": ("rotate_kernel",),
+                  "clutter_corr": ("clutter_corr_half_kernel", "clutter_corr_kernel"), "clutter_fir": ("clutter_fir_kernel",),
+                  "clutter_solve": ("clutter_solve_kernel",), "clutter_reduce": ("clutter_reduce_kernel",)}
     for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
             tj = json.load(open(pth))
             bc = tj.get("bench_config", {})
             if (bc.get("config"), bc.get("batch"), bc.get("fmt"), bc.get("chain", "amb")) != (a.config, B, a.fmt, a.chain):
                 continue
-            rk = next(k_ for k_ in ("rangew2_kernel", "rangew_kernel", "range_kernel", "range8_kernel") if k_ in tj["kernels"])
-            traffic = tj["kernels"][rk]["hbm_bytes"]
             traffic_src = os.path.relpath(pth, ROOT)
+            # HBM bytes per launch of every kernel of this command that the PMC passes saw (summed over the instantiations
+            # one bench key covers, e.g. a command that ran two Doppler kernels)
+            for e in kernels:
+                hit = [v_ for k_, v_ in tj["kernels"].items() if any(k_.startswith(pre) for pre in prof_names.get(e["kernel"], ()))]
+                if hit:
+                    e["traffic"] = sum(h_["hbm_bytes"] for h_ in hit)
+                    if "algorithmic_bytes" in e:
+                        e["traffic_over_algorithmic"] = e["traffic"] / e["algorithmic_bytes"]
+            traffic = next((e.get("traffic") for e in kernels if e["kernel"] == "range"), None)
             break
         except Exception:
             continue

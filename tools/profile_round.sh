@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun) from the repo root:
 #   gpurun --timeout 1500 -- 'bash tools/profile_round.sh'
-# then, back in the container:  python tools/summarize_prof.py r02
+# then, back in the container:  python tools/summarize_prof.py r03 && python tools/collect_bench.py r03
 # For each profiled bench command (tag -> arguments below) leaves under gpurun_out/prof/<tag>/:
 # the rocprofv3 --kernel-trace --stats run and the separate PMC passes (never combined with a
 # trace domain other than --kernel-trace), plus the plain bench logs.
@@ -30,13 +30,15 @@ mkdir -p $OUT/cal
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/cal/fetch -o cal --output-format csv -- $REPO/tools/membench/pmccal > $OUT/cal/fetch.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/cal/write -o cal --output-format csv -- $REPO/tools/membench/pmccal > $OUT/cal/write.log 2>&1
 cd $REPO
-python bench.py > $OUT/bench_r2.log 2>&1
-python bench.py --batch 1 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_r2_b1.log 2>&1
-python bench.py --fmt i16 --no-cpu-baseline > $OUT/bench_r2_i16.log 2>&1
-python bench.py --chain full --batch 64 --no-cpu-baseline > $OUT/bench_r2_full.log 2>&1
-python bench.py --config cfg3 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_r2_cfg3.log 2>&1
-python bench.py --config cfg3 --chain full --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_r2_cfg3_full.log 2>&1
-python bench.py --config cfg3 --chain full --batch 256 --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $OUT/bench_r2_cfg3_full256.log 2>&1
-python bench.py --config cfg5 --fmt f16 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_r2_cfg5.log 2>&1
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_r2_torchrun.log 2>&1
-tail -qn 1 $OUT/bench_r2*.log | cut -c1-200
+rm -f $OUT/bench_r3*.log
+python bench.py > $OUT/bench_r3.log 2>&1
+python bench.py --batch 1 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_r3_b1.log 2>&1
+python bench.py --fmt i16 --no-cpu-baseline > $OUT/bench_r3_i16.log 2>&1
+python bench.py --chain full --batch 64 --no-cpu-baseline > $OUT/bench_r3_full.log 2>&1
+python bench.py --config cfg3 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_r3_cfg3.log 2>&1
+python bench.py --config cfg3 --chain full --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_r3_cfg3_full.log 2>&1
+python bench.py --config cfg5 --fmt f16 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_r3_cfg5.log 2>&1
+python bench.py --config cfg5 --fmt f16 --batch 32 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_r3_cfg5_b32.log 2>&1
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_r3_torchrun.log 2>&1
+python tools/replay_bench.py --out $OUT/replay.json > $OUT/replay_bench.log 2>&1
+tail -qn 1 $OUT/bench_r3*.log | cut -c1-200
