@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 
-KERNELS = ("rangew2_kernel", "rangew_kernel", "range8_kernel", "range_kernel", "doppler_tilew_kernel", "doppler_tilem_kernel", "doppler_tile_kernel", "doppler_fft_kernel",
+KERNELS = ("rangew2_kernel", "rangew_kernel", "range8_kernel", "range_kernel", "doppler_tilew2_kernel", "doppler_tilew_kernel", "doppler_tilem_kernel", "doppler_tile_kernel", "doppler_fft_kernel",
            "doppler_dft_kernel", "metrics_kernel", "cfar1d_kernel", "cfar2d_tile_kernel", "cfar2d_kernel", "sat_rows_kernel", "sat_cols_kernel",
            "rotate_kernel", "clutter_corr_half_kernel", "clutter_corr_kernel", "clutter_fir_kernel", "clutter_solve_kernel", "clutter_reduce_kernel",
            "db_map_kernel", "cal_")
@@ -94,6 +94,9 @@ def summarize(src, tag, prefix):
                     "vgpr", "agpr", "sgpr"])
         for (k, c), v in sorted(agg.items()):
             w.writerow([k, c, len(v), f"{sum(v)/len(v):.6g}", *meta[k]])
+    cfgp = os.path.join(src, "bench_config.json")
+    bench_config = json.load(open(cfgp)) if os.path.exists(cfgp) else None
+    algo = algorithmic_bytes(bench_config) if bench_config else {}
     traffic = {}
     for k in sorted({k for k, _ in agg}):
         fs = agg.get((k, "FETCH_SIZE"))
@@ -102,17 +105,24 @@ def summarize(src, tag, prefix):
             # FETCH_SIZE counts 64 B per request: a whole-line (128 B) request is under-counted by 2, a
             # half-line request (the 8-column Doppler tile reads 64 of every 128 B) is counted exactly
             # (profiles/*_pmc_calibration.json: cal_read8/16 -> 0.5, cal_read_half -> 1.0)
-            factor = 1.0 if any(k.startswith(h) for h in HALF_LINE_READERS) else 2.0
-            fetch = factor * 1024.0 * sum(fs) / len(fs)
+            raw = 1024.0 * sum(fs) / len(fs)
+            factor, why = 2.0, "64 B counted per whole-line request"
+            if any(k.startswith(h) for h in HALF_LINE_READERS):
+                factor, why = 1.0, "row pieces of 64 B or less: requests counted exactly"
+                # ... unless the pieces of a line are read by sibling workgroups of ONE XCD (the XCD-aware tile walks): the
+                # L2 then asks for whole lines.  Decided by the data: a Doppler kernel reads half of its algorithmic bytes,
+                # and a raw figure far below that can only be the whole-line under-count.
+                if k.startswith("doppler") and algo.get("doppler") and raw < 0.75 * (algo["doppler"] / 2):
+                    factor, why = 2.0, "row pieces merged in one XCD's L2: whole-line requests, 64 B counted per request"
+            fetch = factor * raw
             write = 1024.0 * sum(ws) / len(ws)
             traffic[k] = {"fetch_bytes": fetch, "write_bytes": write, "hbm_bytes": fetch + write, "fetch_factor": factor,
-                          "note": f"FETCH_SIZE KiB x{factor:g} (64 B counted per request) + WRITE_SIZE KiB (32-byte sectors)"}
+                          "note": f"FETCH_SIZE KiB x{factor:g} ({why}) + WRITE_SIZE KiB (32-byte sectors)"}
     cfgp = os.path.join(src, "bench_config.json")
     out = {"round": tag, "kernels": traffic}
     bad = []
-    if os.path.exists(cfgp):
-        out["bench_config"] = json.load(open(cfgp))
-        algo = algorithmic_bytes(out["bench_config"])
+    if bench_config:
+        out["bench_config"] = bench_config
         names = {"rangew2_kernel": "range", "rangew_kernel": "range", "range_kernel": "range", "range8_kernel": "range", "doppler": "doppler",
                  "clutter_corr_half_kernel": "clutter_corr", "clutter_corr_kernel": "clutter_corr",
                  "clutter_fir_kernel": "clutter_fir", "cfar2d": "cfar", "cfar1d_kernel": "cfar"}
