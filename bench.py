@@ -336,8 +336,8 @@ def main(argv=None):
     wh = None
     CAP = 65536
     if a.chain == "full":
-        if a.fmt != "c32":
-            raise SystemExit("--chain full needs --fmt c32")
+        if a.fmt not in ("c32", "i16"):
+            raise SystemExit("--chain full needs --fmt c32 or i16")
         wh = blah2_amd.WienerHopf(dmin, dmax, n, device=local, max_batch=B)  # config.yml uses the same lag window
         yfilt = torch.empty((B, n), dtype=torch.complex64, device=dev)
         okflag = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -355,7 +355,11 @@ def main(argv=None):
 
     def step(i):
         r = i % ring
-        if wh is not None:
+        if wh is not None and a.fmt == "i16":  # the replay format: the filter and the range kernel read the .rspduo words
+            wh.process_dev_fmt(blah2_amd.FMT_I16, iqs[r].data_ptr(), None, B, n, yfilt.data_ptr(), n, okflag.data_ptr(), st)
+            amb.process_dev(blah2_amd.FMT_I16X_C32Y, iqs[r].data_ptr(), yfilt.data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
+            det.process_dev(amb, B, hits.data_ptr(), CAP, hitcnt.data_ptr(), out.data_ptr(), met.data_ptr(), st)
+        elif wh is not None:
             wh.process_dev(xs[r].data_ptr(), ys[r].data_ptr(), B, n, yfilt.data_ptr(), okflag.data_ptr(), st)
             amb.process_dev(blah2_amd.FMT_C32, xs[r].data_ptr(), yfilt.data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
             det.process_dev(amb, B, hits.data_ptr(), CAP, hitcnt.data_ptr(), out.data_ptr(), met.data_ptr(), st)
