@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Copies the bench JSON lines of a profiling round (gpurun_out/bench_rN*.log, the last line of each) and the replay
-figures into profiles/ as <round>_bench*.json / <round>_replay.json:   python tools/collect_bench.py r03"""
+figures into profiles/ as <round>_bench*.json / <round>_replay.json:   python tools/collect_bench.py r03
+
+bench.py attaches the PMC traffic of the newest matching profiles/*_traffic.json it finds; on the GPU box that is still
+the PREVIOUS round's file (this round's counters are condensed afterwards, here).  The traffic fields of the copied
+lines are therefore re-attached from this round's <round>_<tag>_traffic.json of the same command (same rule as bench.py)."""
 import glob
 import json
 import os
@@ -18,6 +22,30 @@ for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"bench_r{n}*.log"
     except Exception as e:
         print("skipped", path, e)
         continue
+    cfgk = (j["config"].get("workload", "").split(":")[0], j["config"]["batch_cpis_per_step"], j["config"]["fmt"], j["config"]["chain"])
+    for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}_*_traffic.json"))):
+        tj = json.load(open(tp))
+        bc = tj.get("bench_config", {})
+        names = {"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2]", "cfg5": "BASELINE configs[4]"}
+        if (names.get(bc.get("config")), bc.get("batch"), bc.get("fmt"), bc.get("chain", "amb")) != cfgk:
+            continue
+        sys.path.insert(0, ROOT)
+        prof_names = {"range": ("rangew2_kernel", "rangew_kernel", "range_kernel", "range8_kernel"), "doppler": ("doppler_",),
+                      "metrics": ("metrics_kernel",), "cfar": ("cfar2d_tile_kernel", "cfar2d_kernel", "cfar1d_kernel"),
+                      "sat_rows": ("sat_rows_kernel",), "sat_cols": ("sat_cols_kernel",), "rotate": ("rotate_kernel",),
+                      "clutter_corr": ("clutter_corr_half_kernel", "clutter_corr_kernel"), "clutter_fir": ("clutter_fir_kernel",),
+                      "clutter_solve": ("clutter_solve_kernel",), "clutter_reduce": ("clutter_reduce_kernel",)}
+        for e in j["roofline"]["kernels"]:
+            e.pop("traffic", None)
+            e.pop("traffic_over_algorithmic", None)
+            hit = [v for k, v in tj["kernels"].items() if any(k.startswith(pre) for pre in prof_names.get(e["kernel"], ()))]
+            if hit:
+                e["traffic"] = sum(h["hbm_bytes"] for h in hit)
+                if "algorithmic_bytes" in e:
+                    e["traffic_over_algorithmic"] = e["traffic"] / e["algorithmic_bytes"]
+        j["roofline"]["traffic"] = next((e.get("traffic") for e in j["roofline"]["kernels"] if e["kernel"] == "range"), None)
+        j["roofline"]["traffic_source"] = os.path.relpath(tp, ROOT) + " (re-attached by tools/collect_bench.py)"
+        break
     out = os.path.join(ROOT, "profiles", f"{tag}_bench{name}.json")
     json.dump(j, open(out, "w"), indent=1)
     print(out, round(j["value"], 1), j["unit"], "parity", (j.get("parity") or {}).get("pass"))
