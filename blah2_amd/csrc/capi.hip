@@ -66,7 +66,10 @@ struct blah2hip_amb_s {
   int32_t delayMin = 0, delayMax = 0, dopplerMin = 0, dopplerMax = 0;
   uint32_t fs = 0;
   int r3 = 8;
-  RangePlan plan{};
+  RangePlan plan{};                 // segmentation (of the longest chunk) + the first chunk's lag window
+  struct LagChunk { int32_t lag0, count, col0; }; // linear lags lag0 .. lag0 + count - 1 -> map columns col0 ..
+  std::vector<LagChunk> chunks;     // the delay axis as runs of consecutive LINEAR lags (one chunk in the usual case)
+  int32_t maxChunk = 0;
   std::vector<int32_t> delayAxis;
   std::vector<double> dopplerAxis;
   hipStream_t stream = nullptr;
@@ -158,10 +161,39 @@ void derive_dims(blah2hip_amb_s *h, uint32_t n, bool roundHamming, uint32_t nDop
   d.n_used = d.n_corr * d.n_doppler_bins;
 }
 
+// The delay axis as runs of consecutive linear lags.  Ambiguity.cpp:132-146 gathers delay d from index d mod nfft of an
+// nfft-point CIRCULAR correlation of nCorr-sample pulses: c[L] = R[L] for L < nCorr, R[L - nfft] for L > nfft - nCorr (the
+// opposite-sign lag aliasing in; nfft >= 2 nCorr - 1, so never both), 0 in between.  This engine computes linear
+// correlations of a lag window, so every delay maps to ONE linear lag l(d); l(d) is consecutive in d except where the
+// circular index crosses nfft - nCorr, and windows inside |d| <= nfft - nCorr (every practical one) are a single run
+// with l(d) = d.  Runs longer than `cap` lags are cut into chunks (multiples of 16 lags, so that the chunks of a run
+// keep whole 128-byte runs of the range map): that is how more than 4081 delay bins run on the 4096-point transform.
+void lag_chunks(blah2hip_amb_s *h, int cap)
+{
+  const int64_t nfft = h->dims.nfft, nCorr = h->dims.n_corr;
+  h->chunks.clear();
+  auto lin = [&](int64_t d) {
+    int64_t L = d % nfft;
+    if (L < 0) L += nfft;
+    return (L > nfft - nCorr) ? L - nfft : L;
+  };
+  const int32_t nDelay = (int32_t)h->dims.n_delay_bins;
+  int32_t col = 0;
+  while (col < nDelay) {
+    const int64_t l0 = lin((int64_t)h->delayMin + col);
+    int32_t len = 1;
+    while (col + len < nDelay && lin((int64_t)h->delayMin + col + len) == l0 + len) len++;
+    for (int32_t o = 0; o < len; o += cap) h->chunks.push_back({(int32_t)(l0 + o), std::min<int32_t>(cap, len - o), col + o});
+    col += len;
+  }
+  h->maxChunk = 0;
+  for (const auto &c : h->chunks) h->maxChunk = std::max(h->maxChunk, c.count);
+}
+
 // pick F = 256*R3 and the segmentation minimising (2*nSeg+1) * F*log2(F)
 bool choose_plan(blah2hip_amb_s *h)
 {
-  const int nCorr = h->dims.n_corr, nDelay = h->dims.n_delay_bins;
+  const int nCorr = h->dims.n_corr, nDelay = h->maxChunk; // the longest chunk decides; shorter ones reuse its segmentation
   const int forced = h->fftLenForce;
   double best = 1e300;
   bool found = false;
@@ -187,8 +219,10 @@ bool choose_plan(blah2hip_amb_s *h)
   if (!found) return false;
   h->plan.nCorr = nCorr;
   h->plan.nDoppler = h->dims.n_doppler_bins;
-  h->plan.nDelay = nDelay;
-  h->plan.delayMin = h->delayMin;
+  h->plan.nDelay = h->chunks[0].count;
+  h->plan.delayMin = h->chunks[0].lag0;
+  h->plan.colOff = h->chunks[0].col0;
+  h->plan.nTilesOut = (int32_t)((h->dims.n_delay_bins + 15) / 16);
   h->dims.fft_len = 256 * h->r3;
   h->dims.n_seg = h->plan.nSeg;
   h->dims.seg_len = h->plan.segLen;
@@ -606,18 +640,14 @@ int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler
   derive_dims(h, n, round_hamming != 0, n_doppler_bins);
   h->dims.max_batch = max_batch;
   if (h->dims.n_corr == 0) return fail(BLAH2HIP_ERR_INVALID, "nCorr == 0");
-  {
-    // Ambiguity.cpp:132-146 gathers lag d from index d (d >= 0) or nfft + d (d < 0) of an nfft-point
-    // CIRCULAR correlation of nCorr-sample pulses: lags beyond nfft - nCorr alias onto the
-    // opposite-sign lags.  This engine computes the linear correlation; refuse what would differ.
-    const int64_t lim = (int64_t)h->dims.nfft - (int64_t)h->dims.n_corr;
-    const int64_t lagMax = std::max<int64_t>(std::llabs((long long)delay_min), std::llabs((long long)delay_max));
-    if (lagMax > lim)
-      return fail(BLAH2HIP_ERR_UNSUPPORTED, "lag window reaches the lags the reference's circular correlation aliases "
-                                             "(max |delay| > nfft - nCorr)");
-  }
+  if ((int64_t)std::max(std::llabs((long long)delay_min), std::llabs((long long)delay_max)) >= (int64_t)h->dims.nfft)
+    return fail(BLAH2HIP_ERR_UNSUPPORTED, "|delay| >= nfft: the reference's lag gather (Ambiguity.cpp:132-146) reads outside its buffer there");
+  // one chunk when the window fits a transform; windows of more than 4081 lags in chunks of 2048 (F = 4096: 2049 new
+  // samples per segment), each re-reading the pulse
+  lag_chunks(h, 4081);
+  if (h->chunks.size() > 1 || h->maxChunk > 4081) lag_chunks(h, 2048);
   if (!choose_plan(h)) {
-    return fail(BLAH2HIP_ERR_UNSUPPORTED, "nDelayBins too large for the on-chip transform lengths (<= 4096)");
+    return fail(BLAH2HIP_ERR_UNSUPPORTED, "no on-chip transform length fits the lag window (forced length too short?)");
   }
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -837,24 +867,30 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     ra.cpiStride = (int64_t)plane;
     InC32 in2{xo, yo};
     if ((rc = tic(h, BLAH2HIP_K_RANGE, st))) return rc;
-    if ((rc = launch_range(h, ra, in2, st))) return rc;
+    for (const auto &ck : h->chunks) {
+      ra.plan.delayMin = ck.lag0; ra.plan.nDelay = ck.count; ra.plan.colOff = ck.col0;
+      if ((rc = launch_range(h, ra, in2, st))) return rc;
+    }
     if ((rc = toc(h, BLAH2HIP_K_RANGE, st))) return rc;
   } else {
     if ((rc = tic(h, BLAH2HIP_K_RANGE, st))) return rc;
-    if (fmt == BLAH2HIP_FMT_C32) {
-      InC32 in{(const cf *)d_x, (const cf *)d_y};
-      rc = launch_range(h, ra, in, st);
-    } else if (fmt == BLAH2HIP_FMT_F16) {
-      InF16 in{(const _Float16 *)d_x, (const _Float16 *)d_y};
-      rc = launch_range(h, ra, in, st);
-    } else if (fmt == BLAH2HIP_FMT_I16X_C32Y) {
-      InI16C32 in{(const int16_t *)d_x, (const cf *)d_y};
-      rc = launch_range(h, ra, in, st);
-    } else {
-      InI16 in{(const int16_t *)d_x};
-      rc = launch_range(h, ra, in, st);
+    for (const auto &ck : h->chunks) { // one launch in the usual case
+      ra.plan.delayMin = ck.lag0; ra.plan.nDelay = ck.count; ra.plan.colOff = ck.col0;
+      if (fmt == BLAH2HIP_FMT_C32) {
+        InC32 in{(const cf *)d_x, (const cf *)d_y};
+        rc = launch_range(h, ra, in, st);
+      } else if (fmt == BLAH2HIP_FMT_F16) {
+        InF16 in{(const _Float16 *)d_x, (const _Float16 *)d_y};
+        rc = launch_range(h, ra, in, st);
+      } else if (fmt == BLAH2HIP_FMT_I16X_C32Y) {
+        InI16C32 in{(const int16_t *)d_x, (const cf *)d_y};
+        rc = launch_range(h, ra, in, st);
+      } else {
+        InI16 in{(const int16_t *)d_x};
+        rc = launch_range(h, ra, in, st);
+      }
+      if (rc) return rc;
     }
-    if (rc) return rc;
     if ((rc = toc(h, BLAH2HIP_K_RANGE, st))) return rc;
   }
 

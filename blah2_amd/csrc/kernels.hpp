@@ -273,8 +273,10 @@ __device__ __forceinline__ void bufload_seg_w(const In &in, const RangePlan &p, 
 template <int NC>
 __device__ __forceinline__ void store_lags_w(cf *out, const RangePlan &p, int cpi, int pulse, int t, const cf *v)
 {
-  const int nTiles = (p.nDelay + 15) >> 4;
-  cf *o = out + (((int64_t)cpi * nTiles + (t >> 4)) * p.nDoppler + pulse) * 16 + (t & 15);
+  // column j + colOff of the map; colOff is a multiple of 16 except for the (rare) chunks behind an aliasing boundary,
+  // where the lane's position inside its tile shifts: those go through the general index
+  const int jt = t + (p.colOff & 15);
+  cf *o = out + (((int64_t)cpi * p.nTilesOut + (p.colOff >> 4) + (jt >> 4)) * p.nDoppler + pulse) * 16 + (jt & 15);
   const int64_t step = (int64_t)p.nDoppler * 64; // four tiles
   int rem = p.nDelay - t;                        // lane t stores register c iff 64*c < rem
   int nd = p.nDelay;
@@ -406,8 +408,8 @@ __device__ __forceinline__ void bufload_seg_w2(const In &in, const RangePlan &p,
 // lags z[T + 128*c] of one pulse into the tiled range map: thread T owns position T & 15 of tile (T >> 4) + 8*c
 __device__ __forceinline__ void store_lags_w2(cf *out, const RangePlan &p, int cpi, int pulse, int T, const cf *v)
 {
-  const int nTiles = (p.nDelay + 15) >> 4;
-  cf *o = out + (((int64_t)cpi * nTiles + (T >> 4)) * p.nDoppler + pulse) * 16 + (T & 15);
+  const int jt = T + (p.colOff & 15); // see store_lags_w
+  cf *o = out + (((int64_t)cpi * p.nTilesOut + (p.colOff >> 4) + (jt >> 4)) * p.nDoppler + pulse) * 16 + (jt & 15);
   const int64_t step = (int64_t)p.nDoppler * 128; // eight tiles
   int rem = p.nDelay - T;                         // thread T stores register c iff 128*c < rem
   int nd = p.nDelay;

@@ -37,6 +37,12 @@ struct RangePlan {
   int32_t nSeg;      // segments per pulse
   int32_t segLen;    // samples of x per segment
   float scale;       // 1/F (the reference divides by nfft before its backward FFT, :126)
+  // The lag window of one launch is a CHUNK of the map's delay axis: lags delayMin .. delayMin + nDelay - 1 land in
+  // map columns colOff .. colOff + nDelay - 1 of a range map that is nTilesOut sixteen-column tiles wide.  One chunk with
+  // colOff = 0 is the usual case; more than 4081 delay bins, or a window that reaches the lags the reference's nfft-point
+  // circular correlation aliases (Ambiguity.cpp:132-146), run as several (capi.hip: lag_chunks).
+  int32_t colOff;
+  int32_t nTilesOut;
 };
 
 // complex fp32 planes: x = reference channel, y = surveillance channel
@@ -139,12 +145,11 @@ B2_HD int64_t rmap_index(int nDoppler, int nTiles, int cpi, int pulse, int lag);
 template <int T, int E>
 B2_HD void store_lags_g(cf *out, const RangePlan &p, int cpi, int pulse, int t, const cf *v)
 {
-  const int nTiles = (p.nDelay + 15) >> 4;
 #pragma unroll
   for (int c = 0; c < E; c++) {
     const int j = t + T * c;
     if (j < p.nDelay)
-      out[rmap_index(p.nDoppler, nTiles, cpi, pulse, j)] = cmake(v[c].x * p.scale, v[c].y * p.scale);
+      out[rmap_index(p.nDoppler, p.nTilesOut, cpi, pulse, j + p.colOff)] = cmake(v[c].x * p.scale, v[c].y * p.scale);
   }
 }
 
@@ -161,12 +166,11 @@ template <int R3>
 B2_HD void store_lags(cf *out, const RangePlan &p, int cpi, int pulse, int t, const cf *v)
 {
   constexpr int T = 16 * R3;
-  const int nTiles = (p.nDelay + 15) >> 4;
 #pragma unroll
   for (int c = 0; c < 16; c++) {
     const int j = t + T * c;
     if (j < p.nDelay)
-      out[rmap_index(p.nDoppler, nTiles, cpi, pulse, j)] = cmake(v[c].x * p.scale, v[c].y * p.scale);
+      out[rmap_index(p.nDoppler, p.nTilesOut, cpi, pulse, j + p.colOff)] = cmake(v[c].x * p.scale, v[c].y * p.scale);
   }
 }
 

@@ -112,13 +112,12 @@ int blah2hip_amb_create(int32_t delay_min, int32_t delay_max, int32_t doppler_mi
 int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler_min, int32_t doppler_max,
                            uint32_t fs, uint32_t n, int round_hamming, uint32_t n_doppler_bins,
                            int device, uint32_t max_batch, blah2hip_amb_t *out);
-/* Geometry limits of the on-chip transforms (BLAH2HIP_ERR_UNSUPPORTED beyond them; the
- * reference's own limit is the uint16 narrowing of Ambiguity.h:80-89):
- *   - n_delay_bins <= 4081 (range transform F <= 4096 with at least 16 samples per segment);
- *   - the lag window must not reach the lags the reference's nfft-point CIRCULAR correlation
- *     aliases: max(|delay_min|, |delay_max|) <= nfft - n_corr (Ambiguity.cpp:132-146 reads
- *     index nfft + d for d < 0; beyond that bound the reference returns the opposite-sign
- *     lag, this engine would return 0);
+/* Geometry (the reference's own limit is the uint16 narrowing of Ambiguity.h:80-89, reproduced):
+ *   - any number of delay bins: a window of more than 4081 lags runs as chunks of 2048 on the 4096-point range
+ *     transform, each chunk re-reading the pulses (correct, slower per bin);
+ *   - delays beyond nfft - n_corr read, in the reference's nfft-point CIRCULAR correlation (Ambiguity.cpp:132-146), the
+ *     opposite-sign lag d -+ nfft: reproduced (every delay maps to one linear lag; runs of consecutive lags are chunks);
+ *     |delay| >= nfft, where the reference indexes outside its buffer, is BLAH2HIP_ERR_UNSUPPORTED;
  *   - Doppler lengths above 2049 run on the direct-DFT kernel (correct, slow). */
 int blah2hip_amb_destroy(blah2hip_amb_t h);
 int blah2hip_amb_get_dims(blah2hip_amb_t h, blah2hip_amb_dims_t *dims);

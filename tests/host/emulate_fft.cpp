@@ -325,6 +325,7 @@ int test_range(int nCorr, int nD, int dMin, int dMax, int nSeg, int segLen, unsi
   RangePlan p;
   p.nCorr = nCorr; p.nDoppler = nD; p.nDelay = dMax - dMin + 1; p.delayMin = dMin;
   p.nSeg = nSeg; p.segLen = segLen; p.scale = 1.0f / F;
+  p.colOff = 0; p.nTilesOut = (p.nDelay + 15) >> 4;
   if (segLen + p.nDelay - 1 > F || nSeg * segLen < nCorr) { std::printf("bad plan\n"); return 2; }
   const long n = (long)nCorr * nD;
   std::mt19937 gen(seed);

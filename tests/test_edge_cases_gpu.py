@@ -62,20 +62,57 @@ def test_doppler_transform_lengths(b2):
 
 
 def test_unsupported_geometries_fail_loudly(b2):
-    # lag window wider than the largest on-chip transform
-    with pytest.raises(b2.Blah2HipError) as e:
-        b2.Ambiguity(-100, 4200, -10, 10, 1_000_000, 1_000_000, True)
-    assert e.value.code == -3
     # outside the range where the reference's own lag gather is in bounds
     with pytest.raises(b2.Blah2HipError):
         b2.Ambiguity(5, 100, -10, 10, 1_000_000, 1_000_000, True)
     with pytest.raises(b2.Blah2HipError):
         b2.Ambiguity(-10, 100, 10, -10, 1_000_000, 1_000_000, True)
-    # short pulses: 2049 pulses of 488 samples, nfft = 1000.  Lags beyond nfft - nCorr = 512 alias in the
-    # reference's circular correlation (Ambiguity.cpp:132-146) onto the opposite-sign lags; refused
+    # |delay| >= nfft: Ambiguity.cpp:132-146 would index outside its nfft-point buffer (2049 pulses of 488 samples, nfft = 1000)
     with pytest.raises(b2.Blah2HipError) as e:
-        b2.Ambiguity(-10, 600, -2048, 2048, 2_000_000, 1_000_000, True)
-    assert e.value.code == -3 and "alias" in str(e.value)
+        b2.Ambiguity(-10, 1000, -2048, 2048, 2_000_000, 1_000_000, True)
+    assert e.value.code == -3
+
+
+def test_more_delay_bins_than_one_transform_holds(b2):
+    """4301 delay bins (the reference accepts up to 65535, Ambiguity.h:80-89): the lag window runs as three chunks of at
+    most 2048 lags on the 4096-point transform, each into its own columns of the range map."""
+    amb = run(b2, (-100, 4200, -10, 10, 1_000_000, 1_000_000, True), seed=3)
+    assert amb.get_n_delay_bins() == 4301 and amb.dims.fft_len == 4096
+    # the same through the batched device chain (two CPIs), every Doppler kernel choice left to the planner
+    import torch
+    n, fs = 400_000, 400_000
+    args = (-30, 4400, -4, 4, fs, n)
+    amb = b2.Ambiguity(*args, True, max_batch=2)
+    xs, ys = zip(*(O.synth_iq(n, seed=s_, fs=fs, targets=((4000, 2.0, 0.1), (17, -3.0, 0.05))) for s_ in (1, 2)))
+    dx = torch.from_numpy(np.stack(xs).astype(np.complex64)).cuda()
+    dy = torch.from_numpy(np.stack(ys).astype(np.complex64)).cuda()
+    out = torch.zeros((2, amb.get_n_doppler_bins(), amb.get_n_delay_bins()), dtype=torch.complex64, device="cuda")
+    amb.process_dev(b2.FMT_C32, dx.data_ptr(), dy.data_ptr(), 2, n, out.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    d = O.ambiguity_dims(*args, True)
+    for c in range(2):
+        ref = O.ambiguity_process(d, xs[c], ys[c])
+        assert np.abs(out[c].cpu().numpy() - ref).max() / np.abs(ref).max() <= 1e-5
+        i, j = np.unravel_index(np.argmax(np.abs(ref[:, 3000:])), ref[:, 3000:].shape)
+        assert d.delay[3000 + j] == 4000  # the far target sits in the third chunk
+
+
+@pytest.mark.parametrize("dmin,dmax", [(-10, 600), (-600, 10), (-700, 700), (-999, 999)])
+def test_lags_the_reference_aliases(b2, dmin, dmax):
+    """Short pulses: 2049 pulses of 488 samples, nfft = 1000.  Delays beyond nfft - nCorr = 512 read, in the reference's
+    nfft-point CIRCULAR correlation (Ambiguity.cpp:132-146), the opposite-sign lag d -+ nfft; delays 488..512 are zero.  The
+    engine maps every delay to its one linear lag and runs the runs of consecutive lags as chunks (here up to three, with
+    column offsets that are not multiples of 16)."""
+    args = (dmin, dmax, -2048, 2048, 2_000_000, 1_000_000, True)
+    x, y = O.synth_iq(args[5], seed=21, fs=args[4], targets=((20, 600.0, 0.1), (-37, -200.0, 0.1)))
+    amb = b2.Ambiguity(*args)
+    assert (amb.get_n_corr(), amb.get_nfft()) == (488, 1000)
+    m = amb.process(x, y)
+    ref = O.ambiguity_process(O.ambiguity_dims(*args), x, y)
+    peak = np.abs(ref).max()
+    assert np.abs(m.data.astype(np.complex128) - ref).max() / peak <= 1e-5
+    far = np.abs(amb.delay) > 512
+    assert far.any() and np.abs(ref[:, far]).max() / peak > 1e-3  # the aliased columns are not empty
 
 
 def test_lags_longer_than_a_pulse_are_zero_like_the_reference(b2):

@@ -87,11 +87,24 @@ def test_baseline_cpi_and_device_batch(b2):
         assert rel(out[i].cpu().numpy(), refs[i]) <= TOL
 
 
+@pytest.mark.parametrize("n,bw", [(2_000_000, 10_000), (300_000, 7000), (70_000, 20_000)])
+def test_wide_spectra(b2, n, bw):
+    """nSpectrum above 4096 (the root tables leave LDS for L2): same sums, same tolerance."""
+    rng = np.random.default_rng(n + bw)
+    x = np.round(rng.normal(0, 300, n)) + 1j * np.round(rng.normal(0, 300, n))
+    t = 500 * np.exp(2j * np.pi * 0.0613 * np.arange(n))
+    x += np.round(t.real) + 1j * np.round(t.imag)  # int16-valued like the wire samples: exact in the fp32 upload
+    sa = b2.SpectrumAnalyser(n, bw)
+    assert (sa.decimation, sa.nSpectrum, sa.nfft) == O.spectrum_dims(n, bw) and sa.nSpectrum > 4096
+    spec, _ = sa.process(x)
+    assert rel(spec, O.spectrum_process(x, n, bw)[0]) <= TOL
+
+
 def test_limits(b2):
     with pytest.raises(b2.Blah2HipError):
         b2.SpectrumAnalyser(1000, 2000)       # decimation 0: the reference divides by zero
     with pytest.raises(b2.Blah2HipError) as e:
-        b2.SpectrumAnalyser(2_000_000, 10_000)  # nSpectrum 10000 > 4096
+        b2.SpectrumAnalyser(2_000_000, 100_000)  # nSpectrum 100000: the direct nSpectrum-point sum is bounded at 65536
     assert e.value.code == -3
     sa = b2.SpectrumAnalyser(20_000, 2000)
     with pytest.raises(b2.Blah2HipError):
