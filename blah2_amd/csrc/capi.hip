@@ -203,7 +203,10 @@ bool choose_plan(blah2hip_amb_s *h)
     const int lmax = F - nDelay + 1;
     if (lmax < 16) continue;
     const int nSeg = (nCorr + lmax - 1) / lmax;
-    const int segLen = (nCorr + nSeg - 1) / nSeg;
+    int segLen = (nCorr + nSeg - 1) / nSeg;
+    // F = 1024: segments of exactly 9*64 samples when that costs no extra segment -- consecutive y' windows then overlap by
+    // whole registers of the one-wave kernel, which carries them over instead of reading them again (kernels.hpp: REUSE)
+    if (r3 == 4 && lmax >= 9 * 64 && (nCorr + 9 * 64 - 1) / (9 * 64) == nSeg) segLen = 9 * 64;
     // measured on MI355X (round 2, forced lengths at three geometries): at equal butterfly count the
     // F = 1024 kernel is ~3 % slower than the F = 2048 one
     const double cost = (2.0 * nSeg + 1.0) * F * std::log2((double)F) * (r3 == 4 ? 1.03 : 1.0);
@@ -427,9 +430,54 @@ template <class In> int launch_rangew2_t(blah2hip_amb_s *h, const RangeArgs &a, 
   return BLAH2HIP_OK;
 }
 
+// F = 1024 on the one-wave kernel with 16 points per lane (four waves per SIMD)
+bool use_wave1k_range(const blah2hip_amb_s *h, int nPulses)
+{
+  if (h->r3 != 4 || h->rangeKernel == BLAH2HIP_RANGE_E8) return false;
+  if (h->rangeKernel == BLAH2HIP_RANGE_WAVE1K) return true;
+  return nPulses >= 4 * RANGEW1K_WAVES_PER_SIMD * h->numCU;
+}
+
+template <class In> int launch_rangew1k_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
+{
+  const size_t lds = (size_t)(Wave1kFft::TW_ELEMS + RANGEW1K_WAVES * Wave1kFft::X_ELEMS) * sizeof(cf);
+  const bool shortx = a.plan.segLen <= 9 * 64;
+  const bool out7 = a.plan.nDelay <= 7 * 64;
+  const bool reuse = a.plan.segLen == 9 * 64 && a.plan.nDelay <= 7 * 64 + 1; // whole-register overlap of consecutive y' windows
+  auto kern = reuse ? (out7 ? rangew1k_kernel<In, true, true, true> : rangew1k_kernel<In, true, false, true>)
+              : shortx ? (out7 ? rangew1k_kernel<In, true, true> : rangew1k_kernel<In, true, false>)
+                       : (out7 ? rangew1k_kernel<In, false, true> : rangew1k_kernel<In, false, false>);
+  LDSCFG(kern, lds);
+  const int grid = std::min<int>((a.nPulses + RANGEW1K_WAVES - 1) / RANGEW1K_WAVES, range_grid_cap(h, lds, RANGEW1K_WAVES, 4 * RANGEW1K_WAVES_PER_SIMD));
+#ifdef RANGEW_TRACE
+  static uint64_t *dbg = nullptr;
+  static int calls = 0;
+  if (!dbg) HIPCHK(hipMalloc(&dbg, 64));
+  HIPCHK(hipMemsetAsync(dbg, 0, 64, st));
+  RangeArgs a2 = a;
+  a2.dbg = dbg;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RANGEW1K_WAVES), lds, st, a2, in);
+  if (++calls == 8) {
+    uint64_t hcnt[6];
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(hcnt, dbg, 48, hipMemcpyDeviceToHost));
+    double tot = 0;
+    for (int k = 0; k < 6; k++) tot += (double)hcnt[k];
+    fprintf(stderr, "[rangew1k trace] grid %d pulses %d: other %.3f load %.3f X %.3f Y %.3f inv %.3f store %.3f of %.0f ticks/wave\n", grid, a.nPulses,
+            hcnt[0] / tot, hcnt[1] / tot, hcnt[2] / tot, hcnt[3] / tot, hcnt[4] / tot, hcnt[5] / tot, tot / grid / RANGEW1K_WAVES);
+  }
+#else
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RANGEW1K_WAVES), lds, st, a, in);
+#endif
+  HIPCHK(hipGetLastError());
+  h->lastRange = BLAH2HIP_RANGE_WAVE1K;
+  return BLAH2HIP_OK;
+}
+
 template <class In> int launch_range(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
 {
   if (use_wave_range(h, a.nPulses)) return launch_rangew_t(h, a, in, st);
+  if (use_wave1k_range(h, a.nPulses)) return launch_rangew1k_t(h, a, in, st);
   if (use_wave2_range(h, a.nPulses)) return launch_rangew2_t(h, a, in, st);
   switch (h->r3) {
   case 4: return launch_range8_t<2>(h, a, in, st);
@@ -757,8 +805,11 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
     h->rangeGridForce = (int)value;
     return BLAH2HIP_OK;
   case BLAH2HIP_OPT_RANGE_KERNEL:
-    if (value != 0 && value != BLAH2HIP_RANGE_WAVE && value != BLAH2HIP_RANGE_E16 && value != BLAH2HIP_RANGE_WAVE2)
-      return fail(BLAH2HIP_ERR_INVALID, "range kernel: 0 (by transform length), BLAH2HIP_RANGE_E16, _WAVE or _WAVE2");
+    if (value != 0 && value != BLAH2HIP_RANGE_WAVE && value != BLAH2HIP_RANGE_E16 && value != BLAH2HIP_RANGE_WAVE2 &&
+        value != BLAH2HIP_RANGE_WAVE1K && value != BLAH2HIP_RANGE_E8)
+      return fail(BLAH2HIP_ERR_INVALID, "range kernel: 0 (by transform length), BLAH2HIP_RANGE_E16, _E8, _WAVE, _WAVE2 or _WAVE1K");
+    if ((value == BLAH2HIP_RANGE_WAVE1K || value == BLAH2HIP_RANGE_E8) && h->r3 != 4)
+      return fail(BLAH2HIP_ERR_UNSUPPORTED, "the 16-points-per-lane one-wave kernel and the 8-points-per-thread kernel are 1024-point transforms");
     if (value == BLAH2HIP_RANGE_WAVE2 && h->r3 != 16)
       return fail(BLAH2HIP_ERR_UNSUPPORTED, "the two-wave range kernel is a 4096-point transform");
     if (value == BLAH2HIP_RANGE_WAVE && h->r3 != 8)

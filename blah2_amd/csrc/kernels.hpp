@@ -22,6 +22,7 @@
 #include "fft_wg8.hpp"
 #include "fft_wave.hpp"
 #include "fft_wave2.hpp"
+#include "fft_wave1k.hpp"
 #include "bufload.hpp"
 
 namespace blah2 {
@@ -286,7 +287,11 @@ __device__ __forceinline__ void store_lags_w(cf *out, const RangePlan &p, int cp
 #pragma unroll
   for (int c = 0; c < NC; c++) {
     if (64 * c >= nd) break; // wave-uniform
+#if defined(RW_NO_STORE) // timing experiment: everything but the stores
+    if (64 * c < rem && p.scale == 12345.f) *o = cmake(v[c].x * p.scale, v[c].y * p.scale);
+#else
     if (64 * c < rem) *o = cmake(v[c].x * p.scale, v[c].y * p.scale);
+#endif
     o += step;
   }
 }
@@ -341,6 +346,12 @@ __global__ __launch_bounds__(64 * RANGEW_WAVES, RANGEW_WAVES_PER_SIMD) void rang
       asm volatile("" : "+v"(v[0].x), "+v"(yv[NY - 1].y));
 #endif
       RW_T(1)
+#if defined(RW_NO_COMPUTE) // timing experiment: the kernel's memory operations alone
+#pragma unroll
+      for (int e = 0; e < NX; e++) acc[e] = cadd(acc[e], cadd(v[e], yv[e]));
+#pragma unroll
+      for (int e = NX; e < NY; e++) acc[e] = cadd(acc[e], yv[e]);
+#else
       W::transform<-1, NX>(t, v, w, X);  // v  = X spectrum
 #ifdef RANGEW_TRACE
       asm volatile("" : "+v"(v[0].x));
@@ -353,9 +364,12 @@ __global__ __launch_bounds__(64 * RANGEW_WAVES, RANGEW_WAVES_PER_SIMD) void rang
       RW_T(3)
 #pragma unroll
       for (int e = 0; e < 32; e++) acc[e] = cmacc(acc[e], yv[e], v[e]);
+#endif
     }
     RW_T(0)
+#if !defined(RW_NO_COMPUTE)
     W::template transform<+1, 32, OUT7>(t, acc, w, X);
+#endif
 #ifdef RANGEW_TRACE
     asm volatile("" : "+v"(acc[0].x));
 #endif
@@ -367,6 +381,185 @@ __global__ __launch_bounds__(64 * RANGEW_WAVES, RANGEW_WAVES_PER_SIMD) void rang
   if (t == 0 && a.dbg)
     for (int k = 0; k < 6; k++) atomicAdd((unsigned long long *)&a.dbg[k], (unsigned long long)tr[k]);
 #endif
+}
+
+// --------------------------------------------------------------------------
+// Range kernel on the one-wave 1024-point transform (fft_wave1k.hpp): the kernel above at 16 points per lane, with the
+// loads of the NEXT segment in flight while this one is transformed.
+//
+// Why.  The 2048-point kernel's memory operations alone (-DRW_NO_COMPUTE) take 84 % of its time, its loads alone run
+// at the streaming rate (5.9 TB/s), and doubling the waves per SIMD without prefetching changes nothing (measured,
+// DESIGN.md section 4): a wave has loads in flight only while it waits for them, a quarter of its time, so a CU
+// averages ~50 KB in flight whatever the occupancy -- the kernel is bound by bytes in flight, not by issue slots.
+// Prefetching needs registers the 2048-point kernel does not have (3 x 64 + the next x and y: 320).  At 16 points
+// per lane x, y and the accumulator are 3 x 32, and the raw samples of the next segment need not be a fourth set:
+//     x_{s+1} is requested as soon as x_s has been copied out of its 18 (SHORTX; else 32) registers -- a whole
+//             segment ahead;
+//     y_{s+1} is requested into y_s's own registers after the spectrum product, and is in flight during the
+//             x transform of the next segment.
+// Peak: 32 (X) + 32 (y / Y) + 32 (accumulator) + 18 (next x) = 114 registers + the 16-point kernel's temporaries.
+// The loads and stores are compiler builtins here (not the asm of bufload.hpp): the waits between issue and use are
+// the compiler's, counted in program order across the loop.  The lag stores of a pulse are issued behind the next
+// pulse's first loads.  Out-of-range offsets (negative for y, beyond the segment for x, everything once the wave
+// has run out of pulses) read as zero without a branch, as in the other kernels.
+#ifndef RANGEW1K_WAVES_PER_SIMD
+#define RANGEW1K_WAVES_PER_SIMD 3
+#endif
+#ifndef RANGEW1K_WAVES
+#define RANGEW1K_WAVES 12
+#endif
+typedef unsigned b2_v2u __attribute__((ext_vector_type(2)));
+template <class Chan> struct RawBuiltin;
+template <> struct RawBuiltin<ChanC32> {
+  using raw = b2_v2u;
+  static __device__ __forceinline__ raw ld(__amdgpu_buffer_rsrc_t d, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b64(d, voff, soff, 0); }
+  static __device__ __forceinline__ cf cvt(raw r) { return cmake(__uint_as_float(r.x), __uint_as_float(r.y)); } // not __builtin_bit_cast on a vector element: this clang reads element 0 for both
+};
+template <> struct RawBuiltin<ChanI16> {
+  using raw = unsigned;
+  static __device__ __forceinline__ raw ld(__amdgpu_buffer_rsrc_t d, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(d, voff, soff, 0); }
+  static __device__ __forceinline__ cf cvt(raw r) { return ChanI16::cvt(r); }
+};
+template <> struct RawBuiltin<ChanF16> {
+  using raw = unsigned;
+  static __device__ __forceinline__ raw ld(__amdgpu_buffer_rsrc_t d, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(d, voff, soff, 0); }
+  static __device__ __forceinline__ cf cvt(raw r) { return ChanF16::cvt(r); }
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_b(const void *base, int bytes)
+{
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(u), (short)0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+// x' of segment s: rx[k] = x'[t + 64*k], k < NX; `live` false: nothing is read (zero records)
+template <class In, int NX>
+__device__ __forceinline__ void w1k_issue_x(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, bool live,
+                                            typename RawBuiltin<typename BufLoad<In>::X>::raw *rx)
+{
+  using CX = typename BufLoad<In>::X;
+  const int s0 = s * p.segLen;
+  const int cnt = live ? min(p.segLen, p.nCorr - s0) : 0;
+  const __amdgpu_buffer_rsrc_t d = make_rsrc_b(BufLoad<In>::xp(in, pulseBase + s0), cnt * CX::STRIDE);
+#pragma unroll
+  for (int k = 0; k < NX; k++) rx[k] = RawBuiltin<CX>::ld(d, t * CX::STRIDE, k * 64 * CX::STRIDE);
+}
+// y' of segment s: ry[k] = y'[t + 64*k], k < 16; the offset may be negative (reads as zero): all of it in voffset
+// K0 > 0: only registers K0..15 (the first K0 are carried over from the previous window, see REUSE below)
+template <class In, int K0 = 0>
+__device__ __forceinline__ void w1k_issue_y(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, bool live,
+                                            typename RawBuiltin<typename BufLoad<In>::Y>::raw *ry)
+{
+  using CY = typename BufLoad<In>::Y;
+  const __amdgpu_buffer_rsrc_t d = make_rsrc_b(BufLoad<In>::yp(in, pulseBase), live ? p.nCorr * CY::STRIDE : 0);
+  // one opaque VGPR base per 4 KiB of offset: a constant the compiler can see beyond the 12-bit immediate would be split
+  // into soffset, and a negative voffset stays out of range whatever soffset is (bufload.hpp)
+  constexpr int STEP = 64 * CY::STRIDE, NV = (15 * STEP >> 12) + 1;
+  int vb[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    vb[j] = (s * p.segLen + p.delayMin + t) * CY::STRIDE + j * 4096;
+    asm volatile("" : "+v"(vb[j]));
+  }
+#pragma unroll
+  for (int k = K0; k < 16; k++) ry[k] = RawBuiltin<CY>::ld(d, vb[(k * STEP) >> 12] + ((k * STEP) & 4095), 0);
+}
+
+// SHORTX: segLen <= 9*64 (cfg 2: 557): x' = 0 from 9*64 on -- 7 of 16 loads are not issued and the first 16-point
+// step skips the zero inputs.  OUT7: nDelay <= 7*64 -- the inverse computes only the 7 wanted outputs per lane.
+// REUSE: segLen = 9*64 exactly.  Consecutive y' windows of a pulse then overlap by WHOLE registers: y'_{s+1}[t + 64 k] =
+// y'_s[t + 64 (k + 9)], so registers 9..15 of one window are registers 0..6 of the next and only nine are loaded.  The
+// overlap (nDelay - 1 of every segLen + nDelay - 1 samples) is otherwise read again, and at this kernel's streaming
+// rate an XCD's L2 has turned over between two segments of a wave: the re-read comes from HBM (PMC: 1.08-1.14 x the
+// algorithmic bytes at F = 2048, more at F = 1024 with its shorter segments).
+template <class In, bool SHORTX, bool OUT7, bool REUSE = false>
+__global__ __launch_bounds__(64 * RANGEW1K_WAVES, RANGEW1K_WAVES_PER_SIMD) void rangew1k_kernel(RangeArgs a, In in)
+{
+  static_assert(!REUSE || SHORTX, "");
+  using W = Wave1kFft;
+  using RX = RawBuiltin<typename BufLoad<In>::X>;
+  using RY = RawBuiltin<typename BufLoad<In>::Y>;
+  constexpr int NX = SHORTX ? 9 : 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf *table = reinterpret_cast<cf *>(smem);
+  const int t = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  cf *X = table + W::TW_ELEMS + wave * W::X_ELEMS;
+  W::fill_table(threadIdx.x, 64 * RANGEW1K_WAVES, a.tw, table);
+  __syncthreads(); // the only barrier: waves without a pulse leave after it
+  W::Tw w;
+  W::load_twiddles(t, a.tw, table, w);
+  const RangePlan p = a.plan;
+  const int stride = gridDim.x * RANGEW1K_WAVES;
+  int pulse = blockIdx.x * RANGEW1K_WAVES + wave;
+  if (pulse >= a.nPulses) return;
+  int cpi = pulse / p.nDoppler;
+  int i = pulse - cpi * p.nDoppler;
+  int64_t base = (int64_t)cpi * a.cpiStride + (int64_t)i * p.nCorr;
+  int s = 0;
+  typename RX::raw rx[NX];
+  typename RY::raw ry[16];
+  cf acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; e++) acc[e] = cmake(0.f, 0.f);
+  w1k_issue_x<In, NX>(in, p, base, 0, t, true, rx);
+  w1k_issue_y<In>(in, p, base, 0, t, true, ry);
+  for (;;) {
+    // the segment after this one (wave-uniform)
+    int ns = s + 1, npulse = pulse, ncpi = cpi, ni = i;
+    int64_t nbase = base;
+    if (ns == p.nSeg) {
+      ns = 0;
+      npulse = pulse + stride;
+      ncpi = npulse / p.nDoppler;
+      ni = npulse - ncpi * p.nDoppler;
+      nbase = (int64_t)ncpi * a.cpiStride + (int64_t)ni * p.nCorr;
+    }
+    const bool more = npulse < a.nPulses;
+    cf v[16];
+#pragma unroll
+    for (int k = 0; k < NX; k++) v[k] = RX::cvt(rx[k]);
+    __builtin_amdgcn_sched_barrier(0);
+    w1k_issue_x<In, NX>(in, p, nbase, ns, t, more, rx);
+    __builtin_amdgcn_sched_barrier(0);
+    W::transform<-1, NX>(t, v, w, X); // v = X spectrum
+    cf yv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) yv[k] = RY::cvt(ry[k]);
+    typename RY::raw carry[7];
+    if constexpr (REUSE) {
+#pragma unroll
+      for (int k = 0; k < 7; k++) carry[k] = ry[9 + k];
+    }
+    W::transform<-1, 16>(t, yv, w, X); // yv = Y spectrum
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = cmacc(acc[e], yv[e], v[e]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (REUSE) {
+      if (ns != 0) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) ry[k] = carry[k];
+        w1k_issue_y<In, 7>(in, p, nbase, ns, t, more, ry);
+      } else {
+        w1k_issue_y<In>(in, p, nbase, ns, t, more, ry);
+      }
+    } else {
+      w1k_issue_y<In>(in, p, nbase, ns, t, more, ry);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ns == 0) { // the pulse is complete
+      W::template transform<+1, 16, OUT7>(t, acc, w, X);
+      store_lags_w<OUT7 ? 7 : 16>(a.out, p, cpi, i, t, acc);
+      if (!more) break;
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[e] = cmake(0.f, 0.f);
+      pulse = npulse;
+      cpi = ncpi;
+      i = ni;
+    }
+    s = ns;
+    base = nbase;
+  }
 }
 
 // --------------------------------------------------------------------------

@@ -127,9 +127,10 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 /* Execution plan, per handle.  Options take effect on the next process call. */
 #define BLAH2HIP_OPT_DOPPLER_KERNEL 1 /* BLAH2HIP_DOP_*; AUTO picks by launch size */
 #define BLAH2HIP_OPT_RANGE_GRID 2     /* workgroups of the range kernel; 0 = the launched kernel's residency */
-#define BLAH2HIP_OPT_RANGE_KERNEL 3   /* 0 = by transform length and launch size (F = 1024: E8; 4096: E16; 2048: WAVE once a launch has a
-                                       * pulse per wave slot of the chip -- 8 x CUs -- else E16, e.g. a single CPI);
-                                       * BLAH2HIP_RANGE_E16 / _WAVE (F = 2048) / _WAVE2 (F = 4096, measured 5 % slower than E16) force one */
+#define BLAH2HIP_OPT_RANGE_KERNEL 3   /* 0 = by transform length and launch size (4096: E16; 2048: WAVE once a launch has a pulse per wave
+                                       * slot of the chip -- 8 x CUs -- else E16, e.g. a single CPI; 1024: WAVE1K from 12 x CUs pulses,
+                                       * else E8); BLAH2HIP_RANGE_E16 / _WAVE (F = 2048) / _WAVE2 (F = 4096, measured 5 % slower than
+                                       * E16) / _WAVE1K / _E8 (F = 1024) force one */
 #define BLAH2HIP_OPT_DOPPLER_GRID 4   /* workgroup cap of the PERSISTENT Doppler tile kernels (TILE8 / TILE16 / TILEW / TILEW2); 0 = their
                                        * residency (one or two workgroups per CU).  A small cap makes every workgroup walk many tiles --
                                        * the steady state of the software-pipelined loops -- on a small fixture (tests) */
@@ -153,6 +154,7 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 #define BLAH2HIP_RANGE_E8 2    /* 8 points per thread, last stage across lanes (F = 1024) */
 #define BLAH2HIP_RANGE_WAVE 3  /* one wave per pulse, 32 points per lane, no barriers (F = 2048) */
 #define BLAH2HIP_RANGE_WAVE2 4 /* a pair of waves per pulse, 32 points per thread, one exchange (F = 4096) */
+#define BLAH2HIP_RANGE_WAVE1K 5 /* one wave per pulse, 16 points per lane, four waves per SIMD (F = 1024) */
 /* BLAH2HIP_ERR_UNSUPPORTED when the kernel does not cover the handle's Doppler length */
 int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value);
 #define BLAH2HIP_INFO_LAST_DOPPLER_KERNEL 1 /* BLAH2HIP_DOP_* the last process call launched (0 = none yet) */

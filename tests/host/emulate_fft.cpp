@@ -11,6 +11,7 @@
 #include "../../blah2_amd/csrc/fft_wg8.hpp"
 #include "../../blah2_amd/csrc/fft_wave.hpp"
 #include "../../blah2_amd/csrc/fft_wave2.hpp"
+#include "../../blah2_amd/csrc/fft_wave1k.hpp"
 
 #include <cmath>
 #include <complex>
@@ -290,6 +291,76 @@ int test_fft_wave2()
   return (worst < 2e-6 && worst_inv < 2e-6 && worst_nz < 2e-6) ? 0 : 1;
 }
 
+// one-wave 1024-point transform (fft_wave1k.hpp): 64 lanes x 16 points; both lane exchanges emulated on lane pairs
+template <int SIGN, int NZ = 16, bool OUT7 = false> void wave1k_transform(std::vector<cf> &v, const std::vector<cf> &tw, std::vector<cf> &X)
+{
+  using W = Wave1kFft;
+  std::vector<W::Tw> w(64);
+  std::vector<cf> table(W::TW_ELEMS);
+  for (int t = 0; t < 64; t++) W::fill_table(t, 64, tw.data(), table.data());
+  for (int t = 0; t < 64; t++) W::load_twiddles(t, tw.data(), table.data(), w[t]);
+  for (int t = 0; t < 64; t++) W::s1<SIGN, NZ>(&v[t * 16], w[t]);
+  for (int l = 0; l < 32; l++) W::sw_host(&v[l * 16], &v[(l + 32) * 16]);
+  for (int t = 0; t < 64; t++) W::b1<SIGN>(&v[t * 16], w[t]);
+  for (int l = 0; l < 64; l++)
+    if (!(l & 16)) W::sw_host(&v[l * 16], &v[(l + 16) * 16]);
+  for (int t = 0; t < 64; t++) W::b2<SIGN>(t, &v[t * 16], w[t], X.data());
+  for (int t = 0; t < 64; t++) W::s3<SIGN, OUT7>(t, &v[t * 16], X.data());
+}
+
+int test_fft_wave1k()
+{
+  using W = Wave1kFft;
+  constexpr int F = W::F;
+  std::mt19937 gen(1024);
+  std::uniform_real_distribution<float> dist(-1.f, 1.f);
+  std::vector<cf> in(F), tw(F), X(W::X_ELEMS);
+  for (auto &c : in) c = cmake(dist(gen), dist(gen));
+  for (int k = 0; k < F; k++) { double a = -2.0 * M_PI * k / F; tw[k] = cmake((float)std::cos(a), (float)std::sin(a)); }
+  double worst = 0, worst_inv = 0, worst_nz = 0, worst_o7 = 0;
+  for (int nz : {16, 9}) {
+    std::vector<cf> src = in;
+    if (nz == 9) for (int n = 9 * 64; n < F; n++) src[n] = cmake(0.f, 0.f);
+    std::vector<cf> v(F);
+    for (int t = 0; t < 64; t++)
+      for (int k = 0; k < 16; k++) v[t * 16 + k] = (k >= nz) ? cmake(77.f, -55.f) /* never read */ : src[t + 64 * k];
+    if (nz == 9) wave1k_transform<-1, 9>(v, tw, X); else wave1k_transform<-1>(v, tw, X);
+    std::vector<cd> ref(F);
+    double peak = 0;
+    for (int m = 0; m < F; m++) {
+      cd acc = 0;
+      for (int n = 0; n < F; n++) {
+        const double a = -2.0 * M_PI * (double)(((long)m * n) % F) / F;
+        acc += cd(src[n].x, src[n].y) * cd(std::cos(a), std::sin(a));
+      }
+      ref[m] = acc;
+      peak = std::max(peak, std::abs(acc));
+    }
+    double err = 0;
+    for (int t = 0; t < 64; t++)
+      for (int a = 0; a < 16; a++) {
+        const cf g = v[t * 16 + a];
+        err = std::max(err, std::abs(cd(g.x, g.y) - ref[t + 64 * a]));
+      }
+    if (nz == 16) {
+      worst = err / peak;
+      std::vector<cf> v7 = v;
+      wave1k_transform<+1>(v, tw, X);
+      wave1k_transform<+1, 16, true>(v7, tw, X);
+      for (int t = 0; t < 64; t++)
+        for (int c = 0; c < 16; c++) {
+          const cf g = v[t * 16 + c], e = in[t + 64 * c];
+          worst_inv = std::max(worst_inv, (double)std::abs(cd(g.x / F - e.x, g.y / F - e.y)));
+          if (c < 7) worst_o7 = std::max(worst_o7, (double)std::abs(cd(v7[t * 16 + c].x / F - e.x, v7[t * 16 + c].y / F - e.y)));
+        }
+    } else {
+      worst_nz = err / peak;
+    }
+  }
+  std::printf("WAVE1K F=%d fwd_rel_err=%.3e inv_abs_err=%.3e nz9_rel_err=%.3e out7_abs_err=%.3e\n", F, worst, worst_inv, worst_nz, worst_o7);
+  return (worst < 2e-6 && worst_inv < 2e-6 && worst_nz < 2e-6 && worst_o7 < 2e-6) ? 0 : 1;
+}
+
 // the pruned 16-point DFT of the zero-padded reference segments against the full one
 int test_dft16_nz9()
 {
@@ -398,7 +469,7 @@ int test_range(int nCorr, int nD, int dMin, int dMax, int nSeg, int segLen, unsi
 int main(int argc, char **argv)
 {
   if (argc >= 2 && !std::strcmp(argv[1], "fft"))
-    return test_fft<4>() | test_fft<8>() | test_fft<16>() | test_fft8<2>() | test_fft8<4>() | test_fft8<8>() | test_fft_wave() | test_fft_wave2() | test_dft16_nz9();
+    return test_fft<4>() | test_fft<8>() | test_fft<16>() | test_fft8<2>() | test_fft8<4>() | test_fft8<8>() | test_fft_wave() | test_fft_wave2() | test_fft_wave1k() | test_dft16_nz9();
   if (argc >= 10 && !std::strcmp(argv[1], "range")) {
     const int R3 = std::atoi(argv[2]);
     const int a[7] = {std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]),

@@ -261,3 +261,45 @@ def test_one_wave_range_kernel_long_segments(b2, geom, out7):
     assert amb.dims.fft_len == 2048 and amb.dims.seg_len > 1536
     assert (amb.get_n_delay_bins() <= 448) == out7
     assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE
+
+
+@pytest.mark.parametrize("geom,fmt,seg576,shortx,out7,grid", [
+    (CFG2, "c32", True, True, True, 0),                                        # BASELINE configs[1]: 7 segments of 576, carried y' registers
+    (CFG2, "i16", True, True, True, 3),                                        # the same from .rspduo words, 36 waves: 43 pulses per wave
+    ((-7, 492, -50, 50, 155_540, 155_540), "c32", False, True, False, 0),      # 500 lags: all 16 outputs of the inverse, no carry
+    ((-5, 94, -40, 40, 240_000, 240_000), "c32", False, False, True, 2),       # long segments (every x load issued), few lags
+    ((1, 299, -100, 100, 1_000_000, 777_001), "i16", False, False, True, 1),   # ragged pulse length, window starts at a positive lag
+    ((-10, 400, -2, 2, 20_000, 20_000), "c32", True, True, True, 0)])          # 5 pulses per CPI: most waves leave without a pulse
+def test_one_wave_1024_range_kernel(b2, geom, fmt, seg576, shortx, out7, grid):
+    """rangew1k_kernel (one wave per pulse on the one-wave 1024-point transform, the next segment's loads in flight
+    during the transforms, three CPIs per launch), forced: every instantiation, the carried-over y' registers of the
+    576-sample segmentation, pulse boundaries inside a wave's walk (grid cap), waves without work."""
+    from blah2_amd import _lib
+    amb = run_batch(b2, geom, 3, "auto", seeds=(150, 151, 152), fmt=fmt, fft_len=1024, range_kernel=_lib.RANGE_WAVE1K,
+                    expect=_expected_doppler3(geom), targets=((37, -13.0, 0.05),), cell_tol=2e-4, range_grid=grid)
+    assert amb.dims.fft_len == 1024 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE1K
+    assert (amb.dims.seg_len == 576) == seg576 and (amb.dims.seg_len <= 576) == shortx and (amb.get_n_delay_bins() <= 448) == out7
+    if grid:
+        assert amb.info(_lib.INFO_RANGE_GRID) == grid
+
+
+def test_f1024_kernels_agree(b2):
+    """The two F = 1024 range kernels (8 points per thread in a workgroup, 16 per lane in one wave) on the same batch."""
+    import torch
+    from blah2_amd import _lib
+    geom = (-10, 400, -32, 32, 250_000, 250_000)
+    n = geom[5]
+    xs, ys = zip(*(O.synth_iq(n, seed=s, fs=geom[4], targets=((100, 11.0, 0.1),)) for s in (7, 8)))
+    x = torch.from_numpy(np.stack(xs).astype(np.complex64)).cuda()
+    y = torch.from_numpy(np.stack(ys).astype(np.complex64)).cuda()
+    maps = []
+    for k in (_lib.RANGE_E8, _lib.RANGE_WAVE1K):
+        amb = b2.Ambiguity(*geom, True, max_batch=2)
+        amb.set_fft_len(1024)
+        amb.set_range_kernel(k)
+        out = torch.zeros((2, amb.get_n_doppler_bins(), amb.get_n_delay_bins()), dtype=torch.complex64, device="cuda")
+        amb.process_dev(b2.FMT_C32, x.data_ptr(), y.data_ptr(), 2, n, out.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == k
+        maps.append(out.cpu().numpy())
+    assert np.abs(maps[0] - maps[1]).max() / np.abs(maps[0]).max() <= 5e-7
