@@ -206,10 +206,15 @@ def e2e_host(cfg, local, np, blah2_amd):
                 v = [float(g) for g in m.groups()]
                 out["classes_ms"] = v[0]
                 out["classes_stages_ms"] = dict(zip(("spectrum", "filter", "ambiguity", "set_metrics", "cfar"), v[1:]))
+            m = re.search(r"^cut .*: ([0-9.]+) ms/CPI", p.stdout, re.M)
+            if m and p.returncode == 0:
+                out["classes_cut_ms"] = float(m.group(1))
         except Exception as e:  # the figure is informative; a missing binary must not void the bench line
             out["classes_error"] = str(e)
     out["note"] = ("host-buffer boundary, one CPI per call; classes_ms = SpectrumAnalyser + WienerHopf (410 taps) + Ambiguity + "
-                   "set_metrics + CfarDetector1D through the C++ drop-in classes (blah2.cpp:264-287), 2 x 2 M complex<double> in IqData")
+                   "set_metrics + CfarDetector1D through the C++ drop-in classes (blah2.cpp:264-287), 2 x 2 M complex<double> in IqData; "
+                   "classes_cut_ms = the 2 x 2 M push_back calls of blah2.cpp:254-258 before it, inside which the samples are narrowed "
+                   "and uploaded in 256 k stretches")
     return out
 
 

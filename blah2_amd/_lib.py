@@ -109,6 +109,7 @@ SYMBOLS = {
     "blah2hip_ctx_free_host": (C.c_int, [_vp, _vp]),
     "blah2hip_ctx_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "blah2hip_ctx_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "blah2hip_ctx_d2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "blah2hip_amb_result_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "blah2hip_amb_set_timing": (C.c_int, [_vp, C.c_int]),
     "blah2hip_amb_get_timing": (C.c_int, [_vp, _vp, _vp]),

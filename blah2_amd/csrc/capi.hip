@@ -1637,6 +1637,14 @@ int blah2hip_ctx_h2d(blah2hip_ctx_t c, void *dptr, const void *hptr, size_t byte
   return BLAH2HIP_OK;
 }
 
+int blah2hip_ctx_d2d(blah2hip_ctx_t c, void *dst, const void *src, size_t bytes)
+{
+  if (!c || !dst || !src) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return BLAH2HIP_OK;
+}
+
 int blah2hip_ctx_d2h(blah2hip_ctx_t c, void *hptr, const void *dptr, size_t bytes)
 {
   if (!c || !dptr || !hptr) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");

@@ -62,6 +62,40 @@ void IqData::materialise()
   devCount = 0;
   devSkip = 0;
   devSrc = nullptr;
+  sh.mirrored = 0; // the ring now holds samples its shadow (and the device's copy of it) never saw
+}
+
+bool IqData::attach_shadow(float *buf, size_t chunk, void (*hook)(IqData *, void *), void *user)
+{
+  if (!n || !buf || !hook || !chunk) return false;
+  if (ring.size() != n) { // fix the storage at its capacity, front sample at position 0
+    std::vector<std::complex<double>> full(n);
+    std::pair<const std::complex<double> *, size_t> sp[2];
+    spans(0, count, sp);
+    size_t o = 0;
+    for (const auto &s : sp) { std::copy(s.first, s.first + s.second, full.begin() + (std::ptrdiff_t)o); o += s.second; }
+    ring.swap(full);
+    head = 0;
+  }
+  sh = Shadow();
+  sh.buf = buf;
+  sh.chunk = chunk;
+  sh.hook = hook;
+  sh.user = user;
+  sh.mirrored = 0; // samples already in the FIFO have no shadow: the eager path starts once they have left
+  sh.pendStart = (head + count) % ring.size();
+  sh.pend = 0;
+  return true;
+}
+
+void IqData::detach_shadow() { sh = Shadow(); }
+
+void IqData::shadow_take_pending(size_t &start, size_t &cnt)
+{
+  start = sh.pendStart;
+  cnt = sh.pend;
+  if (!ring.empty()) sh.pendStart = (sh.pendStart + sh.pend) % ring.size();
+  sh.pend = 0;
 }
 
 void IqData::set_device_front(uint32_t cnt, IqDeviceFront *src)
@@ -90,11 +124,20 @@ void IqData::push_back(std::complex<double> sample)
     if (devCount) { devCount--; devSkip++; } // a device-only one simply ceases to exist
     head = (head + 1) % ring.size();
     count--;
+    if (sh.mirrored > count) sh.mirrored = count;
   }
   if (count == ring.size()) grow();
-  ring[(head + count) % ring.size()] = sample;
+  size_t pos = head + count;
+  if (pos >= ring.size()) pos -= ring.size();
+  ring[pos] = sample;
   count++;
   gen++;
+  if (sh.buf) {
+    sh.buf[2 * pos] = (float)sample.real();
+    sh.buf[2 * pos + 1] = (float)sample.imag();
+    if (sh.mirrored < count) sh.mirrored++;
+    if (++sh.pend >= sh.chunk) sh.hook(this, sh.user);
+  }
 }
 
 // reference IqData.cpp:55-63
@@ -105,6 +148,7 @@ std::complex<double> IqData::pop_front()
   const std::complex<double> s = ring[head];
   head = (head + 1) % ring.size();
   count--;
+  if (sh.mirrored > count) sh.mirrored = count;
   gen++;
   return s;
 }
@@ -125,6 +169,7 @@ void IqData::pop_front_block(double *dst, uint32_t cnt)
     }
   if (take) head = (head + take) % ring.size();
   count -= take;
+  if (sh.mirrored > count) sh.mirrored = count;
   gen++;
   if (take < cnt) throw std::runtime_error("Attempting to pop from an empty deque");
 }
@@ -140,13 +185,19 @@ void IqData::drop_front(uint32_t cnt)
   }
   if (take) head = (head + take) % ring.size();
   count -= take;
+  if (sh.mirrored > count) sh.mirrored = count;
   gen++;
   if (take < cnt) throw std::runtime_error("Attempting to pop from an empty deque");
 }
 
 void IqData::keep_front(uint32_t cnt)
 {
-  if (cnt < count) count = cnt;
+  if (cnt < count) { // the most recent samples go: so do their shadows, and what was pushed but not yet reported
+    const size_t gone = count - cnt;
+    sh.mirrored = sh.mirrored > gone ? sh.mirrored - gone : 0;
+    sh.pend = sh.pend > gone ? sh.pend - gone : 0;
+    count = cnt;
+  }
   if (devCount > count) devCount = (uint32_t)count;
   gen++;
 }
@@ -171,6 +222,7 @@ void IqData::print()
     head = (head + 1) % ring.size();
     count--;
   }
+  sh.mirrored = 0;
   gen++;
 }
 
@@ -178,6 +230,9 @@ void IqData::clear()
 {
   head = 0;
   count = 0;
+  sh.pendStart = 0;
+  sh.pend = 0;
+  sh.mirrored = 0;
   devCount = 0;
   devSkip = 0;
   devSrc = nullptr;

@@ -71,6 +71,22 @@ public:
   // called when an IqData dies, so that a cache keyed by its address can forget it
   static void (*destroyed_hook)(IqData *);
 
+  // ---- fp32 shadow of the ring (util/DeviceContext.h) ------------------------------------------
+  // From attach_shadow() on, push_back also narrows each sample into buf[2 * position], position = its index in the
+  // ring (whose storage is fixed at its capacity n by the call), and calls hook(this, user) every `chunk` pushes: the
+  // device context uploads that stretch while the caller is still pushing (blah2.cpp:254-258 fills x and y sample by
+  // sample right before it processes them), so that a CPI is resident by the time the first class asks for it.
+  // False (nothing attached) when the capacity is unbounded (n == 0).  `buf` holds 2 * n floats and stays the caller's.
+  bool attach_shadow(float *buf, size_t chunk, void (*hook)(IqData *, void *), void *user);
+  void detach_shadow();
+  // every sample in the FIFO has its shadow: those pushed since attach_shadow() have, so this holds once the older ones
+  // have left (x and y turn over once per CPI); device-only samples written back into the ring have none either
+  bool shadow_valid() const { return sh.buf && sh.mirrored == count; }
+  // the stretch of ring positions pushed since the last call: [start, start + cnt) modulo the capacity
+  void shadow_take_pending(size_t &start, size_t &cnt);
+  size_t ring_capacity() const { return ring.size(); }
+  size_t head_pos() const { return head; }
+
 private:
   uint32_t n;
   std::mutex mutex_lock;
@@ -80,6 +96,13 @@ private:
   uint32_t devCount = 0;          // front samples whose truth is on the device
   uint32_t devSkip = 0;           // samples of that device view already consumed or evicted in front of them
   IqDeviceFront *devSrc = nullptr;
+  struct Shadow {
+    float *buf = nullptr;
+    size_t mirrored = 0; // the most recent `mirrored` samples of the FIFO have their shadow
+    size_t pendStart = 0, pend = 0, chunk = 0;
+    void (*hook)(IqData *, void *) = nullptr;
+    void *user = nullptr;
+  } sh;
   double min = 0, max = 0, mean = 0;
   std::vector<std::complex<double>> spectrum;
   std::vector<double> frequency;

@@ -215,7 +215,7 @@ static void sequence_at_cfg2()
 {
   {
     const uint32_t fs2 = 2000000, n2 = 2000000;
-    const int nCpi = 4;
+    const int nCpi = 8, nWarm = 3; // CPI 0 attaches the eager path; the first device-to-host copy after its uploads began (CPI 1 or 2) takes 7 ms, once per process
     SpectrumAnalyser spectrumAnalyser(n2, 2000);
     WienerHopf filter(-10, 400, n2);
     Ambiguity ambiguity(-10, 400, -256, 256, fs2, n2, true);
@@ -226,18 +226,27 @@ static void sequence_at_cfg2()
     std::vector<std::complex<double>> xs(n2);
     double t_seq = 0, t_part[5] = {0, 0, 0, 0, 0};
     size_t nDet = 0;
+    std::vector<std::complex<double>> ysv(n2);
+    double t_cut = 0;
     for (int c = 0; c < nCpi; c++) {
       for (auto &v : xs) v = {(double)u(gen), (double)u(gen)};
-      for (uint32_t i = 0; i < n2; i++) { // blah2.cpp:254-258 (extract_buffer: the reference's own loop, not timed here)
-        x.push_back(xs[i]);
+      for (uint32_t i = 0; i < n2; i++) {
         std::complex<double> t = 0.8 * xs[i] + std::complex<double>(u(gen) * 0.1, u(gen) * 0.1);
         if (i >= 37) t += 0.05 * xs[i - 37] * std::exp(std::complex<double>(0, 2 * M_PI * (-63.0) * i / fs2));
-        y.push_back({std::round(t.real()), std::round(t.imag())});
+        ysv[i] = {std::round(t.real()), std::round(t.imag())};
       }
+      // blah2.cpp:254-258: the cut, sample by sample.  Timed apart from the sequence: from the second CPI on push_back also
+      // narrows into the pinned shadow and sends every 256 k samples on their way (util/DeviceContext.h)
+      const auto tc0 = std::chrono::steady_clock::now();
+      for (uint32_t i = 0; i < n2; i++) {
+        x.push_back(xs[i]);
+        y.push_back(ysv[i]);
+      }
+      if (c >= nWarm) t_cut += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
       auto tic = std::chrono::steady_clock::now();
       auto lap = [&](int k) {
         const auto now = std::chrono::steady_clock::now();
-        if (c) t_part[k] += std::chrono::duration<double, std::milli>(now - tic).count();
+        if (c >= nWarm) t_part[k] += std::chrono::duration<double, std::milli>(now - tic).count();
         tic = now;
       };
       const auto t0 = tic;
@@ -246,7 +255,7 @@ static void sequence_at_cfg2()
       auto map = ambiguity.process(&x, &y); lap(2);   // :278
       map->set_metrics(); lap(3);                     // :279
       auto det = cfar.process(map); lap(4);           // :285
-      if (c) t_seq += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (c >= nWarm) t_seq += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       nDet = det->get_nDetections();
       bool found = false;
       for (size_t i = 0; i < nDet; i++)
@@ -256,7 +265,45 @@ static void sequence_at_cfg2()
     }
     std::printf("sequence blah2.cpp:264-287 at 2 MS/s x 1 s (Spectrum, WienerHopf 410 taps, Ambiguity 513 x 411, set_metrics, CFAR): "
                 "%.2f ms/CPI  [spectrum %.2f, filter %.2f, ambiguity %.2f, set_metrics %.2f, cfar %.2f]; %zu detections\n",
-                t_seq / (nCpi - 1), t_part[0] / (nCpi - 1), t_part[1] / (nCpi - 1), t_part[2] / (nCpi - 1), t_part[3] / (nCpi - 1),
-                t_part[4] / (nCpi - 1), nDet);
+                t_seq / (nCpi - nWarm), t_part[0] / (nCpi - nWarm), t_part[1] / (nCpi - nWarm), t_part[2] / (nCpi - nWarm),
+                t_part[3] / (nCpi - nWarm), t_part[4] / (nCpi - nWarm), nDet);
+    std::printf("cut blah2.cpp:254-258 (2 x %u push_back, narrowing + eager upload inside): %.2f ms/CPI\n", n2, t_cut / (nCpi - nWarm));
+  }
+  // the eager path (samples narrowed and uploaded as they are pushed) against the per-CPI path, also with a front that
+  // wraps around the end of the ring and with a reader of y between the filter and the map
+  {
+    const uint32_t n = 200000, fsl = 1000000;
+    std::mt19937 gen(11);
+    std::uniform_int_distribution<int> u(-300, 300);
+    auto run = [&](bool eager, uint32_t extra, bool peek) {
+      IqData x{n}, y{n};
+      WienerHopf filter(-10, 100, n);
+      Ambiguity ambiguity(-10, 100, -100, 100, fsl, n, true);
+      std::mt19937 g2(23);
+      std::vector<double> cells;
+      for (int c = 0; c < 3; c++) {
+        if (!eager) { x.detach_shadow(); y.detach_shadow(); } // keeps this FIFO on the per-CPI path
+        const uint32_t m = n + (c == 2 ? extra : 0);       // `extra` more than the FIFO holds: the oldest are evicted, the front moves
+        for (uint32_t i = 0; i < m; i++) {
+          const std::complex<double> a{(double)u(g2), (double)u(g2)};
+          x.push_back(a);
+          y.push_back({std::round(0.7 * a.real() + 0.1 * u(g2)), std::round(0.7 * a.imag() + 0.1 * u(g2))});
+        }
+        CHECK(filter.process(&x, &y));
+        if (peek && c == 2) CHECK(y.get_data().size() == n);
+        auto map = ambiguity.process(&x, &y);
+        if (c == 2)
+          for (const auto &row : map->data)
+            for (const auto &v : row) { cells.push_back(v.real()); cells.push_back(v.imag()); }
+      }
+      return cells;
+    };
+    const auto ref = run(false, 0, false);
+    CHECK(run(true, 0, false) == ref);
+    CHECK(run(true, 0, true) == ref);
+    const auto refw = run(false, 5000, false);
+    CHECK(refw != ref);
+    CHECK(run(true, 5000, false) == refw);
+    CHECK(run(true, 5000, true) == refw);
   }
 }

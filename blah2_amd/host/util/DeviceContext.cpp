@@ -4,6 +4,7 @@
 #include "process/ambiguity/Ambiguity.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -13,6 +14,8 @@ void chk(int rc, const char *what)
   if (rc != BLAH2HIP_OK) throw std::runtime_error(std::string(what) + ": " + blah2hip_last_error());
 }
 constexpr unsigned N_WORKERS = 8; // narrowing 2 M samples: 0.25 ms with eight threads, 1.7 ms with one
+constexpr size_t SHADOW_CHUNK = 1u << 18;       // samples per eager upload (2 MB)
+constexpr size_t SHADOW_MAX = 64u << 20;        // FIFOs of more samples (a capture buffer of minutes) stay on the per-CPI path
 } // namespace
 
 DeviceContext &DeviceContext::get()
@@ -63,6 +66,8 @@ void DeviceContext::forget(IqData *q)
   (void)blah2hip_ctx_sync(c.ctx);
   (void)blah2hip_ctx_free(c.ctx, m->dev);
   (void)blah2hip_ctx_free(c.ctx, m->devFront);
+  (void)blah2hip_ctx_free(c.ctx, m->devRing);
+  if (m->shadow) (void)blah2hip_ctx_free_host(c.ctx, m->shadow);
   delete m;
   c.mirrors.erase(it);
 }
@@ -98,11 +103,78 @@ float *DeviceContext::staging(size_t samples)
   return pinned[k];
 }
 
+// ---- the eager path ---------------------------------------------------------------------------------
+void DeviceContext::on_chunk(IqData *q, void *mirror)
+{
+  Mirror &m = *static_cast<Mirror *>(mirror);
+  m.ctx->flush_pending(q, m);
+}
+
+// the stretch of ring positions pushed since the last call goes to the same positions of the device ring
+void DeviceContext::flush_pending(IqData *q, Mirror &m)
+{
+  size_t start = 0, cnt = 0;
+  q->shadow_take_pending(start, cnt);
+  while (cnt) {
+    const size_t a = std::min(cnt, m.ringCap - start);
+    chk(blah2hip_ctx_h2d(ctx, m.devRing + 2 * start, m.shadow + 2 * start, a * 2 * sizeof(float)), "DeviceContext: eager upload");
+    cnt -= a;
+    start = 0;
+  }
+}
+
+void DeviceContext::try_attach(IqData *q, Mirror &m)
+{
+  m.tried = true;
+  const size_t n = q->get_n();
+  static const bool off = std::getenv("BLAH2HIP_NO_EAGER_UPLOAD") != nullptr; // measurements: the per-CPI path only
+  if (off || !n || n > SHADOW_MAX) return;
+  void *h = nullptr, *d = nullptr;
+  chk(blah2hip_ctx_malloc_host(ctx, n * 2 * sizeof(float), &h), "DeviceContext: pinned shadow");
+  chk(blah2hip_ctx_malloc(ctx, n * 2 * sizeof(float), &d), "DeviceContext: device ring");
+  m.shadow = (float *)h;
+  m.devRing = (float *)d;
+  m.ringCap = n;
+  if (!q->attach_shadow(m.shadow, SHADOW_CHUNK, &DeviceContext::on_chunk, &m)) {
+    (void)blah2hip_ctx_free_host(ctx, h);
+    (void)blah2hip_ctx_free(ctx, d);
+    m.shadow = m.devRing = nullptr;
+    m.ringCap = 0;
+  }
+}
+
 const void *DeviceContext::resident(IqData *q, uint32_t count)
 {
   Mirror &m = mirror_of(q);
   if (count > q->get_length()) throw std::runtime_error("Attempting to pop from an empty deque"); // what the reference's pops would throw
   if (m.gen == q->generation() && m.view && m.viewCount >= count) return m.view;
+  if (m.ringCap && q->shadow_valid() && !q->device_front_count()) {
+    // everything the FIFO holds was narrowed as it was pushed and all but the last stretch is on its way (or there)
+    flush_pending(q, m);
+    const size_t head = q->head_pos(), all = q->get_length();
+    const size_t lin = std::min(all, m.ringCap - head);
+    if (count <= lin) {
+      m.view = m.devRing + 2 * head;
+      m.viewCount = (uint32_t)lin;
+    } else { // the front wraps around the end of the ring: two device copies make it one plane
+      if (m.cap < all) {
+        sync();
+        if (m.dev) chk(blah2hip_ctx_free(ctx, m.dev), "DeviceContext: free");
+        m.dev = nullptr;
+        m.cap = 0;
+        void *d = nullptr;
+        chk(blah2hip_ctx_malloc(ctx, all * 2 * sizeof(float), &d), "DeviceContext: device plane");
+        m.dev = (float *)d;
+        m.cap = all;
+      }
+      chk(blah2hip_ctx_d2d(ctx, m.dev, m.devRing + 2 * head, lin * 2 * sizeof(float)), "DeviceContext: gather");
+      chk(blah2hip_ctx_d2d(ctx, m.dev + 2 * lin, m.devRing, (all - lin) * 2 * sizeof(float)), "DeviceContext: gather");
+      m.view = m.dev;
+      m.viewCount = (uint32_t)all;
+    }
+    m.gen = q->generation();
+    return m.view;
+  }
   // upload everything the FIFO holds: the next class asks for a little more or less of the same CPI
   const uint32_t all = q->get_length();
   if (q->device_front_count()) (void)q->get_data(); // device-only samples under a view we lost track of: bring them home first (rare)
@@ -124,6 +196,7 @@ const void *DeviceContext::resident(IqData *q, uint32_t count)
   m.view = m.dev;
   m.viewCount = all;
   m.gen = q->generation();
+  if (!m.tried) try_attach(q, m); // from the next CPI on the samples arrive narrowed and uploaded
   return m.view;
 }
 

@@ -6,6 +6,10 @@
 // Here a channel is narrowed (by a few threads, straight out of IqData's ring) into pinned staging and uploaded ONCE
 // per CPI; every class finds it resident as long as IqData::generation() has not moved; WienerHopf's output stays in
 // HBM as the new front of y (IqData::set_device_front) and is consumed there by Ambiguity.
+// From the second CPI of a FIFO on even that happens ahead of time: IqData::push_back narrows every sample into a
+// pinned shadow of its ring as it arrives (blah2.cpp:254-258 moves a CPI into x and y sample by sample right before
+// :264-287 runs) and every 256 k samples that stretch is sent to the same positions of a device ring, so the first
+// class finds the CPI resident and the sequence starts with kernels, not with 32 MB of narrowing and 32 MB of PCIe.
 // Built on the blah2hip_ctx_* part of the C ABI: no HIP headers on this side.
 #ifndef BLAH2HIP_HOST_DEVICECONTEXT_H
 #define BLAH2HIP_HOST_DEVICECONTEXT_H
@@ -61,7 +65,13 @@ private:
     size_t cap = 0;          // samples
     float *devFront = nullptr; // second plane: a filter's output for this channel
     size_t capFront = 0;
-    const float *view = nullptr; // what resident() hands out: dev or devFront, + offset
+    // eager path: a pinned fp32 shadow of the FIFO's ring, filled by IqData::push_back, and its device copy at the same
+    // positions, uploaded in stretches while the caller is still pushing
+    float *shadow = nullptr;
+    float *devRing = nullptr;
+    size_t ringCap = 0;      // samples; 0 = not attached
+    bool tried = false;      // attach attempted (capacity unbounded or too large: stays on the per-CPI path)
+    const float *view = nullptr; // what resident() hands out: dev, devRing or devFront, + offset
     uint32_t viewCount = 0;
     uint64_t gen = ~0ull;    // IqData::generation() the view belongs to
     void read(uint32_t first, uint32_t count, std::complex<double> *dst) override;
@@ -76,6 +86,9 @@ private:
   int uploadsSinceSync = 0;
   Mirror &mirror_of(IqData *q);
   float *staging(size_t samples);
+  void try_attach(IqData *q, Mirror &m);
+  void flush_pending(IqData *q, Mirror &m);
+  static void on_chunk(IqData *q, void *mirror);
 
   // worker threads
   std::vector<std::thread> workers;

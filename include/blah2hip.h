@@ -341,6 +341,7 @@ int blah2hip_ctx_malloc_host(blah2hip_ctx_t c, size_t bytes, void **hptr); /* pi
 int blah2hip_ctx_free_host(blah2hip_ctx_t c, void *hptr);
 int blah2hip_ctx_h2d(blah2hip_ctx_t c, void *dptr, const void *hptr, size_t bytes); /* enqueues on the stream */
 int blah2hip_ctx_d2h(blah2hip_ctx_t c, void *hptr, const void *dptr, size_t bytes); /* enqueues on the stream */
+int blah2hip_ctx_d2d(blah2hip_ctx_t c, void *dst, const void *src, size_t bytes);  /* enqueues on the stream */
 /* device pointers of a handle's internal results of the last blah2hip_amb_process_dev with NULL outputs:
  * map [max_batch][n_doppler][n_delay] complex fp32 and metrics [max_batch][2] doubles */
 int blah2hip_amb_result_ptrs(blah2hip_amb_t h, const void **d_map, const double **d_metrics);
