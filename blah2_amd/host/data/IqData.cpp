@@ -197,6 +197,7 @@ void IqData::keep_front(uint32_t cnt)
     sh.mirrored = sh.mirrored > gone ? sh.mirrored - gone : 0;
     sh.pend = sh.pend > gone ? sh.pend - gone : 0;
     count = cnt;
+    if (!ring.empty()) sh.pendStart = (head + count + ring.size() - sh.pend) % ring.size(); // the unreported stretch ends at the new back
   }
   if (devCount > count) devCount = (uint32_t)count;
   gen++;
