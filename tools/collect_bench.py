@@ -35,6 +35,8 @@ for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"bench_r{n}*.log"
                       "sat_rows": ("sat_rows_kernel",), "sat_cols": ("sat_cols_kernel",), "rotate": ("rotate_kernel",),
                       "clutter_corr": ("clutter_corr_half_kernel", "clutter_corr_kernel"), "clutter_fir": ("clutter_fir_kernel",),
                       "clutter_solve": ("clutter_solve_kernel",), "clutter_reduce": ("clutter_reduce_kernel",)}
+        rk = j["roofline"].get("kernel", "range_kernel")  # the range kernel this line ran, no other
+        prof_names["range"] = tuple(k for k in tj["kernels"] if k == rk or k.startswith(rk + "<"))
         for e in j["roofline"]["kernels"]:
             e.pop("traffic", None)
             e.pop("traffic_over_algorithmic", None)

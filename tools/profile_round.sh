@@ -39,6 +39,8 @@ python bench.py --config cfg3 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/ben
 python bench.py --config cfg3 --chain full --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_r3_cfg3_full.log 2>&1
 python bench.py --config cfg5 --fmt f16 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_r3_cfg5.log 2>&1
 python bench.py --config cfg5 --fmt f16 --batch 32 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_r3_cfg5_b32.log 2>&1
+python bench.py --fft-len 1024 --range-kernel wave1k --no-cpu-baseline > $OUT/bench_r3_w1k.log 2>&1
+python bench.py --config small --steps 40 --warmup 3 --no-cpu-baseline > $OUT/bench_r3_small.log 2>&1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_r3_torchrun.log 2>&1
 python tools/replay_bench.py --out $OUT/replay.json > $OUT/replay_bench.log 2>&1
 tail -qn 1 $OUT/bench_r3*.log | cut -c1-200
