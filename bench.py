@@ -257,9 +257,10 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0,
-                    help="CPIs per step (per GPU); default 128 for the 2 MS/s configs (4 GB of IQ per step: a pulse is "
-                         "the scheduling unit of the range kernel and 128 x 513 pulses leave a 1.5 %% tail on 1024 "
-                         "resident workgroups, 32 x 513 leave 6 %%); 32 for cfg3 (64 with --chain full), 8 for cfg5 -- "
+                    help="CPIs per step (per GPU); default 256 for the 2 MS/s configs (8 GB of fp32 IQ per step; 128 with --chain "
+                         "full: a pulse is the scheduling unit of the range kernel, and 256 x 513 pulses are 42.75 rounds of its "
+                         "3072 resident waves -- measured on one box: 98.8 k / 107.7 k / 110.3 k CPIs/s at 32 / 128 / 256); "
+                         "32 for cfg3 (128 with --chain full), 8 for cfg5 -- "
                          "measured: cfg3 93.9 / 88.8 / 84.7 us/CPI at 8 / 16 / 32, cfg5 142.8 / 138.4 / 138.8 at 4 / 8 / 16")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--fmt", default="c32", choices=["c32", "i16", "f16"])
@@ -308,7 +309,8 @@ def main(argv=None):
 
     cfg, cfg_desc = CONFIGS[a.config]
     dmin, dmax, fmin, fmax, fs, n = cfg
-    B = a.batch if a.batch > 0 else ({"cfg3": 128 if a.chain == "full" else 32, "cfg5": 8, "small": 1024}.get(a.config, 128))
+    B = a.batch if a.batch > 0 else ({"cfg3": 128 if a.chain == "full" else 32, "cfg5": 8, "small": 1024}.get(
+        a.config, 256 if a.chain == "amb" else 128))
     NS = max(1, a.streams) if a.chain == "amb" else 1
     ambs = [blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B, n_doppler_bins=a.n_doppler)
             for _ in range(NS)]
@@ -466,7 +468,9 @@ def main(argv=None):
     # passes of this same command (tools/summarize_prof.py -> profiles/*_traffic.json)
     traffic, traffic_src = None, None
     import glob
-    prof_names = {"range": ("rangew1k_kernel", "rangew2_kernel", "rangew_kernel", "range_kernel", "range8_kernel"), "doppler": ("doppler_",),
+    ran_range = {1: "range_kernel", 2: "range8_kernel", 3: "rangew_kernel", 4: "rangew2_kernel", 5: "rangew1k_kernel"}.get(
+        amb.info(blah2_amd._lib.INFO_LAST_RANGE_KERNEL), "range_kernel")
+    prof_names = {"range": (ran_range,), "doppler": ("doppler_",),  # the range kernel this run launched, no other
                   "metrics": ("metrics_kernel",), "cfar": ("cfar2d_tile_kernel", "cfar2d_kernel", "cfar1d_kernel"),
                   "sat_rows": ("sat_rows_kernel",), "sat_cols": ("sat_cols_kernel",), "rotate": ("rotate_kernel",),
                   "clutter_corr": ("clutter_corr_half_kernel", "clutter_corr_kernel"), "clutter_fir": ("clutter_fir_kernel",),

@@ -207,9 +207,12 @@ bool choose_plan(blah2hip_amb_s *h)
     // F = 1024: segments of exactly 9*64 samples when that costs no extra segment -- consecutive y' windows then overlap by
     // whole registers of the one-wave kernel, which carries them over instead of reading them again (kernels.hpp: REUSE)
     if (r3 == 4 && lmax >= 9 * 64 && (nCorr + 9 * 64 - 1) / (9 * 64) == nSeg) segLen = 9 * 64;
-    // measured on MI355X (round 2, forced lengths at three geometries): at equal butterfly count the
-    // F = 1024 kernel is ~3 % slower than the F = 2048 one
-    const double cost = (2.0 * nSeg + 1.0) * F * std::log2((double)F) * (r3 == 4 ? 1.03 : 1.0);
+    // measured on MI355X at equal butterfly count: the F = 1024 workgroup kernel (8 points per thread) is ~3 % slower than
+    // the F = 2048 kernels (round 2, forced lengths at three geometries); the F = 1024 ONE-WAVE kernel, which runs once a
+    // launch has a pulse for each of its wave slots, is 1-2 % faster than the F = 2048 one-wave kernel (round 3, cfg 2 x 128
+    // on four boxes, fp32 input; equal for int16)
+    const bool w1k = (int64_t)h->dims.max_batch * h->dims.n_doppler_bins >= (int64_t)4 * RANGEW1K_WAVES_PER_SIMD * h->numCU;
+    const double cost = (2.0 * nSeg + 1.0) * F * std::log2((double)F) * (r3 == 4 ? (w1k ? 0.985 : 1.03) : 1.0);
     if (cost < best) {
       best = cost;
       found = true;
@@ -694,12 +697,12 @@ int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler
   // samples per segment), each re-reading the pulse
   lag_chunks(h, 4081);
   if (h->chunks.size() > 1 || h->maxChunk > 4081) lag_chunks(h, 2048);
-  if (!choose_plan(h)) {
-    return fail(BLAH2HIP_ERR_UNSUPPORTED, "no on-chip transform length fits the lag window (forced length too short?)");
-  }
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
   h->numCU = prop.multiProcessorCount;
+  if (!choose_plan(h)) {
+    return fail(BLAH2HIP_ERR_UNSUPPORTED, "no on-chip transform length fits the lag window (forced length too short?)");
+  }
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 
   const uint32_t nD = h->dims.n_doppler_bins, nDelay = h->dims.n_delay_bins;

@@ -87,11 +87,14 @@ def test_cfg2_batched_takes_the_tile_kernel(b2, B):
     nD = 513 (all nine row groups, the k = 8 tail row, the row rotation by 257), and the range
     kernel's grid-stride loop reaches pulses of cpi > 0."""
     amb = run_batch(b2, CFG2, B, "auto", seeds=range(40, 40 + B), expect="tile8")
-    assert (amb.get_n_doppler_bins(), amb.get_n_delay_bins(), amb.dims.fft_len) == (513, 411, 2048)
     from blah2_amd import _lib
-    # F = 2048: the one-wave kernel once the launch has a pulse per wave slot (8 per CU), else the workgroup kernel
+    # a handle whose largest launch has a pulse for each of the 12 wave slots per CU of the 1024-point one-wave kernel
+    # plans F = 1024 for it (same butterfly count as F = 2048 here, measured 1-2 % faster); smaller ones F = 2048: the
+    # one-wave kernel from 8 pulses per CU on, else the workgroup kernel
+    w1k = B * 513 >= 12 * amb.info(_lib.INFO_NUM_CU)
+    assert (amb.get_n_doppler_bins(), amb.get_n_delay_bins(), amb.dims.fft_len) == (513, 411, 1024 if w1k else 2048)
     full = B * 513 >= 8 * amb.info(_lib.INFO_NUM_CU)
-    assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == (_lib.RANGE_WAVE if full else _lib.RANGE_E16)
+    assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == (_lib.RANGE_WAVE1K if w1k else _lib.RANGE_WAVE if full else _lib.RANGE_E16)
 
 
 @pytest.mark.parametrize("fmt", ["c32", "i16"])
@@ -191,7 +194,7 @@ def _expected_doppler(b2, geom):
     return "tilew2" if 2 * -(-d.n_delay_bins // 4) >= 128 else "column"
 
 
-@pytest.mark.parametrize("geom,fft_len", [(CFG2, 2048), ((-24, 2023, -64, 64, 1_260_000, 1_260_000), 4096),
+@pytest.mark.parametrize("geom,fft_len", [(CFG2, 2048), (CFG2, 1024), ((-24, 2023, -64, 64, 1_260_000, 1_260_000), 4096),
                                           ((-10, 100, -100, 100, 1_000_000, 100_000), 1024), ((-10, 400, -300, 200, 2_000_000, 1_000_000), 0)])
 def test_mixed_format_int16_reference_fp32_surveillance(b2, geom, fft_len):
     """BLAH2HIP_FMT_I16X_C32Y -- x from the .rspduo words, y from an fp32 plane (the ambiguity stage behind the int16
@@ -200,7 +203,7 @@ def test_mixed_format_int16_reference_fp32_surveillance(b2, geom, fft_len):
     import torch
     from blah2_amd import _lib
     dmin, dmax, fmin, fmax, fs, n = geom
-    B = 9 if fft_len == 2048 else 2  # nine CPIs of cfg 2 reach the one-wave kernel's launch size
+    B = 9 if geom == CFG2 else 2  # nine CPIs of cfg 2 reach the launch size of the one-wave kernels (F = 2048 and F = 1024)
     xs, ys = zip(*(O.synth_iq(n, seed=700 + c, fs=fs, targets=((37, -13.0, 0.05),)) for c in range(B)))
     iq = np.stack([np.stack([x.real, x.imag, y.real, y.imag], axis=-1) for x, y in zip(xs, ys)]).astype(np.int16)
     d_iq = torch.from_numpy(iq).cuda()
@@ -208,6 +211,8 @@ def test_mixed_format_int16_reference_fp32_surveillance(b2, geom, fft_len):
     dy = torch.from_numpy(np.stack(ys).astype(np.complex64)).cuda()
     st = torch.cuda.current_stream().cuda_stream
     amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, max_batch=B)
+    if fft_len:
+        amb.set_fft_len(fft_len)
     nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
     maps = []
     for fmt, px in ((b2.FMT_C32, dx), (b2.FMT_I16X_C32Y, d_iq)):
@@ -219,6 +224,8 @@ def test_mixed_format_int16_reference_fp32_surveillance(b2, geom, fft_len):
             assert amb.dims.fft_len == fft_len
     if fft_len == 2048:
         assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE
+    if geom == CFG2 and fft_len == 1024:
+        assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE1K
     assert np.array_equal(maps[0], maps[1])
     d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
     ref = O.ambiguity_process(d, xs[B - 1], ys[B - 1])

@@ -21,7 +21,7 @@ profile() { # tag, json description, bench args...
     timeout 400 rocprofv3 --kernel-trace --pmc $pass -d $OUT/prof/$tag/pmc_$ptag -o bench --output-format csv -- $B > $OUT/prof/$tag/pmc_$ptag.log 2>&1 || echo "pmc pass $pass failed ($tag)"
   done
 }
-PMC_EXTRA=1 profile amb '{"config": "cfg2", "batch": 128, "fmt": "c32", "chain": "amb"}' --steps 20 --warmup 5
+PMC_EXTRA=1 profile amb '{"config": "cfg2", "batch": 256, "fmt": "c32", "chain": "amb"}' --steps 12 --warmup 3
 PMC_EXTRA= profile full '{"config": "cfg2", "batch": 64, "fmt": "c32", "chain": "full"}' --chain full --batch 64 --steps 10 --warmup 3
 PMC_EXTRA= profile cfg3 '{"config": "cfg3", "batch": 32, "fmt": "c32", "chain": "amb"}' --config cfg3 --steps 10 --warmup 2 --prewarm-s 0.3
 PMC_EXTRA= profile cfg3_full '{"config": "cfg3", "batch": 128, "fmt": "c32", "chain": "full"}' --config cfg3 --chain full --steps 3 --warmup 1 --prewarm-s 0.3
