@@ -97,6 +97,19 @@ def test_more_delay_bins_than_one_transform_holds(b2):
         assert d.delay[3000 + j] == 4000  # the far target sits in the third chunk
 
 
+def test_lag_chunks_with_an_asymmetric_doppler_window(b2):
+    """Chunked lag windows behind the rotation of the reference channel about the Doppler centre (Ambiguity.cpp:95-102):
+    4301 delay bins in three chunks, Doppler limits -30 .. +10 Hz; and the aliased lags of a short-pulse geometry with
+    an off-centre window."""
+    run(b2, (-100, 4200, -30, 10, 400_000, 400_000, True), seed=5)
+    args = (-600, 10, -2048, 1024, 2_000_000, 1_000_000, True)
+    x, y = O.synth_iq(args[5], seed=22, fs=args[4], targets=((20, 600.0, 0.1), (-37, -200.0, 0.1)))
+    amb = b2.Ambiguity(*args)
+    m = amb.process(x, y)
+    ref = O.ambiguity_process(O.ambiguity_dims(*args), x, y)
+    assert np.abs(m.data.astype(np.complex128) - ref).max() / np.abs(ref).max() <= 1e-5
+
+
 @pytest.mark.parametrize("dmin,dmax", [(-10, 600), (-600, 10), (-700, 700), (-999, 999)])
 def test_lags_the_reference_aliases(b2, dmin, dmax):
     """Short pulses: 2049 pulses of 488 samples, nfft = 1000.  Delays beyond nfft - nCorr = 512 read, in the reference's
