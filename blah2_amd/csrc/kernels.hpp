@@ -1025,6 +1025,144 @@ __global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a, 
   }
 }
 
+// doppler_tile_kernel<16> on the one-wave 1024-point transform of fft_wave1k.hpp (round 3).  Same phases, same tile, same
+// results to rounding; what changes is what a thread carries.  The workgroup transform keeps its 31 stage twiddles in 62
+// registers per thread, which at four waves per SIMD (a 1024-thread workgroup) leaves room for nothing else: chirp
+// values, rotation targets and transposition addresses were recomputed from lane indices in every phase of every tile
+// -- 670 of the 1240 vector instructions per column were index arithmetic and selects, on a kernel whose SIMDs are 68 %
+// busy.  Wave1kFft reads its stage twiddles from a 7.5 KB table in LDS (fits beside the sixteen regions: 157 KB), so the
+// per-lane constants of the walk live in registers across the tiles: the chirp of this lane's nine rows (zero for rows
+// beyond nD, which also zeroes the padding rows without a select) and where each output row goes after the rotation by
+// nD/2 + 1.  One exchange per transform instead of two; the kernel spectrum in natural order (a.bfn).
+constexpr int DOPT1K_LDS_ELEMS = 16 * DOPT_PITCH + Wave1kFft::TW_ELEMS + 1024;
+__global__ __launch_bounds__(1024) void doppler_tile1k_kernel(DopplerArgs a, int nCpi)
+{
+  using K = Wave1kFft;
+  constexpr int NCOL = 16, T = 64, NR = 9, NT = 1024, SH = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double wsum[16];
+  __shared__ float wmax[16];
+  cf *lds = reinterpret_cast<cf *>(smem);
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, t = tid & 63; // wave = column of the tile
+  const int nD = a.nD;
+  cf *region = lds + w * DOPT_PITCH;
+  cf *table = lds + NCOL * DOPT_PITCH;
+  cf *bfL = table + K::TW_ELEMS;
+  const int tilesPerCpi = (a.nDelay + NCOL - 1) / NCOL;
+  const int nTilesAll = tilesPerCpi * nCpi;
+  const int cells = nD * NCOL;
+
+  // once per workgroup: tables, and this lane's constants
+  K::fill_table(tid, NT, a.tw, table);
+  bfL[tid] = a.bfn[tid];
+  K::Tw tw;
+  K::load_twiddles(t, a.tw, table, tw);
+  cf ch[NR];  // chirp of row t + 64 k; 0 beyond nD
+  int oidx[NR]; // where output row t + 64 k goes in the region: rotated by nD/2 + 1, or the spare slot
+  int ridx[NR]; // the input row, clamped (nD < 513: rows of the 9 x 64 that do not exist)
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    const int i = t + T * k;
+    ridx[k] = min(i, nD - 1);
+    const cf c = a.chirp[min(i, nD - 1)];
+    ch[k] = cmake(i < nD ? c.x : 0.f, i < nD ? c.y : 0.f);
+    int o = i - (nD / 2 + 1);
+    if (o < 0) o += nD;
+    oidx[k] = i < nD ? o : DOPT_PITCH - 1;
+  }
+
+  cf nt[NR];
+  auto tile_load = [&](int it) {
+    const int cpi = it / tilesPerCpi, sub = it - cpi * tilesPerCpi;
+    const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, sub * NCOL);
+    const int tl = relaunder(tid);
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+      const int idx = tl + NT * j; // the tile is contiguous: cell idx = row * 16 + column
+      nt[j] = Rt[idx < cells ? idx : 0];
+    }
+  };
+  int it = blockIdx.x;
+  if (it < nTilesAll) tile_load(it);
+  __syncthreads(); // tables
+  for (; it < nTilesAll; it += gridDim.x) {
+    const int cpi = it / tilesPerCpi, sub = it - cpi * tilesPerCpi;
+    const int col0 = sub * NCOL;
+    // phase 1: the tile, transposed into the per-column regions
+    {
+      const int tl = relaunder(tid);
+      cf *dst = lds + (tl & (NCOL - 1)) * DOPT_PITCH + (tl >> SH); // idx + 1024 j: same column, row + 64 j
+#pragma unroll
+      for (int j = 0; j < NR; j++)
+        if (tl + NT * j < cells) dst[T * j] = nt[j];
+    }
+    __syncthreads();
+
+    // phase 2: this wave's column -> registers (DC removal + chirp), next tile's loads, both transforms
+    cf v[16];
+    const cf r0 = region[0];
+#pragma unroll
+    for (int k = 0; k < NR; k++) v[k] = cmul(csub(region[ridx[k]], r0), ch[k]); // rows beyond nD: a valid cell times 0
+    if (it + (int)gridDim.x < nTilesAll) tile_load(it + gridDim.x);
+    __builtin_amdgcn_wave_barrier();
+    K::transform<-1, 9>(t, v, tw, region);
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = cmul(v[e], bfL[e * T + t]);
+    __builtin_amdgcn_wave_barrier();
+    K::transform<+1>(t, v, tw, region);
+    __builtin_amdgcn_wave_barrier();
+
+    // phase 3: chirp, rotate rows by nD/2 + 1, park the column back in its region
+    {
+#pragma unroll
+      for (int c = 0; c < NR; c++) {
+        cf d = cmul(v[c], ch[c]);
+        if (c == 0 && t == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
+        region[oidx[c]] = d;
+      }
+    }
+    __syncthreads();
+
+    // phase 4: coalesced row-segment stores + Map::set_metrics partials
+    double lsum = 0.0;
+    float lmax = 0.f;
+    cf *mapb = a.map + (size_t)cpi * nD * a.nDelay + col0;
+    const int ncol = min(NCOL, a.nDelay - col0);
+    {
+      const int tl = relaunder(tid);
+      const int c = tl & (NCOL - 1), o0 = tl >> SH;
+      const cf *src = lds + c * DOPT_PITCH + o0;
+      cf *dstg = mapb + (size_t)o0 * a.nDelay + c;
+      const size_t gstep = (size_t)T * a.nDelay;
+#pragma unroll
+      for (int j = 0; j < NR; j++) {
+        const bool ok = tl + NT * j < cells && c < ncol;
+        const cf d = src[min(T * j, nD - 1 - o0)];
+        if (ok) dstg[gstep * j] = d;
+        const float db = db_of(d);
+        lsum += ok ? (double)db : 0.0;
+        lmax = ok ? fmaxf(lmax, db) : lmax;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lsum += __shfl_xor(lsum, off);
+      lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    }
+    if (t == 0) { const int wl = relaunder(tid) >> 6; wsum[wl] = lsum; wmax[wl] = lmax; }
+    __syncthreads(); // also: every thread has taken its rows out of the regions
+    if (tid == 0) {
+      double sacc = 0.0;
+      float m = 0.f; // Map.cpp:193: the running max starts at 0
+      for (int i = 0; i < NCOL; i++) { sacc += wsum[i]; m = fmaxf(m, wmax[i]); }
+      const size_t part = (size_t)cpi * tilesPerCpi + sub;
+      a.partSum[part] = sacc;
+      a.partMax[part] = m;
+    }
+  }
+}
+
 // Tile variant for 513 < nD <= 1025 on the ONE-WAVE 2048-point transform (fft_wave.hpp): the phases of
 // doppler_tile_kernel<8> with one wave per column doing both transforms of the chirp-z convolution in
 // its own exchange region (which is also the column's staging area), no barrier between the tile

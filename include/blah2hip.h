@@ -144,12 +144,13 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 #define BLAH2HIP_CFAR2D_SAT 2
 #define BLAH2HIP_DOP_AUTO 0
 #define BLAH2HIP_DOP_TILE8 1   /* nD <= 513: 8-column tiles, one wave per column */
-#define BLAH2HIP_DOP_TILE16 2  /* nD <= 513: 16-column tiles */
+#define BLAH2HIP_DOP_TILE16 2  /* nD <= 513: 16-column tiles, one wave per column on the one-wave 1024-point transform */
 #define BLAH2HIP_DOP_TILEM 3   /* 513 < nD <= 2049: multi-wave columns, 8 or 4 per workgroup */
 #define BLAH2HIP_DOP_COLUMN 4  /* nD <= 2049: one column per workgroup (small launches) */
 #define BLAH2HIP_DOP_DIRECT 5  /* any nD: direct DFT */
 #define BLAH2HIP_DOP_TILEW 6   /* 513 < nD <= 1025: one-wave 2048-point columns, 8 per workgroup */
 #define BLAH2HIP_DOP_TILEW2 7  /* 1025 < nD <= 2049: two-wave 4096-point columns, 4 per workgroup */
+#define BLAH2HIP_DOP_TILE16WG 8 /* TILE16 on the workgroup transform of rounds 1-2 (twiddles in registers; kept for comparison) */
 #define BLAH2HIP_RANGE_E16 1   /* 16 points per thread, one workgroup per pulse (F = 4096; F = 2048 on request) */
 #define BLAH2HIP_RANGE_E8 2    /* 8 points per thread, last stage across lanes (F = 1024) */
 #define BLAH2HIP_RANGE_WAVE 3  /* one wave per pulse, 32 points per lane, no barriers (F = 2048) */

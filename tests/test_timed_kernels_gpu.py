@@ -310,3 +310,13 @@ def test_f1024_kernels_agree(b2):
         assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == k
         maps.append(out.cpu().numpy())
     assert np.abs(maps[0] - maps[1]).max() / np.abs(maps[0]).max() <= 5e-7
+
+
+def test_tile16_on_both_transforms(b2):
+    """The 16-column Doppler tile kernel on the one-wave 1024-point transform (the default: chirp, rotation targets and row
+    indices carried in registers across the tiles) against the workgroup-transform version it replaced: same maps to
+    rounding, both against the oracle, at nD = 513 and at a short, even Doppler length (rows that do not exist)."""
+    for geom, B in ((CFG2, 10), ((-10, 400, -50, 50, 300_000, 300_000), 12)):
+        a = run_batch(b2, geom, B, "tile16", seeds=range(500, 500 + B))
+        b = run_batch(b2, geom, B, "tile16wg", seeds=range(500, 500 + B))
+        assert a.last_doppler_kernel() == "tile16" and b.last_doppler_kernel() == "tile16wg"
