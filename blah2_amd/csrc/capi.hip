@@ -466,7 +466,7 @@ template <class In> int launch_rangew1k_t(blah2hip_amb_s *h, const RangeArgs &a,
     HIPCHK(hipMemcpy(hcnt, dbg, 48, hipMemcpyDeviceToHost));
     double tot = 0;
     for (int k = 0; k < 6; k++) tot += (double)hcnt[k];
-    fprintf(stderr, "[rangew1k trace] grid %d pulses %d: other %.3f load %.3f X %.3f Y %.3f inv %.3f store %.3f of %.0f ticks/wave\n", grid, a.nPulses,
+    fprintf(stderr, "[rangew1k trace] grid %d pulses %d: loop %.3f wait-x %.3f X %.3f wait-y %.3f Y+product %.3f inverse+store %.3f of %.0f ticks/wave\n", grid, a.nPulses,
             hcnt[0] / tot, hcnt[1] / tot, hcnt[2] / tot, hcnt[3] / tot, hcnt[4] / tot, hcnt[5] / tot, tot / grid / RANGEW1K_WAVES);
   }
 #else

@@ -504,6 +504,9 @@ __global__ __launch_bounds__(64 * RANGEW1K_WAVES, RANGEW1K_WAVES_PER_SIMD) void 
   for (int e = 0; e < 16; e++) acc[e] = cmake(0.f, 0.f);
   w1k_issue_x<In, NX>(in, p, base, 0, t, true, rx);
   w1k_issue_y<In>(in, p, base, 0, t, true, ry);
+#ifdef RANGEW_TRACE // buckets: 0 loop bookkeeping, 1 wait x, 2 issue x + X transform, 3 wait y, 4 Y transform + product + issue y, 5 inverse + stores
+  uint64_t tr[6] = {0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime();
+#endif
   for (;;) {
     // the segment after this one (wave-uniform)
     int ns = s + 1, npulse = pulse, ncpi = cpi, ni = i;
@@ -517,15 +520,28 @@ __global__ __launch_bounds__(64 * RANGEW1K_WAVES, RANGEW1K_WAVES_PER_SIMD) void 
     }
     const bool more = npulse < a.nPulses;
     cf v[16];
+    RW_T(0)
 #pragma unroll
     for (int k = 0; k < NX; k++) v[k] = RX::cvt(rx[k]);
+#ifdef RANGEW_TRACE
+    asm volatile("" : "+v"(v[0].x), "+v"(v[NX - 1].y)); // the wait for x ends here
+#endif
+    RW_T(1)
     __builtin_amdgcn_sched_barrier(0);
     w1k_issue_x<In, NX>(in, p, nbase, ns, t, more, rx);
     __builtin_amdgcn_sched_barrier(0);
     W::transform<-1, NX>(t, v, w, X); // v = X spectrum
+#ifdef RANGEW_TRACE
+    asm volatile("" : "+v"(v[0].x));
+#endif
+    RW_T(2)
     cf yv[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) yv[k] = RY::cvt(ry[k]);
+#ifdef RANGEW_TRACE
+    asm volatile("" : "+v"(yv[0].x), "+v"(yv[15].y)); // the wait for y ends here
+#endif
+    RW_T(3)
     typename RY::raw carry[7];
     if constexpr (REUSE) {
 #pragma unroll
@@ -547,10 +563,23 @@ __global__ __launch_bounds__(64 * RANGEW1K_WAVES, RANGEW1K_WAVES_PER_SIMD) void 
       w1k_issue_y<In>(in, p, nbase, ns, t, more, ry);
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef RANGEW_TRACE
+    asm volatile("" : "+v"(acc[0].x));
+#endif
+    RW_T(4)
     if (ns == 0) { // the pulse is complete
       W::template transform<+1, 16, OUT7>(t, acc, w, X);
       store_lags_w<OUT7 ? 7 : 16>(a.out, p, cpi, i, t, acc);
+#ifdef RANGEW_TRACE
+      RW_T(5)
+      if (!more) {
+        if (t == 0 && a.dbg)
+          for (int k = 0; k < 6; k++) atomicAdd((unsigned long long *)&a.dbg[k], (unsigned long long)tr[k]);
+        break;
+      }
+#else
       if (!more) break;
+#endif
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[e] = cmake(0.f, 0.f);
       pulse = npulse;
