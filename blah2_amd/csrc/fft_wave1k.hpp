@@ -66,6 +66,25 @@ template <int SIGN> B2_HD void dft16_out7(cf *v)
   for (int k = 0; k < 7; k++) v[k] = o[k];
 }
 
+// 4-point DFT from four values that stay untouched (separate single-instruction statements: the compiler is free to put
+// the results elsewhere) -- the first step of a transform whose raw inputs are still wanted afterwards
+template <int SIGN> B2_HD void dft4_nd(cf &o0, cf &o1, cf &o2, cf &o3, cf a0, cf a1, cf a2, cf a3)
+{
+  const cf t0 = cadd(a0, a2), t1 = csub(a0, a2);
+  const cf t2 = cadd(a1, a3), d = csub(a1, a3);
+  o0 = cadd(t0, t2);
+  o1 = cadd_i<SIGN>(t1, d);
+  o2 = csub(t0, t2);
+  o3 = csub_i<SIGN>(t1, d);
+}
+// 16-point DFT of in[0..16) into out[0..16); `in` is not written
+template <int SIGN> B2_HD void dft16_nd(cf *out, const cf *in)
+{
+#pragma unroll
+  for (int n0 = 0; n0 < 4; n0++) dft4_nd<SIGN>(out[n0], out[n0 + 4], out[n0 + 8], out[n0 + 12], in[n0], in[n0 + 4], in[n0 + 8], in[n0 + 12]);
+  dft16_tail<SIGN>(out);
+}
+
 struct Wave1kFft {
   static constexpr int F = 1024;
   static constexpr int L = 64;  // lanes
@@ -181,7 +200,24 @@ struct Wave1kFft {
     else dft16<SIGN>(v);
   }
 
+  // S1 out of place: out = the 16-point DFT of `in` times the stage twiddles; `in` keeps its values
+  template <int SIGN> B2_HD static void s1_nd(cf *out, const cf *in, const Tw &w)
+  {
+    dft16_nd<SIGN>(out, in);
+#pragma unroll
+    for (int q = 1; q < 16; q++) out[q] = twid<SIGN>(out[q], w.tab[(q - 1) * 64]);
+  }
+
 #if defined(__HIPCC__)
+  // everything after S1
+  template <int SIGN, bool OUT7 = false> __device__ __forceinline__ static void finish(int t, cf *v, const Tw &w, cf *X)
+  {
+    sw32(v);
+    b1<SIGN>(v, w);
+    sw16(v);
+    b2<SIGN>(t, v, w, X);
+    s3<SIGN, OUT7>(t, v, X);
+  }
   template <int SIGN, int NZ = 16, bool OUT7 = false> __device__ __forceinline__ static void transform(int t, cf *v, const Tw &w, cf *X)
   {
     s1<SIGN, NZ>(v, w);

@@ -527,34 +527,34 @@ __global__ __launch_bounds__(64 * RANGEW1K_WAVES, RANGEW1K_WAVES_PER_SIMD) void 
     asm volatile("" : "+v"(v[0].x), "+v"(v[NX - 1].y)); // the wait for x ends here
 #endif
     RW_T(1)
+    // the first steps of the transform read the raw registers and write new ones; only then is the next x requested into
+    // them -- requested before, the compiler has to copy the 18 registers out of the loads' way
+    W::s1<-1, NX>(v, w);
     __builtin_amdgcn_sched_barrier(0);
     w1k_issue_x<In, NX>(in, p, nbase, ns, t, more, rx);
     __builtin_amdgcn_sched_barrier(0);
-    W::transform<-1, NX>(t, v, w, X); // v = X spectrum
+    W::finish<-1>(t, v, w, X); // v = X spectrum
 #ifdef RANGEW_TRACE
     asm volatile("" : "+v"(v[0].x));
 #endif
     RW_T(2)
-    cf yv[16];
+    cf yin[16], yv[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) yv[k] = RY::cvt(ry[k]);
+    for (int k = 0; k < 16; k++) yin[k] = RY::cvt(ry[k]);
 #ifdef RANGEW_TRACE
-    asm volatile("" : "+v"(yv[0].x), "+v"(yv[15].y)); // the wait for y ends here
+    asm volatile("" : "+v"(yin[0].x), "+v"(yin[15].y)); // the wait for y ends here
 #endif
     RW_T(3)
-    typename RY::raw carry[7];
-    if constexpr (REUSE) {
-#pragma unroll
-      for (int k = 0; k < 7; k++) carry[k] = ry[9 + k];
-    }
-    W::transform<-1, 16>(t, yv, w, X); // yv = Y spectrum
+    // out of place: the raw registers 9..15 are the next window's 0..6 (REUSE) and stay where they are
+    W::s1_nd<-1>(yv, yin, w);
+    W::finish<-1>(t, yv, w, X); // yv = Y spectrum
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[e] = cmacc(acc[e], yv[e], v[e]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (REUSE) {
       if (ns != 0) {
 #pragma unroll
-        for (int k = 0; k < 7; k++) ry[k] = carry[k];
+        for (int k = 0; k < 7; k++) ry[k] = ry[9 + k];
         w1k_issue_y<In, 7>(in, p, nbase, ns, t, more, ry);
       } else {
         w1k_issue_y<In>(in, p, nbase, ns, t, more, ry);
