@@ -14,6 +14,7 @@
 #include "process/detection/Interpolate.h"
 #include "process/meta/HammingNumber.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -215,7 +216,10 @@ static void sequence_at_cfg2()
 {
   {
     const uint32_t fs2 = 2000000, n2 = 2000000;
-    const int nCpi = 8, nWarm = 3; // CPI 0 attaches the eager path; the first device-to-host copy after its uploads began (CPI 1 or 2) takes 7 ms, once per process
+    // CPI 0 attaches the eager path.  One device-to-host copy in the first few CPIs after its uploads began takes 7 ms, once
+    // per process (the runtime growing a pool, by the look of it): the stage times are MEDIANS over the timed CPIs, every
+    // CPI's total is printed
+    const int nCpi = 10, nWarm = 2;
     SpectrumAnalyser spectrumAnalyser(n2, 2000);
     WienerHopf filter(-10, 400, n2);
     Ambiguity ambiguity(-10, 400, -256, 256, fs2, n2, true);
@@ -224,7 +228,7 @@ static void sequence_at_cfg2()
     std::mt19937 gen(5);
     std::uniform_int_distribution<int> u(-300, 300);
     std::vector<std::complex<double>> xs(n2);
-    double t_seq = 0, t_part[5] = {0, 0, 0, 0, 0};
+    std::vector<double> seqs, parts[5];
     size_t nDet = 0;
     std::vector<std::complex<double>> ysv(n2);
     double t_cut = 0;
@@ -246,7 +250,7 @@ static void sequence_at_cfg2()
       auto tic = std::chrono::steady_clock::now();
       auto lap = [&](int k) {
         const auto now = std::chrono::steady_clock::now();
-        if (c >= nWarm) t_part[k] += std::chrono::duration<double, std::milli>(now - tic).count();
+        if (c >= nWarm) parts[k].push_back(std::chrono::duration<double, std::milli>(now - tic).count());
         tic = now;
       };
       const auto t0 = tic;
@@ -255,7 +259,7 @@ static void sequence_at_cfg2()
       auto map = ambiguity.process(&x, &y); lap(2);   // :278
       map->set_metrics(); lap(3);                     // :279
       auto det = cfar.process(map); lap(4);           // :285
-      if (c >= nWarm) t_seq += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (c >= nWarm) seqs.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       nDet = det->get_nDetections();
       bool found = false;
       for (size_t i = 0; i < nDet; i++)
@@ -263,10 +267,13 @@ static void sequence_at_cfg2()
       CHECK(found);
       CHECK(x.get_length() == n2 - ambiguity.get_n_samples());
     }
+    auto median = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     std::printf("sequence blah2.cpp:264-287 at 2 MS/s x 1 s (Spectrum, WienerHopf 410 taps, Ambiguity 513 x 411, set_metrics, CFAR): "
                 "%.2f ms/CPI  [spectrum %.2f, filter %.2f, ambiguity %.2f, set_metrics %.2f, cfar %.2f]; %zu detections\n",
-                t_seq / (nCpi - nWarm), t_part[0] / (nCpi - nWarm), t_part[1] / (nCpi - nWarm), t_part[2] / (nCpi - nWarm),
-                t_part[3] / (nCpi - nWarm), t_part[4] / (nCpi - nWarm), nDet);
+                median(seqs), median(parts[0]), median(parts[1]), median(parts[2]), median(parts[3]), median(parts[4]), nDet);
+    std::printf("  (medians of %zu CPIs; each CPI:", seqs.size());
+    for (double v : seqs) std::printf(" %.2f", v);
+    std::printf(" ms)\n");
     std::printf("cut blah2.cpp:254-258 (2 x %u push_back, narrowing + eager upload inside): %.2f ms/CPI\n", n2, t_cut / (nCpi - nWarm));
   }
   // the eager path (samples narrowed and uploaded as they are pushed) against the per-CPI path, also with a front that
