@@ -135,4 +135,40 @@ __device__ __forceinline__ void bufload_chan(typename Chan::raw *r, b2_v4i d, co
   }
 }
 
+// ---- the same through the compiler's builtins ---------------------------------------------------
+// For kernels that keep loads in flight across other work (the prefetching range kernel) or mix loads and stores
+// freely: the compiler counts these itself, so the waits between issue and use are its own.
+typedef unsigned b2_v2u __attribute__((ext_vector_type(2)));
+template <class Chan> struct RawBuiltin;
+template <> struct RawBuiltin<ChanC32> {
+  using raw = b2_v2u;
+  static __device__ __forceinline__ raw ld(__amdgpu_buffer_rsrc_t d, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b64(d, voff, soff, 0); }
+  static __device__ __forceinline__ cf cvt(raw r) { return cmake(__uint_as_float(r.x), __uint_as_float(r.y)); } // not __builtin_bit_cast on a vector element: this clang reads element 0 for both
+};
+template <> struct RawBuiltin<ChanI16> {
+  using raw = unsigned;
+  static __device__ __forceinline__ raw ld(__amdgpu_buffer_rsrc_t d, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(d, voff, soff, 0); }
+  static __device__ __forceinline__ cf cvt(raw r) { return ChanI16::cvt(r); }
+};
+template <> struct RawBuiltin<ChanF16> {
+  using raw = unsigned;
+  static __device__ __forceinline__ raw ld(__amdgpu_buffer_rsrc_t d, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(d, voff, soff, 0); }
+  static __device__ __forceinline__ cf cvt(raw r) { return ChanF16::cvt(r); }
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_b(const void *base, int bytes)
+{
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(u), (short)0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+// complex fp32 store; out-of-range offsets (negative included) are dropped by the range check
+__device__ __forceinline__ void bufstore_c32(__amdgpu_buffer_rsrc_t d, int voff, cf v)
+{
+  b2_v2u r;
+  r.x = __float_as_uint(v.x);
+  r.y = __float_as_uint(v.y);
+  __builtin_amdgcn_raw_buffer_store_b64(r, d, voff, 0, 0);
+}
+
 } // namespace blah2

@@ -31,6 +31,7 @@
 #include "blah2hip.h"
 #include "fft_wg.hpp"
 #include "range_core.hpp"
+#include "bufload.hpp"
 #include "timing.hpp"
 
 #include <algorithm>
@@ -113,6 +114,17 @@ template <> struct ChanOf<InI16> {
   using type = I16Chan;
   static __device__ __forceinline__ type x(const void *px, const void *, int64_t i) { return I16Chan{(const int16_t *)px + 4 * i}; }
   static __device__ __forceinline__ type y(const void *px, const void *, int64_t i) { return I16Chan{(const int16_t *)px + 4 * i + 2}; }
+};
+
+// one channel of a CPI as the raw-buffer channel type of bufload.hpp (sample stride, raw word, conversion)
+template <class In> struct BufChanOf;
+template <> struct BufChanOf<InC32> {
+  using Y = ChanC32;
+  static __device__ __forceinline__ const void *y(const void *, const void *py, int64_t i) { return (const cf *)py + i; }
+};
+template <> struct BufChanOf<InI16> {
+  using Y = ChanI16;
+  static __device__ __forceinline__ const void *y(const void *px, const void *, int64_t i) { return (const int16_t *)px + 4 * i + 2; }
 };
 
 struct CorrArgs {
@@ -568,10 +580,16 @@ template <int R3, class In> __global__ __launch_bounds__(16 * R3, 2) void clutte
       const bool inr = src >= 0 && src < N;
       const cf xv = X[xs_index(inr ? (uint32_t)src : 0u, a.xs)];
       v[k] = inr ? xv : cmake(0.f, 0.f);
-      // y of the output sample this register will end up holding (n = src)
-      const bool outv = (m >= hist) && (m < hist + a.segLen) && (src < N);
-      yv[k] = Y[outv ? src : 0];
     }
+    // y of the output samples, and later the stores: descriptors over exactly this block's new samples [n0, n0 + min(segLen,
+    // N - n0)), register k at offset m - hist -- history rows (negative) and rows beyond the block are outside the range, so
+    // the loads return zeros that are never stored and the stores are dropped: no predicate, no branch per element
+    const int cnt = min(a.segLen, N - n0);
+    using CY = typename BufChanOf<In>::Y;
+    const __amdgpu_buffer_rsrc_t yd = make_rsrc_b(BufChanOf<In>::y(a.x, a.y, (int64_t)cpi * a.cpiStride + n0), cnt * CY::STRIDE);
+    const __amdgpu_buffer_rsrc_t od = make_rsrc_b(O + n0, cnt * 8);
+#pragma unroll
+    for (int k = 0; k < 16; k++) yv[k] = RawBuiltin<CY>::cvt(RawBuiltin<CY>::ld(yd, (t + T * k - hist) * CY::STRIDE, 0));
     if (ok) {
       W::fwd_s1(t, v, tw1, P);
       __syncthreads();
@@ -589,12 +607,7 @@ template <int R3, class In> __global__ __launch_bounds__(16 * R3, 2) void clutte
       __syncthreads();
     }
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
-      const int m = t + T * c;
-      const int n = n0 + (m - hist);
-      if (m >= hist && m < hist + a.segLen && n < N)
-        O[n] = ok ? csub(yv[c], v[c]) : yv[c]; // not PD: surveillance channel passes through
-    }
+    for (int c = 0; c < 16; c++) bufstore_c32(od, (t + T * c - hist) * 8, ok ? csub(yv[c], v[c]) : yv[c]); // not PD: surveillance channel passes through
   }
 }
 

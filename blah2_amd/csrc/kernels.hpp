@@ -408,30 +408,6 @@ __global__ __launch_bounds__(64 * RANGEW_WAVES, RANGEW_WAVES_PER_SIMD) void rang
 #ifndef RANGEW1K_WAVES
 #define RANGEW1K_WAVES 12
 #endif
-typedef unsigned b2_v2u __attribute__((ext_vector_type(2)));
-template <class Chan> struct RawBuiltin;
-template <> struct RawBuiltin<ChanC32> {
-  using raw = b2_v2u;
-  static __device__ __forceinline__ raw ld(__amdgpu_buffer_rsrc_t d, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b64(d, voff, soff, 0); }
-  static __device__ __forceinline__ cf cvt(raw r) { return cmake(__uint_as_float(r.x), __uint_as_float(r.y)); } // not __builtin_bit_cast on a vector element: this clang reads element 0 for both
-};
-template <> struct RawBuiltin<ChanI16> {
-  using raw = unsigned;
-  static __device__ __forceinline__ raw ld(__amdgpu_buffer_rsrc_t d, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(d, voff, soff, 0); }
-  static __device__ __forceinline__ cf cvt(raw r) { return ChanI16::cvt(r); }
-};
-template <> struct RawBuiltin<ChanF16> {
-  using raw = unsigned;
-  static __device__ __forceinline__ raw ld(__amdgpu_buffer_rsrc_t d, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(d, voff, soff, 0); }
-  static __device__ __forceinline__ cf cvt(raw r) { return ChanF16::cvt(r); }
-};
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_b(const void *base, int bytes)
-{
-  const uint64_t a = reinterpret_cast<uint64_t>(base);
-  const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) |
-                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(u), (short)0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
 // x' of segment s: rx[k] = x'[t + 64*k], k < NX; `live` false: nothing is read (zero records)
 template <class In, int NX>
 __device__ __forceinline__ void w1k_issue_x(const In &in, const RangePlan &p, int64_t pulseBase, int s, int t, bool live,
