@@ -119,13 +119,28 @@ template <> struct ChanOf<InI16> {
 // one channel of a CPI as the raw-buffer channel type of bufload.hpp (sample stride, raw word, conversion)
 template <class In> struct BufChanOf;
 template <> struct BufChanOf<InC32> {
+  using X = ChanC32;
   using Y = ChanC32;
+  static __device__ __forceinline__ const void *x(const void *px, const void *, int64_t i) { return (const cf *)px + i; }
   static __device__ __forceinline__ const void *y(const void *, const void *py, int64_t i) { return (const cf *)py + i; }
 };
 template <> struct BufChanOf<InI16> {
+  using X = ChanI16;
   using Y = ChanI16;
+  static __device__ __forceinline__ const void *x(const void *px, const void *, int64_t i) { return (const int16_t *)px + 4 * i; }
   static __device__ __forceinline__ const void *y(const void *px, const void *, int64_t i) { return (const int16_t *)px + 4 * i + 2; }
 };
+// Does the window [src0, src0 + F) of the shifted reference channel map to ONE contiguous run of x, and where does it
+// start?  xs_index is i - sub from `thresh` on (then mod N): contiguous unless the window starts before `thresh` (or
+// before sample 0) or runs over the end of the CPI, which only the first and last windows of a CPI do.  *cnt = the samples
+// of the window that exist (src < N); the rest is zero padding.
+__device__ __forceinline__ bool xs_window_plain(int src0, int F, const XsMap &m, uint32_t *j0, int *cnt)
+{
+  const int64_t left = (int64_t)m.N - src0;
+  *cnt = (int)(left < F ? (left < 0 ? 0 : left) : F);
+  *j0 = (uint32_t)src0 - m.sub;
+  return src0 >= 0 && (uint32_t)src0 >= m.thresh && (uint64_t)*j0 + (uint32_t)*cnt <= m.N;
+}
 
 struct CorrArgs {
   const void *x, *y; // InC32: the two planes; InI16: x = the interleaved buffer, y unused
@@ -573,13 +588,22 @@ template <int R3, class In> __global__ __launch_bounds__(16 * R3, 2) void clutte
     const int g = sw.base + r;
     const int n0 = g * a.segLen;
     cf v[16], yv[16];
+    uint32_t j0;
+    int xcnt;
+    if (xs_window_plain(n0 - hist, 16 * T, a.xs, &j0, &xcnt)) { // all but the first and last windows of a CPI
+      using CX = typename BufChanOf<In>::X;
+      const __amdgpu_buffer_rsrc_t xd = make_rsrc_b(BufChanOf<In>::x(a.x, a.y, (int64_t)cpi * a.cpiStride + j0), xcnt * CX::STRIDE);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const int m = t + T * k;
-      const int src = n0 - hist + m;
-      const bool inr = src >= 0 && src < N;
-      const cf xv = X[xs_index(inr ? (uint32_t)src : 0u, a.xs)];
-      v[k] = inr ? xv : cmake(0.f, 0.f);
+      for (int k = 0; k < 16; k++) v[k] = RawBuiltin<CX>::cvt(RawBuiltin<CX>::ld(xd, (t + T * k) * CX::STRIDE, 0));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const int m = t + T * k;
+        const int src = n0 - hist + m;
+        const bool inr = src >= 0 && src < N;
+        const cf xv = X[xs_index(inr ? (uint32_t)src : 0u, a.xs)];
+        v[k] = inr ? xv : cmake(0.f, 0.f);
+      }
     }
     // y of the output samples, and later the stores: descriptors over exactly this block's new samples [n0, n0 + min(segLen,
     // N - n0)), register k at offset m - hist -- history rows (negative) and rows beyond the block are outside the range, so
