@@ -179,11 +179,25 @@ template <int R3, class In> __global__ __launch_bounds__(16 * R3, 2) void clutte
     const uint32_t n0 = (uint32_t)g * (uint32_t)a.segLen;
     // all 32 loads of the segment first (the y window is consumed last)
     cf v[16], wv[16], yw[16];
+    uint32_t j0;
+    int xcnt;
+    const bool whole = (uint64_t)n0 + 16 * T <= a.N; // the window does not run around the end of the CPI
+    if (whole && xs_window_plain((int)n0, 16 * T, a.xs, &j0, &xcnt)) { // all but a CPI's first and last windows: immediates only
+      using CX = typename BufChanOf<In>::X;
+      using CY = typename BufChanOf<In>::Y;
+      const __amdgpu_buffer_rsrc_t xd = make_rsrc_b(BufChanOf<In>::x(a.x, a.y, (int64_t)cpi * a.cpiStride + j0), 16 * T * CX::STRIDE);
+      const __amdgpu_buffer_rsrc_t yd = make_rsrc_b(BufChanOf<In>::y(a.x, a.y, (int64_t)cpi * a.cpiStride + n0), 16 * T * CY::STRIDE);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const uint32_t nw = wrapN(n0 + (uint32_t)(t + T * k), a.N); // circular window index, n0 + m < N + F
-      wv[k] = X[xs_index(nw, a.xs)];                      // xs window (mode r)
-      yw[k] = Y[nw];                                      // y window (mode b)
+      for (int k = 0; k < 16; k++) wv[k] = RawBuiltin<CX>::cvt(RawBuiltin<CX>::ld(xd, (t + T * k) * CX::STRIDE, 0));
+#pragma unroll
+      for (int k = 0; k < 16; k++) yw[k] = RawBuiltin<CY>::cvt(RawBuiltin<CY>::ld(yd, (t + T * k) * CY::STRIDE, 0));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const uint32_t nw = wrapN(n0 + (uint32_t)(t + T * k), a.N); // circular window index, n0 + m < N + F
+        wv[k] = X[xs_index(nw, a.xs)];                      // xs window (mode r)
+        yw[k] = Y[nw];                                      // y window (mode b)
+      }
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -280,25 +294,33 @@ template <int R3, class In> __global__ __launch_bounds__(16 * R3, 2) void clutte
     __syncthreads();
   };
   // first L samples of a zero-padded window starting at sample n0 of xs / of y (zero beyond N)
+  // Through buffer descriptors over exactly the `len` samples: the range check is the zero padding.  xs is read that
+  // way where the stretch maps to one contiguous run of x (xs_window_plain: everywhere but at a CPI's ends).
+  using CX = typename BufChanOf<In>::X;
+  using CY = typename BufChanOf<In>::Y;
   auto load_xs = [&](uint32_t n0, uint32_t len, cf *v) {
+    uint32_t j0;
+    int cnt;
+    if (xs_window_plain((int)n0, (int)len, a.xs, &j0, &cnt) && cnt == (int)len) {
+      const __amdgpu_buffer_rsrc_t d = make_rsrc_b(BufChanOf<In>::x(a.x, a.y, (int64_t)cpi * a.cpiStride + j0), (int)len * CX::STRIDE);
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const uint32_t m = (uint32_t)(t + T * k);
-      const bool inr = m < len;
-      const cf s = X[xs_index(inr ? n0 + m : 0u, a.xs)];
-      v[k] = inr ? s : cmake(0.f, 0.f);
+      for (int k = 0; k < 8; k++) v[k] = RawBuiltin<CX>::cvt(RawBuiltin<CX>::ld(d, (t + T * k) * CX::STRIDE, 0));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t m = (uint32_t)(t + T * k);
+        const bool inr = m < len;
+        const cf s = X[xs_index(inr ? n0 + m : 0u, a.xs)];
+        v[k] = inr ? s : cmake(0.f, 0.f);
+      }
     }
 #pragma unroll
     for (int k = 8; k < 16; k++) v[k] = cmake(0.f, 0.f);
   };
   auto load_y = [&](uint32_t n0, uint32_t len, cf *v) {
+    const __amdgpu_buffer_rsrc_t d = make_rsrc_b(BufChanOf<In>::y(a.x, a.y, (int64_t)cpi * a.cpiStride + n0), (int)len * CY::STRIDE);
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const uint32_t m = (uint32_t)(t + T * k);
-      const bool inr = m < len;
-      const cf s = Y[inr ? n0 + m : 0u];
-      v[k] = inr ? s : cmake(0.f, 0.f);
-    }
+    for (int k = 0; k < 8; k++) v[k] = RawBuiltin<CY>::cvt(RawBuiltin<CY>::ld(d, (t + T * k) * CY::STRIDE, 0));
 #pragma unroll
     for (int k = 8; k < 16; k++) v[k] = cmake(0.f, 0.f);
   };
