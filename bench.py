@@ -257,10 +257,10 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0,
-                    help="CPIs per step (per GPU); default 256 for the 2 MS/s configs (8 GB of fp32 IQ per step; 128 with --chain "
-                         "full: a pulse is the scheduling unit of the range kernel, and 256 x 513 pulses are 42.75 rounds of its "
+                    help="CPIs per step (per GPU); default 256 for the 2 MS/s configs (8 GB of fp32 IQ per step: a pulse is the scheduling unit of the range kernel, and 256 x 513 pulses are 42.75 rounds of its "
                          "3072 resident waves -- measured on one box: 98.8 k / 107.7 k / 110.3 k CPIs/s at 32 / 128 / 256); "
-                         "32 for cfg3 (128 with --chain full), 8 for cfg5 -- "
+                         "32 for cfg3 (256 with --chain full, 41 GB of IQ: the Toeplitz solve takes 1.6 ms per launch whatever the batch -- "
+                         "4.69 k CPIs/s at 128, 4.92 k at 256), 8 for cfg5 -- "
                          "measured: cfg3 93.9 / 88.8 / 84.7 us/CPI at 8 / 16 / 32, cfg5 142.8 / 138.4 / 138.8 at 4 / 8 / 16")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--fmt", default="c32", choices=["c32", "i16", "f16"])
@@ -309,8 +309,7 @@ def main(argv=None):
 
     cfg, cfg_desc = CONFIGS[a.config]
     dmin, dmax, fmin, fmax, fs, n = cfg
-    B = a.batch if a.batch > 0 else ({"cfg3": 128 if a.chain == "full" else 32, "cfg5": 8, "small": 1024}.get(
-        a.config, 256 if a.chain == "amb" else 128))
+    B = a.batch if a.batch > 0 else ({"cfg3": 256 if a.chain == "full" else 32, "cfg5": 8, "small": 1024}.get(a.config, 256))
     NS = max(1, a.streams) if a.chain == "amb" else 1
     ambs = [blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B, n_doppler_bins=a.n_doppler)
             for _ in range(NS)]

@@ -22,9 +22,9 @@ profile() { # tag, json description, bench args...
   done
 }
 PMC_EXTRA=1 profile amb '{"config": "cfg2", "batch": 256, "fmt": "c32", "chain": "amb"}' --steps 12 --warmup 3
-PMC_EXTRA= profile full '{"config": "cfg2", "batch": 64, "fmt": "c32", "chain": "full"}' --chain full --batch 64 --steps 10 --warmup 3
+PMC_EXTRA= profile full '{"config": "cfg2", "batch": 256, "fmt": "c32", "chain": "full"}' --chain full --steps 6 --warmup 2
 PMC_EXTRA= profile cfg3 '{"config": "cfg3", "batch": 32, "fmt": "c32", "chain": "amb"}' --config cfg3 --steps 10 --warmup 2 --prewarm-s 0.3
-PMC_EXTRA= profile cfg3_full '{"config": "cfg3", "batch": 128, "fmt": "c32", "chain": "full"}' --config cfg3 --chain full --steps 3 --warmup 1 --prewarm-s 0.3
+PMC_EXTRA= profile cfg3_full '{"config": "cfg3", "batch": 256, "fmt": "c32", "chain": "full"}' --config cfg3 --chain full --steps 2 --warmup 1 --prewarm-s 0.3
 PMC_EXTRA= profile cfg5 '{"config": "cfg5", "batch": 8, "fmt": "f16", "chain": "amb"}' --config cfg5 --fmt f16 --steps 10 --warmup 2
 mkdir -p $OUT/cal
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/cal/fetch -o cal --output-format csv -- $REPO/tools/membench/pmccal > $OUT/cal/fetch.log 2>&1
@@ -34,9 +34,9 @@ rm -f $OUT/bench_r3*.log
 python bench.py > $OUT/bench_r3.log 2>&1
 python bench.py --batch 1 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_r3_b1.log 2>&1
 python bench.py --fmt i16 --no-cpu-baseline > $OUT/bench_r3_i16.log 2>&1
-python bench.py --chain full --batch 64 --no-cpu-baseline > $OUT/bench_r3_full.log 2>&1
+python bench.py --chain full --steps 20 --no-cpu-baseline > $OUT/bench_r3_full.log 2>&1
 python bench.py --config cfg3 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_r3_cfg3.log 2>&1
-python bench.py --config cfg3 --chain full --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_r3_cfg3_full.log 2>&1
+python bench.py --config cfg3 --chain full --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_r3_cfg3_full.log 2>&1
 python bench.py --config cfg5 --fmt f16 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_r3_cfg5.log 2>&1
 python bench.py --config cfg5 --fmt f16 --batch 32 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_r3_cfg5_b32.log 2>&1
 python bench.py --fft-len 1024 --range-kernel wave1k --no-cpu-baseline > $OUT/bench_r3_w1k.log 2>&1
