@@ -163,12 +163,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_b(const void *base, 
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(u), (short)0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 // complex fp32 store; out-of-range offsets (negative included) are dropped by the range check
-__device__ __forceinline__ void bufstore_c32(__amdgpu_buffer_rsrc_t d, int voff, cf v)
+__device__ __forceinline__ void bufstore_c32(__amdgpu_buffer_rsrc_t d, int voff, cf v, int soff = 0)
 {
   b2_v2u r;
   r.x = __float_as_uint(v.x);
   r.y = __float_as_uint(v.y);
-  __builtin_amdgcn_raw_buffer_store_b64(r, d, voff, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(r, d, voff, soff, 0);
 }
 
 } // namespace blah2

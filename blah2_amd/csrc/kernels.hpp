@@ -1214,7 +1214,11 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
 
   // the chirp (the same for every column) lives in LDS: 34 registers less across the loop
   cf *chirpL = regions + NCOL * DOPW_RS;
-  for (int i = tid; i < DOPW_CHIRP_ELEMS; i += NT) chirpL[i] = a.chirp[min(i, nD - 1)];
+  // zero beyond nD: the padding rows of a column (which the tile fill leaves at zero, see below) then need no select
+  for (int i = tid; i < DOPW_CHIRP_ELEMS; i += NT) {
+    const cf c = a.chirp[min(i, nD - 1)];
+    chirpL[i] = cmake(i < nD ? c.x : 0.f, i < nD ? c.y : 0.f);
+  }
   W::fill_table(tid, NT, a.tw, table);
   W::Tw tw;
   W::load_twiddles(t, a.tw, table, tw);
@@ -1223,15 +1227,20 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
   typedef float f4 __attribute__((ext_vector_type(4)));
   f4 nt[NRP];
   const int pairs = nD * (NCOL / 2);
+  // Through a buffer descriptor over the half tile's nD row pieces (64 of every 128 bytes): pair idx = tid + 512 j sits
+  // 16 KiB behind pair tid + 512 (j - 1), so the loads differ only in soffset; pieces of rows >= nD are beyond the
+  // descriptor and read as zeros -- which is what the padding rows of the columns have to hold
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
   auto tile_load = [&](int it) {
     const int cpi = it / tilesPerCpi, sub = it - cpi * tilesPerCpi;
     const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, sub * NCOL);
-    const int tl = relaunder(tid); // per-phase address arithmetic is recomputed, not kept live across the loop
+    const __amdgpu_buffer_rsrc_t d = make_rsrc_b(Rt, (nD - 1) * 128 + NCOL * 8);
+    const int tl = relaunder(tid);
+    const int voff = (tl >> (SH - 1)) * 128 + (tl & (NCOL / 2 - 1)) * 16;
 #pragma unroll
     for (int j = 0; j < NRP; j++) {
-      const int idx = tl + NT * j;
-      const int pc = idx & (NCOL / 2 - 1), row = idx >> (SH - 1);
-      nt[j] = *reinterpret_cast<const f4 *>(Rt + (idx < pairs ? row * 16 + 2 * pc : 0));
+      const u4 r = __builtin_amdgcn_raw_buffer_load_b128(d, voff, j * (NT >> (SH - 1)) * 128, 0);
+      nt[j] = f4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
     }
   };
   int it = blockIdx.x;
@@ -1243,14 +1252,11 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
     // have read the regions: barrier at the end of the loop body)
     {
       const int tl = relaunder(tid);
+      cf *dst = regions + (2 * (tl & (NCOL / 2 - 1))) * DOPW_RS + (tl >> (SH - 1)); // pair idx + 512 j: same columns, row + 128 j
 #pragma unroll
-      for (int j = 0; j < NRP; j++) {
-        const int idx = tl + NT * j;
-        const int pc = idx & (NCOL / 2 - 1), row = idx >> (SH - 1);
-        if (idx < pairs) {
-          regions[(2 * pc) * DOPW_RS + row] = cmake(nt[j].x, nt[j].y);
-          regions[(2 * pc + 1) * DOPW_RS + row] = cmake(nt[j].z, nt[j].w);
-        }
+      for (int j = 0; j < NRP; j++) { // every row up to 9 * 128 - 1, the zeros of rows >= nD included: no predicate
+        dst[(NT >> (SH - 1)) * j] = cmake(nt[j].x, nt[j].y);
+        dst[DOPW_RS + (NT >> (SH - 1)) * j] = cmake(nt[j].z, nt[j].w);
       }
     }
     DW_T(0)
@@ -1264,12 +1270,7 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
     const cf r0 = region[0];
     const int t2 = relaunder(t);
 #pragma unroll
-    for (int k = 0; k < NR; k++) {
-      const int i = t2 + 64 * k;
-      const cf rv = region[min(i, nD - 1)];
-      const cf p = cmul(csub(rv, r0), chirpL[i]);
-      v[k] = cmake(i < nD ? p.x : 0.f, i < nD ? p.y : 0.f);
-    }
+    for (int k = 0; k < NR; k++) v[k] = cmul(csub(region[t2 + 64 * k], r0), chirpL[t2 + 64 * k]); // rows >= nD: (0 - r0) * 0
 #pragma unroll
     for (int k = NR; k < 32; k++) v[k] = cmake(0.f, 0.f);
     // The kernel spectrum (16 KB, L2-resident) is requested here and lands during the forward
@@ -1318,25 +1319,32 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
     const int ncol = min(NCOL, a.nDelay - col0);
     const int tl4 = relaunder(tid);
     const bool wide = (a.nDelay & 1) == 0; // 16-byte row pieces need the rows to start 16-byte aligned
+    {
+      // stores through a descriptor over the CPI's map: rows >= nD fall behind its end, columns beyond the map's last
+      // one (the last tile of a row) get offset -1; pair idx + 512 j is 128 rows further down: soffset
+      const __amdgpu_buffer_rsrc_t md = make_rsrc_b(a.map + (size_t)cpi * nD * a.nDelay, nD * a.nDelay * 8);
+      const int pc = tl4 & (NCOL / 2 - 1), o0 = tl4 >> (SH - 1);
+      const cf *src = regions + (2 * pc) * DOPW_RS + o0;
+      const bool c0 = 2 * pc < ncol, c1 = 2 * pc + 1 < ncol;
+      const int off = (o0 * a.nDelay + col0 + 2 * pc) * 8;
+      const int rstep = (NT >> (SH - 1)) * a.nDelay * 8;
 #pragma unroll
-    for (int j = 0; j < NRP; j++) {
-      const int idx = tl4 + NT * j;
-      const int pc = idx & (NCOL / 2 - 1), o = idx >> (SH - 1);
-      const bool ok0 = idx < pairs && 2 * pc < ncol, ok1 = idx < pairs && 2 * pc + 1 < ncol;
-      const cf d0 = regions[(2 * pc) * DOPW_RS + min(o, nD - 1)];
-      const cf d1 = regions[(2 * pc + 1) * DOPW_RS + min(o, nD - 1)];
-      cf *dst = mapb + (size_t)o * a.nDelay + 2 * pc;
-      if (wide && ok1) {
-        f4 q = {d0.x, d0.y, d1.x, d1.y};
-        *reinterpret_cast<f4 *>(dst) = q;
-      } else {
-        if (ok0) dst[0] = d0;
-        if (ok1) dst[1] = d1;
+      for (int j = 0; j < NRP; j++) {
+        const cf d0 = src[(NT >> (SH - 1)) * j], d1 = src[DOPW_RS + (NT >> (SH - 1)) * j];
+        if (wide) { // ncol is even with nDelay: both columns or none
+          const u4 q = {__float_as_uint(d0.x), __float_as_uint(d0.y), __float_as_uint(d1.x), __float_as_uint(d1.y)};
+          __builtin_amdgcn_raw_buffer_store_b128(q, md, c1 ? off : -1, j * rstep, 0);
+        } else {
+          bufstore_c32(md, (c0 ? off : -1), d0, j * rstep);
+          bufstore_c32(md, (c1 ? off + 8 : -1), d1, j * rstep);
+        }
+        const bool inr = o0 + (NT >> (SH - 1)) * j < nD;
+        const bool ok0 = inr && c0, ok1 = inr && c1;
+        const float db0 = db_of(d0), db1 = db_of(d1);
+        lsum += (ok0 ? (double)db0 : 0.0) + (ok1 ? (double)db1 : 0.0);
+        lmax = ok0 ? fmaxf(lmax, db0) : lmax;
+        lmax = ok1 ? fmaxf(lmax, db1) : lmax;
       }
-      const float db0 = db_of(d0), db1 = db_of(d1);
-      lsum += (ok0 ? (double)db0 : 0.0) + (ok1 ? (double)db1 : 0.0);
-      lmax = ok0 ? fmaxf(lmax, db0) : lmax;
-      lmax = ok1 ? fmaxf(lmax, db1) : lmax;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
