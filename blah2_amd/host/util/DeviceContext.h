@@ -10,6 +10,9 @@
 // pinned shadow of its ring as it arrives (blah2.cpp:254-258 moves a CPI into x and y sample by sample right before
 // :264-287 runs) and every 256 k samples that stretch is sent to the same positions of a device ring, so the first
 // class finds the CPI resident and the sequence starts with kernels, not with 32 MB of narrowing and 32 MB of PCIe.
+// (The uploads are enqueued from inside push_back, on the context's stream: like the reference, which holds a FIFO's lock
+// around both, a FIFO's pushes and the classes that process it must not run concurrently.  FIFOs the classes never see --
+// the capture buffers -- are never attached.)
 // Built on the blah2hip_ctx_* part of the C ABI: no HIP headers on this side.
 #ifndef BLAH2HIP_HOST_DEVICECONTEXT_H
 #define BLAH2HIP_HOST_DEVICECONTEXT_H
