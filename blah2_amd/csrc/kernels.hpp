@@ -1410,7 +1410,10 @@ __global__ __launch_bounds__(128 * DOPW2_NCOL, 2) void doppler_tilew2_kernel(Dop
   cf *region = regions + col * DOPW2_RS;
 
   cf *chirpL = regions + NCOL * DOPW2_RS;
-  for (int i = tid; i < DOPW2_CHIRP_ELEMS; i += NT) chirpL[i] = a.chirp[min(i, nD - 1)];
+  for (int i = tid; i < DOPW2_CHIRP_ELEMS; i += NT) { // zero beyond nD, like doppler_tilew_kernel
+    const cf c = a.chirp[min(i, nD - 1)];
+    chirpL[i] = cmake(i < nD ? c.x : 0.f, i < nD ? c.y : 0.f);
+  }
   W::fill_table(tid, NT, a.tw, table);
   W::Tw tw;
   W::load_twiddles(wave, lane, a.tw, table, tw);
@@ -1432,12 +1435,16 @@ __global__ __launch_bounds__(128 * DOPW2_NCOL, 2) void doppler_tilew2_kernel(Dop
     int cpi, sub;
     tile_of(g, cpi, sub);
     const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, min(sub, tilesPerCpi - 1) * NCOL);
+    // buffer loads over the quarter tile's nD row pieces (32 of every 128 bytes): pair idx + 512 j is 256 rows further
+    // down (soffset), rows >= nD read as zeros (see doppler_tilew_kernel)
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t d = make_rsrc_b(Rt, (nD - 1) * 128 + NCOL * 8);
     const int tl = relaunder(tid);
+    const int voff = (tl >> 1) * 128 + (tl & 1) * 16;
 #pragma unroll
     for (int j = 0; j < NRP; j++) {
-      const int idx = tl + NT * j;
-      const int pc = idx & (NCOL / 2 - 1), row = idx >> 1;
-      nt[j] = *reinterpret_cast<const f4 *>(Rt + (idx < pairs ? row * 16 + 2 * pc : 0));
+      const u4 r = __builtin_amdgcn_raw_buffer_load_b128(d, voff, j * (NT >> 1) * 128, 0);
+      nt[j] = f4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
     }
   };
   if (grp < nGroupsAll) tile_load(grp);
@@ -1449,14 +1456,11 @@ __global__ __launch_bounds__(128 * DOPW2_NCOL, 2) void doppler_tilew2_kernel(Dop
     // phase 1: the tile, transposed into the per-column regions
     {
       const int tl = relaunder(tid);
+      cf *dst = regions + (2 * (tl & 1)) * DOPW2_RS + (tl >> 1);
 #pragma unroll
-      for (int j = 0; j < NRP; j++) {
-        const int idx = tl + NT * j;
-        const int pc = idx & (NCOL / 2 - 1), row = idx >> 1;
-        if (idx < pairs) {
-          regions[(2 * pc) * DOPW2_RS + row] = cmake(nt[j].x, nt[j].y);
-          regions[(2 * pc + 1) * DOPW2_RS + row] = cmake(nt[j].z, nt[j].w);
-        }
+      for (int j = 0; j < NRP; j++) { // every row up to 9 * 256 - 1, the zeros of rows >= nD included
+        dst[(NT >> 1) * j] = cmake(nt[j].x, nt[j].y);
+        dst[DOPW2_RS + (NT >> 1) * j] = cmake(nt[j].z, nt[j].w);
       }
     }
     __syncthreads();
@@ -1468,12 +1472,7 @@ __global__ __launch_bounds__(128 * DOPW2_NCOL, 2) void doppler_tilew2_kernel(Dop
     {
       const int t2 = relaunder(T);
 #pragma unroll
-      for (int k = 0; k < NR; k++) {
-        const int i = t2 + 128 * k;
-        const cf rv = region[min(i, nD - 1)];
-        const cf pch = cmul(csub(rv, r0), chirpL[i]);
-        v[k] = cmake(i < nD ? pch.x : 0.f, i < nD ? pch.y : 0.f);
-      }
+      for (int k = 0; k < NR; k++) v[k] = cmul(csub(region[t2 + 128 * k], r0), chirpL[t2 + 128 * k]); // rows >= nD: (0 - r0) * 0
     }
 #pragma unroll
     for (int k = NR; k < 32; k++) v[k] = cmake(0.f, 0.f);
@@ -1513,21 +1512,25 @@ __global__ __launch_bounds__(128 * DOPW2_NCOL, 2) void doppler_tilew2_kernel(Dop
     {
       const int tl4 = relaunder(tid);
       const bool wide = (a.nDelay & 1) == 0; // 16-byte row pieces need the rows to start 16-byte aligned
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t md = make_rsrc_b(a.map + (size_t)cpi * nD * a.nDelay, nD * a.nDelay * 8);
+      const int pc = tl4 & 1, o0 = tl4 >> 1;
+      const cf *src = regions + (2 * pc) * DOPW2_RS + o0;
+      const bool c0 = 2 * pc < ncol, c1 = 2 * pc + 1 < ncol;
+      const int off = (o0 * a.nDelay + col0 + 2 * pc) * 8;
+      const int rstep = (NT >> 1) * a.nDelay * 8;
 #pragma unroll
       for (int j = 0; j < NRP; j++) {
-        const int idx = tl4 + NT * j;
-        const int pc = idx & (NCOL / 2 - 1), o = idx >> 1;
-        const bool ok0 = idx < pairs && 2 * pc < ncol, ok1 = idx < pairs && 2 * pc + 1 < ncol;
-        const cf d0 = regions[(2 * pc) * DOPW2_RS + min(o, nD - 1)];
-        const cf d1 = regions[(2 * pc + 1) * DOPW2_RS + min(o, nD - 1)];
-        cf *dst = mapb + (size_t)o * a.nDelay + 2 * pc;
-        if (wide && ok1) {
-          f4 q = {d0.x, d0.y, d1.x, d1.y};
-          *reinterpret_cast<f4 *>(dst) = q;
+        const cf d0 = src[(NT >> 1) * j], d1 = src[DOPW2_RS + (NT >> 1) * j];
+        if (wide) {
+          const u4 q = {__float_as_uint(d0.x), __float_as_uint(d0.y), __float_as_uint(d1.x), __float_as_uint(d1.y)};
+          __builtin_amdgcn_raw_buffer_store_b128(q, md, c1 ? off : -1, j * rstep, 0);
         } else {
-          if (ok0) dst[0] = d0;
-          if (ok1) dst[1] = d1;
+          bufstore_c32(md, (c0 ? off : -1), d0, j * rstep);
+          bufstore_c32(md, (c1 ? off + 8 : -1), d1, j * rstep);
         }
+        const bool inr = o0 + (NT >> 1) * j < nD;
+        const bool ok0 = inr && c0, ok1 = inr && c1;
         const float db0 = db_of(d0), db1 = db_of(d1);
         lsum += (ok0 ? (double)db0 : 0.0) + (ok1 ? (double)db1 : 0.0);
         lmax = ok0 ? fmaxf(lmax, db0) : lmax;
