@@ -50,3 +50,20 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(base, f), errors="replace").read()
                 assert "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_python_constants_mirror_the_header():
+    """Every BLAH2HIP_* option / kernel / format code that blah2_amd/_lib.py names has the header's value (the codes
+    are what crosses the ABI; a renumbering on one side only would select the wrong kernel silently)."""
+    from blah2_amd import _lib
+    src = open(os.path.join(ROOT, "include", "blah2hip.h")).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^#define\s+BLAH2HIP_([A-Z0-9_]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\b", src, re.M)}
+    assert len(defs) >= 40
+    checked = 0
+    for name, value in vars(_lib).items():
+        if name.isupper() and isinstance(value, int) and name in defs:
+            assert defs[name] == value, (name, defs[name], value)
+            checked += 1
+    assert checked >= 30
+    for must in ("RANGE_WAVE1K", "DOP_TILE16WG", "OPT_FFT_LEN", "FMT_I16X_C32Y", "CLUTTER_OPT_CORR"):
+        assert must in defs and getattr(_lib, must) == defs[must], must
