@@ -3,7 +3,7 @@
 
 Run in the build container (needs /root/reference and `make -C oracle ref`):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [fixture names ...]
 
 Each fixture holds a seeded synthetic capture in the .rspduo wire layout
 (int16 I1 Q1 I2 Q2, /root/reference/src/capture/rspduo/RspDuo.cpp:512-526) and
@@ -33,6 +33,13 @@ CASES = {
     "medium": (1_000_000, 100_000, -10, 100, -100, 100, True, 14,
                ((37, -63.0, 0.05), (80, 30.0, 0.03)), (-10, 100)),
     "delay_pos_only": (200_000, 30_000, 0, 40, -30, 30, True, 15, ((20, 10.0, 0.05),), (0, 40)),
+    # round 3, the widened envelope.  199-sample pulses, nfft = 2*199 - 1 = 397 (no Hamming rounding, so that no delay falls
+    # into the all-zero band between nCorr and nfft - nCorr, whose cells are FFT rounding noise in the reference and make
+    # Map::set_metrics' mean of dB values incomparable): delays from 199 on read the opposite-sign lag d - 397 out of the
+    # reference's nfft-point circular correlation (Ambiguity.cpp:132-146)
+    "aliased_lags": (200_000, 40_000, -30, 350, -500, 500, False, 16, ((20, 100.0, 0.05), (-15, -200.0, 0.05)), (-3, 20)),
+    # 4201 delay bins (more than one on-chip transform holds: the engine runs the window as lag chunks)
+    "many_delay_bins": (60_000, 60_000, -20, 4180, -2, 2, True, 17, ((4000, 1.0, 0.05), (17, -1.0, 0.05)), (-3, 20)),
 }
 # name -> (n, bandwidth, seed)
 SPECTRUM_CASES = {
@@ -47,7 +54,10 @@ DET = dict(pfa=1e-5, n_guard=2, n_train=6, min_delay=5, min_doppler=15.0, n_cent
 def main():
     if not R.available():
         sys.exit("oracle/_ref/libblah2ref.so missing: run `make -C oracle ref` first")
+    only = set(sys.argv[1:])  # optional: fixture names to (re)generate
     for name, (fs, n, dmin, dmax, fmin, fmax, rh, seed, targets, clut) in CASES.items():
+        if only and name not in only:
+            continue
         x, y = O.synth_iq(n, seed=seed, fs=fs, targets=targets)
         iq = np.empty((n, 4), dtype=np.int16)
         iq[:, 0], iq[:, 1], iq[:, 2], iq[:, 3] = x.real, x.imag, y.real, y.imag
@@ -88,6 +98,8 @@ def main():
     # decimation, odd nfft, nSpectrum != 2000
     os.makedirs(os.path.join(HERE, "spectrum"), exist_ok=True)
     for name, (n, bw, seed) in SPECTRUM_CASES.items():
+        if only and name not in only:
+            continue
         x, _ = O.synth_iq(n, seed=seed, fs=2_000_000)
         spec, n_freq = R.spectrum(x, n, bw)
         iq = np.empty((n, 2), dtype=np.int16)
