@@ -47,6 +47,7 @@ SPECTRUM_CASES = {
     "odd_nfft": (44_000, 2001.0, 22),                  # D = 21, nS = 2095, nfft = 43995 (odd)
     "even_decimation_odd_bins": (45_122, 2000.0, 23), # D = 22, nS = 2051: bins congruent to D/2+1 mod D
     "small": (5_000, 400.0, 24),                       # D = 12, nS = 416
+    "wide": (70_000, 20_000.0, 25),                    # D = 3, nS = 23333 (round 3: more bins than the on-chip tables hold)
 }
 DET = dict(pfa=1e-5, n_guard=2, n_train=6, min_delay=5, min_doppler=15.0, n_centroid=6)
 
