@@ -38,6 +38,9 @@ CASES = {
     # Map::set_metrics' mean of dB values incomparable): delays from 199 on read the opposite-sign lag d - 397 out of the
     # reference's nfft-point circular correlation (Ambiguity.cpp:132-146)
     "aliased_lags": (200_000, 40_000, -30, 350, -500, 500, False, 16, ((20, 100.0, 0.05), (-15, -200.0, 0.05)), (-3, 20)),
+    # clutter filter with a POSITIVE delayMin: the first delayMin reference samples come from the uint32 wrap of
+    # WienerHopf.cpp:61-70 (index i - delayMin below zero), the piece the engine's windows treat element by element
+    "clutter_pos_delay": (200_000, 30_000, 0, 40, -30, 30, True, 18, ((20, 10.0, 0.05),), (3, 40)),
     # 4201 delay bins (more than one on-chip transform holds: the engine runs the window as lag chunks)
     "many_delay_bins": (60_000, 60_000, -20, 4180, -2, 2, True, 17, ((4000, 1.0, 0.05), (17, -1.0, 0.05)), (-3, 20)),
 }

@@ -37,7 +37,8 @@ def test_clutter_golden(b2, name, path):
     ref = g["clutter_y"]
     err = np.max(np.abs(yf.astype(np.complex128) - ref)) / np.max(np.abs(ref))
     assert err <= Y_TOL, f"filtered-channel error {err:.3e}"
-    assert np.linalg.norm(yf) < 0.5 * np.linalg.norm(g["y"])
+    if dmin <= 0:  # the taps cover the direct path at delay 0
+        assert np.linalg.norm(yf) < 0.5 * np.linalg.norm(g["y"])
 
 
 @pytest.mark.parametrize("fft_len", [1024, 2048, 4096])

@@ -96,8 +96,9 @@ def test_wiener_hopf_restatement_matches_compiled_reference(name):
     ok, yf = O.wiener_hopf(g["x"], g["y"], int(g["clutter_params"][0]), int(g["clutter_params"][1]))
     assert ok == bool(g["clutter_ok"])
     assert np.max(np.abs(yf - g["clutter_y"])) / np.max(np.abs(g["clutter_y"])) < 1e-9
-    # the filter removes the direct-path/clutter energy
-    assert np.linalg.norm(yf) < 0.5 * np.linalg.norm(g["y"])
+    # the filter removes the direct-path/clutter energy (where its taps cover the direct path at delay 0)
+    if int(g["clutter_params"][0]) <= 0:
+        assert np.linalg.norm(yf) < 0.5 * np.linalg.norm(g["y"])
 
 
 def test_wiener_hopf_failure_contract():
