@@ -1,0 +1,59 @@
+"""The look-ahead form of the clutter filter's Toeplitz solve (tools/proto/toeplitz_lookahead.py: preparation for a
+multi-CU kernel) against the stepwise recursion the device runs, LAPACK, and the normal equations
+of a compiled-reference fixture."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import blah2_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("toeplitz_lookahead", os.path.join(ROOT, "tools", "proto", "toeplitz_lookahead.py"))
+P = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(P)
+
+
+def coloured_normal_equations(n, colour, seed):
+    rng = np.random.default_rng(seed)
+    sig = rng.standard_normal(8 * n) + 1j * rng.standard_normal(8 * n)
+    for i in range(1, sig.size):
+        sig[i] += colour * sig[i - 1]
+    r = np.correlate(sig, sig, mode="full")[sig.size - 1:sig.size - 1 + n] / sig.size
+    r[0] = r[0].real
+    return r, rng.standard_normal(n) + 1j * rng.standard_normal(n)
+
+
+@pytest.mark.parametrize("n,colour", [(97, 0.0), (300, 0.9), (411, 0.99)])
+@pytest.mark.parametrize("k", [1, 8, 32])
+def test_lookahead_equals_stepwise(n, colour, k):
+    r, b = coloured_normal_equations(n, colour, n)
+    T = P._toeplitz(r)
+    w1, ok1 = P.solve_stepwise(r, b)
+    w2, ok2 = P.solve_lookahead(r, b, k)
+    assert ok1 and ok2
+    ref = np.linalg.solve(T, b)
+    scale = np.linalg.cond(T) * 1e-15
+    assert np.linalg.norm(w2 - w1) / np.linalg.norm(w1) <= 50 * scale
+    assert np.linalg.norm(w2 - ref) / np.linalg.norm(ref) <= 50 * scale
+    assert np.linalg.norm(T @ w2 - b) <= 2 * max(np.linalg.norm(T @ w1 - b), 1e-13 * np.linalg.norm(b))
+
+
+def test_not_positive_definite_is_refused_by_both():
+    r = np.array([1.0, 0.9, 1.2, 0.1, 0.0, 0.3], complex)
+    for k in (1, 2, 5):
+        assert not P.solve_lookahead(r, np.ones(6), k)[1]
+    assert not P.solve_stepwise(r, np.ones(6))[1]
+    assert not P.solve_lookahead(np.array([0.0, 0.1], complex), np.ones(2))[1]
+
+
+def test_on_the_normal_equations_of_a_reference_fixture():
+    g = load_golden("medium")
+    dmin, dmax = (int(v) for v in g["clutter_params"])
+    ok, _, w_ref, r_ref, b_ref = O.wiener_hopf(g["x"], g["y"], dmin, dmax, return_filter=True)
+    assert ok and r_ref.size == dmax - dmin
+    w, ok2 = P.solve_lookahead(r_ref, b_ref, 16)
+    assert ok2
+    assert np.linalg.norm(w - w_ref) / np.linalg.norm(w_ref) <= 1e-9
