@@ -39,12 +39,17 @@ def test_lookahead_equals_stepwise(n, colour, k):
     assert np.linalg.norm(w2 - w1) / np.linalg.norm(w1) <= 50 * scale
     assert np.linalg.norm(w2 - ref) / np.linalg.norm(ref) <= 50 * scale
     assert np.linalg.norm(T @ w2 - b) <= 2 * max(np.linalg.norm(T @ w1 - b), 1e-13 * np.linalg.norm(b))
+    # the same on the device's storage: three arrays whose meaning changes at the order boundary, every index doing the
+    # work of one pair, the upper pair through its shifted transformation
+    w3, ok3 = P.solve_lookahead_unified(r, b, k)
+    assert ok3 and np.linalg.norm(w3 - w2) / np.linalg.norm(w2) <= 50 * scale
 
 
 def test_not_positive_definite_is_refused_by_both():
     r = np.array([1.0, 0.9, 1.2, 0.1, 0.0, 0.3], complex)
     for k in (1, 2, 5):
         assert not P.solve_lookahead(r, np.ones(6), k)[1]
+        assert not P.solve_lookahead_unified(r, np.ones(6), k)[1]
     assert not P.solve_stepwise(r, np.ones(6))[1]
     assert not P.solve_lookahead(np.array([0.0, 0.1], complex), np.ones(2))[1]
 

@@ -133,6 +133,77 @@ def solve_lookahead(r, b, k=16):
     return x, True
 
 
+def solve_lookahead_unified(r, b, k=16):
+    """The block form on the DEVICE's storage: three arrays of n entries whose meaning changes at the order boundary m --
+    index j <= m carries (F[j], B[j], x[j]), index j > m carries (A[j], C[j-1], g[j]) -- so that every index does the work
+    of ONE pair.  Per block [m, m + k): the look-ahead triangle reads the k entries above m; then, out of place,
+        j <= m + k : (U, V, acc)[j] <- Theta, Psi applied to the LOWER entries (F, B at indices <= m, zero above)
+        j >  m + k : (U, V, acc)[j] <- Theta, Psi applied to the UPPER entries (A, zC at indices > m: a halo of k below j)
+    which is the split a multi-CU kernel distributes: a CU needs, beyond its own slice, the k entries below it (old
+    values) and the block's Theta / Psi."""
+    r = np.asarray(r, dtype=np.complex128)
+    b = np.asarray(b, dtype=np.complex128)
+    n = r.size
+    if not (r[0].real > 0):
+        return np.zeros(n, complex), False
+    s = r[0].real
+    U = r.copy(); V = np.concatenate(([0.0], r[:-1])); acc = b - r * (b[0] / s)   # upper roles: A, C[j-1], g
+    U[0] = 1.0; V[0] = 1.0; acc[0] = b[0] / s                                      # lower roles at j = 0: F, B, x
+    m = 0
+    while m < n - 1:
+        kk = min(k, n - 1 - m)
+        # look-ahead on the kk entries above m (upper roles there: A[j], C[j-1], g[j])
+        a = U[m + 1:m + 1 + kk].copy(); c = V[m + 1:m + 1 + kk].copy(); gg = acc[m + 1:m + 1 + kk].copy()
+        efs, dts = [], []
+        for i in range(kk):
+            ef = a[i] / s
+            D = 1.0 - abs(ef) ** 2
+            if not (D > 0.0) or not np.isfinite(D):
+                return np.zeros(n, complex), False
+            s = s * D
+            a_new = a - ef * c
+            c_same = c - np.conj(ef) * a
+            dt = gg[i] / s
+            gg = gg - dt * c_same
+            a = a_new
+            c = np.concatenate(([0.0], c_same[:-1]))
+            efs.append(ef); dts.append(dt)
+        # lower pair (F, B): one order is [[1, -ef z], [-conj(ef), z]], x' = x + dt B'
+        # upper pair in its shifted storage (U, V) = (A[j], C[j-1]): [[1, -ef], [-conj(ef) z, z]], g' = g - dt (V - conj(ef) U)
+        # (the same transformation seen through V = z C: Theta_up = diag(1, z) Theta_low diag(1, 1/z))
+        T = np.zeros((2, 2, kk + 1), complex); T[0, 0, 0] = 1.0; T[1, 1, 0] = 1.0
+        Tu = T.copy()
+        Pl = np.zeros((2, kk + 1), complex)
+        Pu = np.zeros((2, kk + 1), complex)
+        for ef, dt in zip(efs, dts):
+            zT1 = np.zeros_like(T[1]); zT1[:, 1:] = T[1][:, :-1]
+            T = np.stack([T[0] - ef * zT1, zT1 - np.conj(ef) * T[0]])
+            Pl = Pl + dt * T[1]
+            inner = Tu[1] - np.conj(ef) * Tu[0]          # C' of this order in terms of the block's input pair
+            Pu = Pu + dt * inner
+            zin = np.zeros_like(inner); zin[:, 1:] = inner[:, :-1]
+            Tu = np.stack([Tu[0] - ef * Tu[1], zin])
+        lo = slice(0, m + 1)                  # the lower entries that exist
+        Fl = np.zeros(n, complex); Fl[lo] = U[lo]
+        Bl = np.zeros(n, complex); Bl[lo] = V[lo]
+        xl = np.zeros(n, complex); xl[lo] = acc[lo]
+        Au = U.copy(); Au[lo] = 0.0           # the upper entries; what sits below m is never reached by a halo of kk from j > m + kk
+        Cu = V.copy(); Cu[lo] = 0.0
+        nU = np.empty(n, complex); nV = np.empty(n, complex); nacc = np.empty(n, complex)
+        top = m + kk
+        # lower formula for j <= top
+        nU[:top + 1] = (_apply(T[0, 0], Fl) + _apply(T[0, 1], Bl))[:top + 1]
+        nV[:top + 1] = (_apply(T[1, 0], Fl) + _apply(T[1, 1], Bl))[:top + 1]
+        nacc[:top + 1] = (xl + _apply(Pl[0], Fl) + _apply(Pl[1], Bl))[:top + 1]
+        # upper formula for j > top
+        nU[top + 1:] = (_apply(Tu[0, 0], Au) + _apply(Tu[0, 1], Cu))[top + 1:]
+        nV[top + 1:] = (_apply(Tu[1, 0], Au) + _apply(Tu[1, 1], Cu))[top + 1:]
+        nacc[top + 1:] = (acc - (_apply(Pu[0], Au) + _apply(Pu[1], Cu)))[top + 1:]
+        U, V, acc = nU, nV, nacc
+        m = top
+    return acc, True
+
+
 def _toeplitz(r):
     n = r.size
     i, j = np.indices((n, n))
@@ -159,6 +230,8 @@ def _selftest():
         for k in (1, 4, 16, 32):
             w2, ok2 = solve_lookahead(r, b, k)
             assert ok2
+            w3, ok3 = solve_lookahead_unified(r, b, k)
+            assert ok3 and np.linalg.norm(w3 - w2) / np.linalg.norm(w2) < 1e3 * np.finfo(float).eps * max(1.0, np.linalg.cond(T)) , (n, k)
             e2 = np.linalg.norm(T @ w2 - b) / np.linalg.norm(b)
             dw = np.linalg.norm(w2 - w1) / np.linalg.norm(w1)
             worst = max(worst, dw)
