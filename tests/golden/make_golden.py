@@ -41,6 +41,8 @@ CASES = {
     # clutter filter with a POSITIVE delayMin: the first delayMin reference samples come from the uint32 wrap of
     # WienerHopf.cpp:61-70 (index i - delayMin below zero), the piece the engine's windows treat element by element
     "clutter_pos_delay": (200_000, 30_000, 0, 40, -30, 30, True, 18, ((20, 10.0, 0.05),), (3, 40)),
+    # nCorr = 200000 / 3 = 66666 does not fit the reference's uint16 (Ambiguity.h:80-89): it processes 1130 samples per pulse
+    "ncorr_wraps_uint16": (200_000, 200_000, -3, 20, -1, 1, True, 19, ((7, 0.4, 0.05),), (-3, 20)),
     # 4201 delay bins (more than one on-chip transform holds: the engine runs the window as lag chunks)
     "many_delay_bins": (60_000, 60_000, -20, 4180, -2, 2, True, 17, ((4000, 1.0, 0.05), (17, -1.0, 0.05)), (-3, 20)),
 }
