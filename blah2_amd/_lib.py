@@ -23,7 +23,9 @@ CLUTTER_KERNEL_NAMES = {CK_CORR: "clutter_corr", CK_REDUCE: "clutter_reduce", CK
                         CK_FIR: "clutter_fir"}
 OPT_DOPPLER_KERNEL, OPT_RANGE_GRID, OPT_RANGE_KERNEL, OPT_DOPPLER_GRID, OPT_FFT_LEN, OPT_CFAR2D_KERNEL = 1, 2, 3, 4, 5, 6
 CFAR2D_AUTO, CFAR2D_TILE, CFAR2D_SAT = 0, 1, 2
-CLUTTER_OPT_SOLVE_K, CLUTTER_OPT_FFT_LEN, CLUTTER_OPT_CORR = 1, 2, 3
+CLUTTER_OPT_SOLVE_K, CLUTTER_OPT_FFT_LEN, CLUTTER_OPT_CORR, CLUTTER_OPT_SOLVE_FORM, CLUTTER_OPT_SOLVE_E = 1, 2, 3, 4, 5
+CLUTTER_SOLVE_AUTO, CLUTTER_SOLVE_STEPWISE, CLUTTER_SOLVE_LOOKAHEAD = 0, 1, 2
+CLUTTER_INFO_SOLVE_FORM, CLUTTER_INFO_SOLVE_E, CLUTTER_INFO_SOLVE_G, CLUTTER_INFO_SOLVE_FAULT = 1, 2, 3, 4
 CLUTTER_CORR_AUTO, CLUTTER_CORR_HALF, CLUTTER_CORR_WINDOW = 0, 1, 2
 DOP_AUTO, DOP_TILE8, DOP_TILE16, DOP_TILEM, DOP_COLUMN, DOP_DIRECT, DOP_TILEW, DOP_TILEW2, DOP_TILE16WG = 0, 1, 2, 3, 4, 5, 6, 7, 8
 DOPPLER_KERNEL_NAMES = {DOP_AUTO: "auto", DOP_TILE8: "tile8", DOP_TILE16: "tile16", DOP_TILEM: "tilem",
@@ -89,6 +91,9 @@ SYMBOLS = {
     "blah2hip_clutter_process_dev": (C.c_int, [_vp, _vp, _vp, _u32, C.c_uint64, _vp, _vp, _vp]),
     "blah2hip_clutter_process_dev_fmt": (C.c_int, [_vp, C.c_int, _vp, _vp, _u32, C.c_uint64, _vp, C.c_uint64, _vp, _vp]),
     "blah2hip_clutter_set_option": (C.c_int, [_vp, C.c_int, C.c_int64]),
+    "blah2hip_clutter_solve": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
+    "blah2hip_clutter_solve_dev": (C.c_int, [_vp, _vp, _u32, _vp, _vp, _vp]),
+    "blah2hip_clutter_get_info": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64)]),
     "blah2hip_clutter_get_dims": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "blah2hip_clutter_read_last": (C.c_int, [_vp, _u32, _vp, _vp, C.POINTER(C.c_int)]),
     "blah2hip_clutter_set_timing": (C.c_int, [_vp, C.c_int]),

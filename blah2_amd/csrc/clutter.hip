@@ -396,12 +396,17 @@ struct SolveArgs {
   cf *w;             // [nCpi][nBins]
   int32_t *ok;       // [nCpi]
   int32_t nBins, nJobs;
+  uint32_t *epoch;   // launch epoch of the look-ahead solve's mailboxes (solve_la.hpp), bumped here
 };
 
 // grid (ceil(nBins/256), 2, nCpi): fixed-order fp64 sum over the jobs
 __global__ __launch_bounds__(256) void clutter_reduce_kernel(SolveArgs a)
 {
   const int k = blockIdx.x * 256 + threadIdx.x, mode = blockIdx.y, cpi = blockIdx.z;
+  if (a.epoch && k == 0 && mode == 0 && cpi == 0) { // one thread per launch; the solve kernel behind the boundary reads it
+    const uint32_t e = *a.epoch + 1u;
+    *a.epoch = e ? e : 1u;
+  }
   if (k >= a.nBins) return;
   const cf *p = a.partial + ((size_t)cpi * 2 + mode) * a.nJobs * a.nBins + k;
   // four interleaved accumulators: the loads of a group of 8 are independent (fixed order -> deterministic)
@@ -557,6 +562,8 @@ __global__ __launch_bounds__(1024) void clutter_solve_kernel(SolveArgs a)
   if (t == 0) a.ok[cpi] = ok ? 1 : 0;
 }
 
+#include "solve_la.hpp"
+
 // ---- overlap-save FIR: y_out = y - (w * xs)[0..N) ----------------------------
 struct FirArgs {
   const void *x, *y;
@@ -693,7 +700,13 @@ struct blah2hip_clutter_s {
   int32_t *d_ok = nullptr;
   cf *d_stage = nullptr; // host entry points: x, y, y_out planes
   size_t stageElems = 0;
-  int solveK = 0;            // indices per thread of the Toeplitz solve (0 = by size)
+  int solveK = 0;            // indices per thread of the one-workgroup Toeplitz solve (0 = by size)
+  int solveForm = 0;         // BLAH2HIP_CLUTTER_OPT_SOLVE_FORM
+  int solveE = 0;            // BLAH2HIP_CLUTTER_OPT_SOLVE_E (0 = by launch size)
+  sla::u64 *d_mail = nullptr; // mailboxes of the look-ahead solve (solve_la.hpp), sized for max_batch
+  int64_t mailWords = 0;
+  uint32_t *d_epoch = nullptr; // [0] launch epoch, [1] fault word (a bounded spin ran out)
+  int lastForm = 0, lastE = 0, lastG = 0; // what the last launch ran
   bool corrHalf = false;     // half-window correlation (2 transforms per F/2 samples) instead of the windowed one
   int fftLenForce = 0;       // BLAH2HIP_CLUTTER_OPT_FFT_LEN (0 = planner)
   int corrForce = 0;         // BLAH2HIP_CLUTTER_OPT_CORR
@@ -702,6 +715,37 @@ struct blah2hip_clutter_s {
 };
 
 namespace {
+
+// Mailboxes of the look-ahead Toeplitz solve (solve_la.hpp): sized for the largest launch each plan can be chosen for
+// (create, and again when BLAH2HIP_CLUTTER_OPT_SOLVE_E changes).  Zeroed once: tags are launch epochs >= 1.
+int solve_la_alloc(blah2hip_clutter_s *h)
+{
+  int64_t need = 0;
+  for (int E : sla::kE) {
+    if (h->solveE && E != h->solveE) continue;
+    const sla::Plan p = sla::make_plan(h->nBins, E);
+    int64_t batch = h->maxBatch;
+    if (!h->solveE && E != 12) batch = std::min<int64_t>(batch, 8 * (h->numCU / (8 * p.G)));
+    need = std::max(need, p.stride * batch);
+  }
+  if (need > h->mailWords) {
+    if (h->d_mail) CHIP(hipFree(h->d_mail));
+    h->d_mail = nullptr; h->mailWords = 0;
+    CHIP(hipMalloc(&h->d_mail, (size_t)need * sizeof(sla::u64)));
+    CHIP(hipMemset(h->d_mail, 0, (size_t)need * sizeof(sla::u64)));
+    h->mailWords = need;
+  }
+  if (!h->d_epoch) {
+    CHIP(hipMalloc(&h->d_epoch, 2 * sizeof(uint32_t)));
+    CHIP(hipMemset(h->d_epoch, 0, 2 * sizeof(uint32_t)));
+  }
+  return BLAH2HIP_OK;
+}
+
+template <int E> void launch_solve_la(const sla::Args &a, int grid, hipStream_t st)
+{
+  hipLaunchKernelGGL(sla::clutter_solve_la_kernel<E>, dim3(grid), dim3(256), 0, st, a);
+}
 
 // Transform length, segmentation, correlation form and the buffers sized by them (create, and again when
 // BLAH2HIP_CLUTTER_OPT_FFT_LEN / _CORR re-plan).  F - nBins + 1 useful samples per F log F work.
@@ -750,6 +794,54 @@ int clutter_plan(blah2hip_clutter_s *h)
   return BLAH2HIP_OK;
 }
 
+// The Toeplitz solve of nCpi systems whose r, b sit in h->d_rb (the epoch of the look-ahead form's mailboxes has been
+// bumped by the launch in front: clutter_reduce_kernel, or solve_epoch_kernel)
+int launch_solve(blah2hip_clutter_s *h, const SolveArgs &sa, uint32_t nCpi, hipStream_t st)
+{
+  int32_t *ok = sa.ok;
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<1>, 160 * 1024 - 2048));
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<2>, 160 * 1024 - 2048));
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<4>, 160 * 1024 - 2048));
+  CHIP(h->timer.tic(BLAH2HIP_CK_SOLVE, st));
+  if (h->solveForm != BLAH2HIP_CLUTTER_SOLVE_STEPWISE && h->d_mail) {
+    // blocks of 32 orders on several workgroups per CPI (solve_la.hpp): as many CUs per CPI as the launch leaves free
+    const sla::Plan p = sla::choose_plan(h->nBins, (int)nCpi, h->numCU, h->solveE);
+    sla::Args la;
+    la.rb = sa.rb; la.w = sa.w; la.ok = ok; la.mail = h->d_mail; la.epoch = h->d_epoch; la.fault = h->d_epoch + 1;
+    la.n = h->nBins; la.NB = p.NB; la.nbulk = p.nbulk; la.G = p.G; la.nCpi = (int)nCpi; la.mailStride = p.stride;
+    la.offHalo = p.offHalo; la.offFeed = p.offFeed; la.offHaloFlag = p.offHaloFlag; la.offFeedFlag = p.offFeedFlag;
+    la.offStatus = p.offStatus;
+    if (p.stride * (int64_t)nCpi > h->mailWords) CFAIL(BLAH2HIP_ERR_INVALID, "internal: solve mailbox too small for this launch");
+    const int grid = ((int)nCpi + 7) / 8 * 8 * p.G;
+    switch (p.E) {
+    case 2: launch_solve_la<2>(la, grid, st); break;
+    case 3: launch_solve_la<3>(la, grid, st); break;
+    case 6: launch_solve_la<6>(la, grid, st); break;
+    default: launch_solve_la<12>(la, grid, st); break;
+    }
+    h->lastForm = BLAH2HIP_CLUTTER_SOLVE_LOOKAHEAD; h->lastE = p.E; h->lastG = p.G;
+  } else {
+    // one index per thread up to 1024 taps (measured: more, smaller threads win while the recursion is
+    // latency-bound), 2 up to 2048, 4 above
+    const size_t sl = ((size_t)2 * (h->nBins + 1)) * sizeof(dcx) + 2 * sizeof(SolveScal);
+    const int kper = h->solveK ? h->solveK : (h->nBins > 2048 ? 4 : (h->nBins > 1024 ? 2 : 1));
+    const int nt = std::min(1024, 64 * ((h->nBins + 64 * kper - 1) / (64 * kper)));
+    if (kper == 1) hipLaunchKernelGGL(clutter_solve_kernel<1>, dim3(nCpi), dim3(nt), sl, st, sa);
+    else if (kper == 2) hipLaunchKernelGGL(clutter_solve_kernel<2>, dim3(nCpi), dim3(nt), sl, st, sa);
+    else hipLaunchKernelGGL(clutter_solve_kernel<4>, dim3(nCpi), dim3(nt), sl, st, sa);
+    h->lastForm = BLAH2HIP_CLUTTER_SOLVE_STEPWISE; h->lastE = 0; h->lastG = 1;
+  }
+  CHIP(hipGetLastError());
+  CHIP(h->timer.toc(BLAH2HIP_CK_SOLVE, st));
+  return BLAH2HIP_OK;
+}
+
+__global__ void solve_epoch_kernel(uint32_t *epoch)
+{
+  const uint32_t e = *epoch + 1u;
+  *epoch = e ? e : 1u;
+}
+
 template <int R3, class In> int launch_clutter(blah2hip_clutter_s *h, const void *px, const void *py, uint32_t nCpi,
                                                int64_t stride, cf *yout, int64_t outStride, int32_t *ok, hipStream_t st)
 {
@@ -758,9 +850,6 @@ template <int R3, class In> int launch_clutter(blah2hip_clutter_s *h, const void
   // once per (device, kernel), see capi.hip
   CHIP(blah2hip_ensure_lds_((const void *)clutter_corr_kernel<R3, In>, (int)lds));
   CHIP(blah2hip_ensure_lds_((const void *)clutter_fir_kernel<R3, In>, (int)lds));
-  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<1>, 160 * 1024 - 2048));
-  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<2>, 160 * 1024 - 2048));
-  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<4>, 160 * 1024 - 2048));
   XsMap xs;
   xs.N = h->N;
   xs.thresh = h->delayMin > 0 ? (uint32_t)h->delayMin : 0u;
@@ -796,20 +885,11 @@ template <int R3, class In> int launch_clutter(blah2hip_clutter_s *h, const void
 
   SolveArgs sa;
   sa.partial = h->d_partial; sa.rb = h->d_rb; sa.w = h->d_w; sa.ok = ok; sa.nBins = h->nBins; sa.nJobs = nJobs;
+  sa.epoch = h->d_epoch;
   CHIP(h->timer.tic(BLAH2HIP_CK_REDUCE, st));
   hipLaunchKernelGGL(clutter_reduce_kernel, dim3((h->nBins + 255) / 256, 2, nCpi), dim3(256), 0, st, sa);
   CHIP(h->timer.toc(BLAH2HIP_CK_REDUCE, st));
-  CHIP(h->timer.tic(BLAH2HIP_CK_SOLVE, st));
-  // one index per thread up to 1024 taps (measured: more, smaller threads win while the recursion is
-  // latency-bound), 2 up to 2048, 4 above
-  const size_t sl = ((size_t)2 * (h->nBins + 1)) * sizeof(dcx) + 2 * sizeof(SolveScal);
-  const int kper = h->solveK ? h->solveK : (h->nBins > 2048 ? 4 : (h->nBins > 1024 ? 2 : 1));
-  const int nt = std::min(1024, 64 * ((h->nBins + 64 * kper - 1) / (64 * kper)));
-  if (kper == 1) hipLaunchKernelGGL(clutter_solve_kernel<1>, dim3(nCpi), dim3(nt), sl, st, sa);
-  else if (kper == 2) hipLaunchKernelGGL(clutter_solve_kernel<2>, dim3(nCpi), dim3(nt), sl, st, sa);
-  else hipLaunchKernelGGL(clutter_solve_kernel<4>, dim3(nCpi), dim3(nt), sl, st, sa);
-  CHIP(hipGetLastError());
-  CHIP(h->timer.toc(BLAH2HIP_CK_SOLVE, st));
+  { const int rc_ = launch_solve(h, sa, nCpi, st); if (rc_) return rc_; }
 
   FirArgs fa;
   fa.x = px; fa.y = py; fa.yout = yout; fa.cpiStride = stride; fa.outStride = outStride; fa.N = h->N; fa.xs = xs;
@@ -861,6 +941,7 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
   CHIP(hipMalloc(&h->d_rb, (size_t)max_batch * 2 * nBins * sizeof(dcx)));
   CHIP(hipMalloc(&h->d_w, (size_t)max_batch * nBins * sizeof(cf)));
   CHIP(hipMalloc(&h->d_ok, max_batch * sizeof(int32_t)));
+  { const int rc_ = solve_la_alloc(h); if (rc_) return rc_; }
   return BLAH2HIP_OK;
   };
   const int rc = build();
@@ -878,7 +959,7 @@ int blah2hip_clutter_destroy(blah2hip_clutter_t h)
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void *p : {(void *)h->d_tw, (void *)h->d_partial, (void *)h->d_rb, (void *)h->d_w, (void *)h->d_ok,
-                  (void *)h->d_stage})
+                  (void *)h->d_stage, (void *)h->d_mail, (void *)h->d_epoch})
     if (p) (void)hipFree(p);
   h->timer.destroy();
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -893,6 +974,25 @@ int blah2hip_clutter_get_dims(blah2hip_clutter_t h, uint32_t *n_bins, uint32_t *
   if (fft_len) *fft_len = (uint32_t)h->F;
   if (seg_len) *seg_len = (uint32_t)h->segLen;
   return BLAH2HIP_OK;
+}
+
+int blah2hip_clutter_get_info(blah2hip_clutter_t h, int what, int64_t *value)
+{
+  if (!h || !value) CFAIL(BLAH2HIP_ERR_INVALID, "NULL argument");
+  switch (what) {
+  case BLAH2HIP_CLUTTER_INFO_SOLVE_FORM: *value = h->lastForm; return BLAH2HIP_OK;
+  case BLAH2HIP_CLUTTER_INFO_SOLVE_E: *value = h->lastE; return BLAH2HIP_OK;
+  case BLAH2HIP_CLUTTER_INFO_SOLVE_G: *value = h->lastG; return BLAH2HIP_OK;
+  case BLAH2HIP_CLUTTER_INFO_SOLVE_FAULT: {
+    uint32_t v = 0;
+    CHIP(hipSetDevice(h->device));
+    CHIP(hipDeviceSynchronize());
+    if (h->d_epoch) CHIP(hipMemcpy(&v, h->d_epoch + 1, sizeof(v), hipMemcpyDeviceToHost));
+    *value = v;
+    return BLAH2HIP_OK;
+  }
+  default: CFAIL(BLAH2HIP_ERR_INVALID, "unknown info");
+  }
 }
 
 int blah2hip_clutter_read_last(blah2hip_clutter_t h, uint32_t cpi, float *w, double *rb, int *ok)
@@ -921,6 +1021,22 @@ int blah2hip_clutter_set_option(blah2hip_clutter_t h, int option, int64_t value)
     if (value && (int64_t)h->nBins > 1024 * value) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins needs more indices per thread");
     h->solveK = (int)value;
     return BLAH2HIP_OK;
+  case BLAH2HIP_CLUTTER_OPT_SOLVE_FORM:
+    if (value < BLAH2HIP_CLUTTER_SOLVE_AUTO || value > BLAH2HIP_CLUTTER_SOLVE_LOOKAHEAD)
+      CFAIL(BLAH2HIP_ERR_INVALID, "solve form: BLAH2HIP_CLUTTER_SOLVE_AUTO, _STEPWISE or _LOOKAHEAD");
+    h->solveForm = (int)value;
+    return BLAH2HIP_OK;
+  case BLAH2HIP_CLUTTER_OPT_SOLVE_E: {
+    if (value != 0 && value != 2 && value != 3 && value != 6 && value != 12)
+      CFAIL(BLAH2HIP_ERR_INVALID, "indices per lane of the look-ahead solve: 0 (by launch size), 2, 3, 6 or 12");
+    const int prev = h->solveE;
+    h->solveE = (int)value;
+    CHIP(hipSetDevice(h->device));
+    CHIP(hipDeviceSynchronize()); // the mailboxes may still be in use by enqueued work
+    const int rc = solve_la_alloc(h);
+    if (rc) h->solveE = prev;
+    return rc;
+  }
   case BLAH2HIP_CLUTTER_OPT_FFT_LEN:
   case BLAH2HIP_CLUTTER_OPT_CORR: {
     const bool isLen = option == BLAH2HIP_CLUTTER_OPT_FFT_LEN;
@@ -943,6 +1059,37 @@ int blah2hip_clutter_set_option(blah2hip_clutter_t h, int option, int64_t value)
   }
   default: CFAIL(BLAH2HIP_ERR_INVALID, "unknown option");
   }
+}
+
+int blah2hip_clutter_solve(blah2hip_clutter_t h, const double *rb, uint32_t n_cpi, float *w, int32_t *ok)
+{
+  if (!h || !rb || !w || !ok) CFAIL(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (n_cpi == 0 || n_cpi > h->maxBatch) CFAIL(BLAH2HIP_ERR_INVALID, "n_cpi outside [1, max_batch]");
+  CHIP(hipSetDevice(h->device));
+  const size_t n = (size_t)h->nBins;
+  CHIP(hipMemcpyAsync(h->d_rb, rb, (size_t)n_cpi * 2 * n * sizeof(dcx), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(solve_epoch_kernel, dim3(1), dim3(1), 0, h->stream, h->d_epoch);
+  SolveArgs sa;
+  sa.partial = nullptr; sa.rb = h->d_rb; sa.w = h->d_w; sa.ok = h->d_ok; sa.nBins = h->nBins; sa.nJobs = 0; sa.epoch = h->d_epoch;
+  { const int rc_ = launch_solve(h, sa, n_cpi, h->stream); if (rc_) return rc_; }
+  h->lastOk = h->d_ok;
+  CHIP(hipMemcpyAsync(w, h->d_w, (size_t)n_cpi * n * sizeof(cf), hipMemcpyDeviceToHost, h->stream));
+  CHIP(hipMemcpyAsync(ok, h->d_ok, (size_t)n_cpi * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  CHIP(hipStreamSynchronize(h->stream));
+  return BLAH2HIP_OK;
+}
+
+int blah2hip_clutter_solve_dev(blah2hip_clutter_t h, const double *d_rb, uint32_t n_cpi, float *d_w, int32_t *d_ok, void *stream)
+{
+  if (!h || !d_rb || !d_w || !d_ok) CFAIL(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (n_cpi == 0 || n_cpi > h->maxBatch) CFAIL(BLAH2HIP_ERR_INVALID, "n_cpi outside [1, max_batch]");
+  CHIP(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(solve_epoch_kernel, dim3(1), dim3(1), 0, st, h->d_epoch);
+  SolveArgs sa;
+  sa.partial = nullptr; sa.rb = (dcx *)d_rb; sa.w = (cf *)d_w; sa.ok = d_ok; sa.nBins = h->nBins; sa.nJobs = 0; sa.epoch = h->d_epoch;
+  h->lastOk = d_ok;
+  return launch_solve(h, sa, n_cpi, st);
 }
 
 int blah2hip_clutter_set_timing(blah2hip_clutter_t h, int enable)

@@ -448,6 +448,42 @@ class WienerHopf:
     def set_solve_indices_per_thread(self, k):
         check(self._L.blah2hip_clutter_set_option(self._h, _lib.CLUTTER_OPT_SOLVE_K, int(k)))
 
+    def set_solve_form(self, which, indices_per_lane=0):
+        """'auto' / 'stepwise' (one workgroup per CPI, a barrier per order) / 'lookahead' (blocks of 32 orders on several
+        workgroups per CPI); ``indices_per_lane`` in {0, 2, 3, 6, 12} fixes the look-ahead form's slice width."""
+        if isinstance(which, str):
+            which = {"auto": _lib.CLUTTER_SOLVE_AUTO, "stepwise": _lib.CLUTTER_SOLVE_STEPWISE,
+                     "lookahead": _lib.CLUTTER_SOLVE_LOOKAHEAD}[which]
+        check(self._L.blah2hip_clutter_set_option(self._h, _lib.CLUTTER_OPT_SOLVE_FORM, int(which)))
+        check(self._L.blah2hip_clutter_set_option(self._h, _lib.CLUTTER_OPT_SOLVE_E, int(indices_per_lane)))
+
+    def solve(self, r, b):
+        """The filter's Toeplitz solve alone: toeplitz(r) w = b for [n_cpi][nBins] (or [nBins]) complex r, b.
+        Returns (ok[n_cpi] bool, w[n_cpi][nBins] complex64)."""
+        r = np.atleast_2d(np.asarray(r, dtype=np.complex128))
+        b = np.atleast_2d(np.asarray(b, dtype=np.complex128))
+        if r.shape != b.shape or r.shape[1] != self.nBins:
+            raise ValueError(f"solve needs [n_cpi][{self.nBins}] arrays")
+        rb = np.ascontiguousarray(np.stack([r, b], axis=1))
+        w = np.empty((r.shape[0], self.nBins), dtype=np.complex64)
+        ok = np.zeros(r.shape[0], dtype=np.int32)
+        check(self._L.blah2hip_clutter_solve(self._h, _ptr(rb), r.shape[0], _ptr(w), _ptr(ok)))
+        return ok.astype(bool), w
+
+    def solve_dev(self, d_rb, n_cpi, d_w, d_ok, stream=0):
+        """Enqueue the solve on device arrays: d_rb [n_cpi][2][nBins] complex128, d_w [n_cpi][nBins] complex64, d_ok int32."""
+        check(self._L.blah2hip_clutter_solve_dev(self._h, d_rb, n_cpi, d_w, d_ok, stream))
+
+    def solve_info(self):
+        """What the last call's Toeplitz solve ran: {'form', 'E' (indices per lane), 'G' (workgroups per CPI), 'fault'}."""
+        out = {}
+        for name, what in (("form", _lib.CLUTTER_INFO_SOLVE_FORM), ("E", _lib.CLUTTER_INFO_SOLVE_E),
+                           ("G", _lib.CLUTTER_INFO_SOLVE_G), ("fault", _lib.CLUTTER_INFO_SOLVE_FAULT)):
+            v = C.c_int64(0)
+            check(self._L.blah2hip_clutter_get_info(self._h, what, C.byref(v)))
+            out[name] = int(v.value)
+        return out
+
     def read_last(self, cpi=0):
         """(ok, w, r, b) of CPI ``cpi`` of the last call: the nBins filter taps (complex64) and the fp64
         correlations r, b of the normal equations A w = b, A[i][j] = r[i-j] (diagnostics)."""

@@ -297,7 +297,30 @@ int blah2hip_clutter_process_dev_fmt(blah2hip_clutter_t h, int fmt, const void *
 #define BLAH2HIP_CLUTTER_CORR_AUTO 0
 #define BLAH2HIP_CLUTTER_CORR_HALF 1
 #define BLAH2HIP_CLUTTER_CORR_WINDOW 2
+/* The Toeplitz solve of the normal equations (WienerHopf.cpp:85-122).  SOLVE_FORM: _LOOKAHEAD = blocks of 32 orders on
+ * several workgroups per CPI (as many CUs as the launch leaves free; the default), _STEPWISE = the one-workgroup kernel,
+ * one barrier per order (SOLVE_K applies to it).  SOLVE_E: indices per lane of the look-ahead form's slices
+ * (2, 3, 6 or 12: 96 ... 736 indices per wave; 0 = the smallest whose workgroups each get a CU at the launch's batch). */
+#define BLAH2HIP_CLUTTER_OPT_SOLVE_FORM 4
+#define BLAH2HIP_CLUTTER_OPT_SOLVE_E 5
+#define BLAH2HIP_CLUTTER_SOLVE_AUTO 0
+#define BLAH2HIP_CLUTTER_SOLVE_STEPWISE 1
+#define BLAH2HIP_CLUTTER_SOLVE_LOOKAHEAD 2
 int blah2hip_clutter_set_option(blah2hip_clutter_t h, int option, int64_t value);
+/* What the last process call launched: the solve's form, indices per lane and workgroups per CPI; SOLVE_FAULT reads
+ * (synchronising) the word a look-ahead solve sets when one of its bounded waits ran out -- ok is 0 for that CPI. */
+#define BLAH2HIP_CLUTTER_INFO_SOLVE_FORM 1
+#define BLAH2HIP_CLUTTER_INFO_SOLVE_E 2
+#define BLAH2HIP_CLUTTER_INFO_SOLVE_G 3
+#define BLAH2HIP_CLUTTER_INFO_SOLVE_FAULT 4
+int blah2hip_clutter_get_info(blah2hip_clutter_t h, int what, int64_t *value);
+/* The filter's Toeplitz solve on its own: n_cpi systems toeplitz(r) w = b given as rb = [n_cpi][2][nBins] complex fp64 (r then b,
+ * interleaved re, im; the layout blah2hip_clutter_read_last returns), taps to w ([n_cpi][nBins] complex fp32), ok[c] = 0
+ * where the matrix is not positive definite (WienerHopf.cpp:111-115).  Host arrays; synchronises.  For tests and timing of the
+ * solve kernels apart from the correlations (set_timing / get_timing: BLAH2HIP_CK_SOLVE). */
+int blah2hip_clutter_solve(blah2hip_clutter_t h, const double *rb, uint32_t n_cpi, float *w, int32_t *ok);
+/* The same on device-resident arrays; enqueues only. */
+int blah2hip_clutter_solve_dev(blah2hip_clutter_t h, const double *d_rb, uint32_t n_cpi, float *d_w, int32_t *d_ok, void *stream);
 /* Derived sizes: nBins = delayMax - delayMin taps (WienerHopf.cpp:12), on-chip transform
  * length and samples per overlap-save block. */
 int blah2hip_clutter_get_dims(blah2hip_clutter_t h, uint32_t *n_bins, uint32_t *fft_len, uint32_t *seg_len);

@@ -62,3 +62,28 @@ def test_on_the_normal_equations_of_a_reference_fixture():
     w, ok2 = P.solve_lookahead(r_ref, b_ref, 16)
     assert ok2
     assert np.linalg.norm(w - w_ref) / np.linalg.norm(w_ref) <= 1e-9
+
+
+# ---- the wave-level model of the device's look-ahead kernel (csrc/solve_la.hpp): front wave + bulk slices ---------------
+spec2 = importlib.util.spec_from_file_location("toeplitz_front_bulk", os.path.join(ROOT, "tools", "proto", "toeplitz_front_bulk.py"))
+FB = importlib.util.module_from_spec(spec2)
+spec2.loader.exec_module(FB)
+
+
+@pytest.mark.parametrize("n,colour", [(1, 0.0), (2, 0.0), (33, 0.0), (34, 0.5), (97, 0.9), (300, 0.9), (411, 0.5)])
+@pytest.mark.parametrize("E", [1, 2, 3, 6, 12])
+def test_front_bulk_model_equals_stepwise(n, colour, E):
+    """Slices of 64 E - 32 indices with a halo of 32, blocks of 32 orders, the front's two 64-lane sets and its feed-in
+    schedule: the index algebra of the kernel, with the halo poisoned before every refresh."""
+    r, b = coloured_normal_equations(n, colour, 3 * n + E)
+    w1, ok1 = P.solve_stepwise(r, b)
+    w2, ok2 = FB.solve_front_bulk(r, b, E)
+    assert ok1 and ok2
+    scale = np.linalg.cond(P._toeplitz(r)) * 1e-15 if n > 1 else 1e-15
+    assert np.linalg.norm(w2 - w1) <= 50 * scale * np.linalg.norm(w1)
+
+
+def test_front_bulk_model_refuses_what_is_not_positive_definite():
+    r = np.array([1.0, 0.9, 1.2, 0.1, 0.0, 0.3], complex)
+    assert not FB.solve_front_bulk(r, np.ones(6), 2)[1]
+    assert not FB.solve_front_bulk(np.array([-1.0, 0.1], complex), np.ones(2), 3)[1]

@@ -9,7 +9,7 @@
 set -eu
 cd "$(dirname "$0")/.."
 mkdir -p tools/ab
-for v in rangew:RANGEW_TRACE dopw:DOPW_TRACE c2t:C2T_TRACE; do
+for v in ${TRACE_VARIANTS:-rangew:RANGEW_TRACE dopw:DOPW_TRACE c2t:C2T_TRACE sla:SLA_TRACE}; do
   n=${v%%:*}; m=${v##*:}
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -fno-slp-vectorize -D$m \
     -I include -I blah2_amd/csrc blah2_amd/csrc/capi.hip blah2_amd/csrc/clutter.hip blah2_amd/csrc/spectrum.hip \
