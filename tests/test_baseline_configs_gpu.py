@@ -15,7 +15,7 @@ def b2(built_lib):
     return blah2_amd
 
 
-def check(b2, cfg, expect_dims, targets, seed, elem_tol=2e-4):
+def check(b2, cfg, expect_dims, targets, seed, elem_tol=1e-4):
     dmin, dmax, fmin, fmax, fs, n = cfg
     x, y = O.synth_iq(n, seed=seed, fs=fs, targets=targets)
     amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True)
@@ -93,4 +93,4 @@ def test_fp16_iq_storage_fp32_accumulate(b2):
     err = np.abs(m.data.astype(np.complex128) - ref)
     assert err.max() / np.abs(ref).max() <= 1e-5
     strong = np.abs(ref) > np.mean(np.abs(ref))
-    assert np.max(err[strong] / np.abs(ref[strong])) <= 2e-4
+    assert np.max(err[strong] / np.abs(ref[strong])) <= 1e-4

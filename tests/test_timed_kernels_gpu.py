@@ -156,7 +156,7 @@ def test_one_wave_and_two_wave_tile_kernels(b2, fmax, n, nD, kernel):
 def test_four_wave_tile_kernel(b2, fmax, n, nD):
     """1025 < nD <= 2049 -> doppler_tilem_kernel<16> (four-wave columns, 4 per workgroup)."""
     geom = (-7, 292, -fmax, fmax, n, n)
-    amb = run_batch(b2, geom, 2, "tilem", seeds=(90 + nD, 91 + nD), targets=((37, -13.0, 0.05),), cell_tol=2e-4)
+    amb = run_batch(b2, geom, 2, "tilem", seeds=(90 + nD, 91 + nD), targets=((37, -13.0, 0.05),), cell_tol=1e-4)
     assert amb.get_n_doppler_bins() == nD
     from blah2_amd import _lib
     assert amb.info(_lib.INFO_DOPPLER_FFT_LEN) == 4096
@@ -176,7 +176,7 @@ def test_range_kernel_of_every_transform_length_batched(b2, geom, fft_len, kerne
     switches to the one-wave kernel); two distinct CPIs per launch."""
     from blah2_amd import _lib
     amb = run_batch(b2, geom, 2, "auto", seeds=(5, 6), expect=_expected_doppler(b2, geom),
-                    targets=((37, -13.0, 0.05),), cell_tol=2e-4)
+                    targets=((37, -13.0, 0.05),), cell_tol=1e-4)
     assert amb.dims.fft_len == fft_len
     assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == {"e8": _lib.RANGE_E8, "e16": _lib.RANGE_E16, "wave": _lib.RANGE_WAVE}[kernel]
 
@@ -243,7 +243,7 @@ def test_two_wave_range_kernel(b2, geom, fmt, xhalf):
     a lag window that starts at a positive lag, and the int16 wire format."""
     from blah2_amd import _lib
     amb = run_batch(b2, geom, 3, "auto", seeds=(120, 121, 122), fmt=fmt, fft_len=4096, range_kernel=_lib.RANGE_WAVE2,
-                    expect=_expected_doppler3(geom), targets=((37, -13.0, 0.05),), cell_tol=2e-4)
+                    expect=_expected_doppler3(geom), targets=((37, -13.0, 0.05),), cell_tol=1e-4)
     assert amb.dims.fft_len == 4096 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE2
     assert (amb.dims.seg_len <= 2048) == xhalf
 
@@ -283,7 +283,7 @@ def test_one_wave_1024_range_kernel(b2, geom, fmt, seg576, shortx, out7, grid):
     576-sample segmentation, pulse boundaries inside a wave's walk (grid cap), waves without work."""
     from blah2_amd import _lib
     amb = run_batch(b2, geom, 3, "auto", seeds=(150, 151, 152), fmt=fmt, fft_len=1024, range_kernel=_lib.RANGE_WAVE1K,
-                    expect=_expected_doppler3(geom), targets=((37, -13.0, 0.05),), cell_tol=2e-4, range_grid=grid)
+                    expect=_expected_doppler3(geom), targets=((37, -13.0, 0.05),), cell_tol=1e-4, range_grid=grid)
     assert amb.dims.fft_len == 1024 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE1K
     assert (amb.dims.seg_len == 576) == seg576 and (amb.dims.seg_len <= 576) == shortx and (amb.get_n_delay_bins() <= 448) == out7
     if grid:
