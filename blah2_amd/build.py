@@ -79,18 +79,25 @@ HOSTTEST = os.path.join(HOST, "test", "test_ambiguity")
 
 
 def build_host_test(force=False, verbose=True):
-    """C++ test program for the drop-in classes (mirrors the reference's TestAmbiguity.cpp)."""
-    src = os.path.join(HOST, "test", "test_ambiguity.cpp")
-    if not os.path.exists(src) or not os.path.exists(HOSTLIB):
+    """C++ test programs for the drop-in classes: test_ambiguity (mirrors the reference's TestAmbiguity.cpp) and
+    test_golden (the classes against the compiled reference's values, tests/test_host_cpp_gpu.py)."""
+    if not os.path.exists(HOSTLIB):
         return None
-    if not force and not _newer(HOSTTEST, [src, HOSTLIB, LIB]):
-        return HOSTTEST
-    cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", HOST, src, "-o", HOSTTEST,
-           "-L", PKG, "-lblah2host", "-lblah2hip", "-Wl,-rpath,$ORIGIN/../.."]
-    if verbose:
-        print("[blah2_amd.build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return HOSTTEST
+    last = None
+    for name in ("test_ambiguity", "test_golden"):
+        src = os.path.join(HOST, "test", name + ".cpp")
+        exe = os.path.join(HOST, "test", name)
+        if not os.path.exists(src):
+            continue
+        last = exe
+        if not force and not _newer(exe, [src, HOSTLIB, LIB]):
+            continue
+        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", HOST, src, "-o", exe,
+               "-L", PKG, "-lblah2host", "-lblah2hip", "-Wl,-rpath,$ORIGIN/../.."]
+        if verbose:
+            print("[blah2_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return last
 
 
 def build_all(force=False, verbose=True):

@@ -2,7 +2,7 @@
 // test/unit/process/ambiguity/TestAmbiguity.cpp (Catch2 is not available in
 // this image, so plain checks).  Exercises the exact call sequence of
 // blah2.cpp:268-287 through the drop-in classes.  Run on a GPU box:
-//     test_ambiguity [golden.bin]
+//     test_ambiguity [--sequence]        (the values of the compiled reference: test_golden.cpp)
 // Exit code 0 = all checks passed.
 #include "data/IqData.h"
 #include "data/Map.h"
