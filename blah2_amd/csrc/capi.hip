@@ -355,26 +355,7 @@ template <class In> int launch_rangew_t(blah2hip_amb_s *h, const RangeArgs &a, I
   auto kern = shortw ? rangew_kernel<In, true, true> : (out7 ? rangew_kernel<In, false, true> : rangew_kernel<In, false, false>);
   LDSCFG(kern, lds);
   const int grid = std::min<int>((a.nPulses + RANGEW_WAVES - 1) / RANGEW_WAVES, range_grid_cap(h, lds, RANGEW_WAVES, 4 * RANGEW_WAVES_PER_SIMD));
-#ifdef RANGEW_TRACE
-  static uint64_t *dbg = nullptr;
-  static int calls = 0;
-  if (!dbg) HIPCHK(hipMalloc(&dbg, 64));
-  HIPCHK(hipMemsetAsync(dbg, 0, 64, st));
-  RangeArgs a2 = a;
-  a2.dbg = dbg;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RANGEW_WAVES), lds, st, a2, in);
-  if (++calls == 8) {
-    uint64_t hcnt[6];
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipMemcpy(hcnt, dbg, 48, hipMemcpyDeviceToHost));
-    double tot = 0;
-    for (int k = 0; k < 6; k++) tot += (double)hcnt[k];
-    fprintf(stderr, "[rangew trace] grid %d pulses %d: other %.3f load %.3f X %.3f Y %.3f inv %.3f store %.3f of %.0f ticks/wave\n", grid, a.nPulses,
-            hcnt[0] / tot, hcnt[1] / tot, hcnt[2] / tot, hcnt[3] / tot, hcnt[4] / tot, hcnt[5] / tot, tot / grid / RANGEW_WAVES);
-  }
-#else
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RANGEW_WAVES), lds, st, a, in);
-#endif
   HIPCHK(hipGetLastError());
   h->lastRange = BLAH2HIP_RANGE_WAVE;
   return BLAH2HIP_OK;
@@ -389,49 +370,6 @@ template <class In> int launch_rangew_t(blah2hip_amb_s *h, const RangeArgs &a, I
 // (cfg 3 x 8): 568 vs 707.  The 8-point transform executes 26 % more VALU instructions per point
 // (radix 8-8-8-4 twiddles + the lane butterflies) and the kernel follows that count, not its occupancy.
 // F = 4096 on the two-wave kernel
-bool use_wave2_range(const blah2hip_amb_s *h, int nPulses)
-{
-  if (h->r3 != 16 || h->rangeKernel == BLAH2HIP_RANGE_E16) return false;
-  // Only on request.  Measured (round 3, cfg 3 x 32, same box, interleaved): 63.8 us/CPI against 60.6-61.3 for the
-  // workgroup kernel.  A wave of the pair spends what a wave of the one-wave kernel spends per 32-point-per-lane
-  // transform (10.9 k cycles per transform incl. its share of the loads, s_memtime trace), but a 4096-point transform
-  // is two of those -- 22 wave-transforms per pulse either way; the single exchange does not buy what the second
-  // twiddle multiply and the pair's barriers cost.
-  (void)nPulses;
-  return h->rangeKernel == BLAH2HIP_RANGE_WAVE2;
-}
-
-template <class In> int launch_rangew2_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
-{
-  const size_t lds = Wave2Fft::LDS_BYTES;
-  const bool xhalf = a.plan.segLen <= 16 * 128;
-  auto kern = xhalf ? rangew2_kernel<In, true> : rangew2_kernel<In, false>;
-  LDSCFG(kern, lds);
-  const int grid = std::min<int>(a.nPulses, range_grid_cap(h, lds, 2, 8)); // four pairs per CU (LDS; 2 waves per SIMD)
-#ifdef RANGEW_TRACE
-  static uint64_t *dbg = nullptr;
-  static int calls = 0;
-  if (!dbg) HIPCHK(hipMalloc(&dbg, 64));
-  HIPCHK(hipMemsetAsync(dbg, 0, 64, st));
-  RangeArgs a2 = a;
-  a2.dbg = dbg;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(Wave2Fft::NT), lds, st, a2, in);
-  if (++calls == 8) {
-    uint64_t hcnt[6];
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipMemcpy(hcnt, dbg, 48, hipMemcpyDeviceToHost));
-    double tot = 0;
-    for (int k = 0; k < 6; k++) tot += (double)hcnt[k];
-    fprintf(stderr, "[rangew2 trace] grid %d pulses %d: other %.3f load %.3f X %.3f Y %.3f inv %.3f store %.3f of %.0f ticks/wave\n", grid, a.nPulses,
-            hcnt[0] / tot, hcnt[1] / tot, hcnt[2] / tot, hcnt[3] / tot, hcnt[4] / tot, hcnt[5] / tot, tot / grid / 2);
-  }
-#else
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(Wave2Fft::NT), lds, st, a, in);
-#endif
-  HIPCHK(hipGetLastError());
-  h->lastRange = BLAH2HIP_RANGE_WAVE2;
-  return BLAH2HIP_OK;
-}
 
 // F = 1024 on the one-wave kernel with 16 points per lane (four waves per SIMD)
 bool use_wave1k_range(const blah2hip_amb_s *h, int nPulses)
@@ -452,26 +390,7 @@ template <class In> int launch_rangew1k_t(blah2hip_amb_s *h, const RangeArgs &a,
                        : (out7 ? rangew1k_kernel<In, false, true> : rangew1k_kernel<In, false, false>);
   LDSCFG(kern, lds);
   const int grid = std::min<int>((a.nPulses + RANGEW1K_WAVES - 1) / RANGEW1K_WAVES, range_grid_cap(h, lds, RANGEW1K_WAVES, 4 * RANGEW1K_WAVES_PER_SIMD));
-#ifdef RANGEW_TRACE
-  static uint64_t *dbg = nullptr;
-  static int calls = 0;
-  if (!dbg) HIPCHK(hipMalloc(&dbg, 64));
-  HIPCHK(hipMemsetAsync(dbg, 0, 64, st));
-  RangeArgs a2 = a;
-  a2.dbg = dbg;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RANGEW1K_WAVES), lds, st, a2, in);
-  if (++calls == 8) {
-    uint64_t hcnt[6];
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipMemcpy(hcnt, dbg, 48, hipMemcpyDeviceToHost));
-    double tot = 0;
-    for (int k = 0; k < 6; k++) tot += (double)hcnt[k];
-    fprintf(stderr, "[rangew1k trace] grid %d pulses %d: loop %.3f wait-x %.3f X %.3f wait-y %.3f Y+product %.3f inverse+store %.3f of %.0f ticks/wave\n", grid, a.nPulses,
-            hcnt[0] / tot, hcnt[1] / tot, hcnt[2] / tot, hcnt[3] / tot, hcnt[4] / tot, hcnt[5] / tot, tot / grid / RANGEW1K_WAVES);
-  }
-#else
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RANGEW1K_WAVES), lds, st, a, in);
-#endif
   HIPCHK(hipGetLastError());
   h->lastRange = BLAH2HIP_RANGE_WAVE1K;
   return BLAH2HIP_OK;
@@ -481,7 +400,6 @@ template <class In> int launch_range(blah2hip_amb_s *h, const RangeArgs &a, In i
 {
   if (use_wave_range(h, a.nPulses)) return launch_rangew_t(h, a, in, st);
   if (use_wave1k_range(h, a.nPulses)) return launch_rangew1k_t(h, a, in, st);
-  if (use_wave2_range(h, a.nPulses)) return launch_rangew2_t(h, a, in, st);
   switch (h->r3) {
   case 4: return launch_range8_t<2>(h, a, in, st);
   case 8: return launch_range_t<8>(h, a, in, st);
@@ -809,13 +727,11 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
     h->rangeGridForce = (int)value;
     return BLAH2HIP_OK;
   case BLAH2HIP_OPT_RANGE_KERNEL:
-    if (value != 0 && value != BLAH2HIP_RANGE_WAVE && value != BLAH2HIP_RANGE_E16 && value != BLAH2HIP_RANGE_WAVE2 &&
-        value != BLAH2HIP_RANGE_WAVE1K && value != BLAH2HIP_RANGE_E8)
-      return fail(BLAH2HIP_ERR_INVALID, "range kernel: 0 (by transform length), BLAH2HIP_RANGE_E16, _E8, _WAVE, _WAVE2 or _WAVE1K");
+    if (value != 0 && value != BLAH2HIP_RANGE_WAVE && value != BLAH2HIP_RANGE_E16 && value != BLAH2HIP_RANGE_WAVE1K &&
+        value != BLAH2HIP_RANGE_E8)
+      return fail(BLAH2HIP_ERR_INVALID, "range kernel: 0 (by transform length), BLAH2HIP_RANGE_E16, _E8, _WAVE or _WAVE1K");
     if ((value == BLAH2HIP_RANGE_WAVE1K || value == BLAH2HIP_RANGE_E8) && h->r3 != 4)
       return fail(BLAH2HIP_ERR_UNSUPPORTED, "the 16-points-per-lane one-wave kernel and the 8-points-per-thread kernel are 1024-point transforms");
-    if (value == BLAH2HIP_RANGE_WAVE2 && h->r3 != 16)
-      return fail(BLAH2HIP_ERR_UNSUPPORTED, "the two-wave range kernel is a 4096-point transform");
     if (value == BLAH2HIP_RANGE_WAVE && h->r3 != 8)
       return fail(BLAH2HIP_ERR_UNSUPPORTED, "the one-wave range kernel is a 2048-point transform");
     if (value == BLAH2HIP_RANGE_E16 && h->r3 == 4)
@@ -1001,24 +917,7 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     // persistent: one workgroup per CU (LDS) walks the tiles of the whole batch
     const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, h->dopGridForce ? h->dopGridForce : h->numCU);
     dopGrid = wgs; dopTiles = grid * (int)n_cpi;
-#ifdef DOPW_TRACE
-    static uint64_t *dbg = nullptr;
-    static int calls = 0;
-    if (!dbg) HIPCHK(hipMalloc(&dbg, 64));
-    HIPCHK(hipMemsetAsync(dbg, 0, 64, st));
-    hipLaunchKernelGGL(doppler_tilew_kernel, dim3(wgs), dim3(64 * DOPW_NCOL), lds, st, da, (int)n_cpi, dbg);
-    if (++calls == 8) {
-      uint64_t hc[8];
-      HIPCHK(hipStreamSynchronize(st));
-      HIPCHK(hipMemcpy(hc, dbg, 64, hipMemcpyDeviceToHost));
-      double tot = 0;
-      for (int k = 0; k < 8; k++) tot += (double)hc[k];
-      fprintf(stderr, "[dopw trace] wgs %d: fill %.3f barriers %.3f colread+issue %.3f transforms %.3f bfmul %.3f park %.3f stores %.3f of %.0f ticks/wave\n", wgs,
-              hc[0] / tot, hc[1] / tot, hc[2] / tot, hc[3] / tot, hc[4] / tot, hc[5] / tot, hc[6] / tot, tot / wgs / DOPW_NCOL);
-    }
-#else
-    hipLaunchKernelGGL(doppler_tilew_kernel, dim3(wgs), dim3(64 * DOPW_NCOL), lds, st, da, (int)n_cpi, (uint64_t *)nullptr);
-#endif
+    hipLaunchKernelGGL(doppler_tilew_kernel, dim3(wgs), dim3(64 * DOPW_NCOL), lds, st, da, (int)n_cpi);
     nPartsUsed = grid;
     break;
   }
@@ -1364,14 +1263,6 @@ int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
     const size_t lds = c2t_lds_bytes(hC, ta.alphaLds);
     const int64_t nAll = (int64_t)ta.tilesX * ta.tilesY * n_cpi;
     const int grid = (int)std::max<int64_t>(8, (std::min<int64_t>(nAll, h->numCU) + 7) & ~7); // one persistent workgroup per CU (LDS)
-    ta.dbg = nullptr;
-#ifdef C2T_TRACE
-    static uint64_t *dbg = nullptr;
-    static int calls = 0;
-    if (!dbg) HIPCHK(hipMalloc(&dbg, 80));
-    HIPCHK(hipMemsetAsync(dbg, 0, 80, st));
-    ta.dbg = dbg;
-#endif
     if ((rc = tic(h, BLAH2HIP_K_CFAR, st))) return rc;
     auto launch = [&](auto kern) -> int {
       LDSCFG(kern, lds);
@@ -1384,17 +1275,6 @@ int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     if ((rc = toc(h, BLAH2HIP_K_CFAR, st))) return rc;
-#ifdef C2T_TRACE
-    if (++calls == 8) {
-      uint64_t hc[10];
-      HIPCHK(hipStreamSynchronize(st));
-      HIPCHK(hipMemcpy(hc, dbg, 80, hipMemcpyDeviceToHost));
-      double tot = 0;
-      for (int k = 0; k < 10; k++) tot += (double)hc[k];
-      fprintf(stderr, "[c2t trace] grid %d tiles %lld: loop+decode %.3f fill %.3f bar1 %.3f issue %.3f row sums %.3f row stores %.3f bar2 %.3f col sums %.3f tests %.3f bar3 %.3f of %.0f ticks/wave\n",
-              grid, (long long)nAll, hc[0] / tot, hc[1] / tot, hc[2] / tot, hc[3] / tot, hc[9] / tot, hc[4] / tot, hc[5] / tot, hc[8] / tot, hc[6] / tot, hc[7] / tot, tot / grid / C2T_WAVES);
-    }
-#endif
     return BLAH2HIP_OK;
   }
   if ((rc = tic(h, BLAH2HIP_K_SAT_ROWS, st))) return rc;

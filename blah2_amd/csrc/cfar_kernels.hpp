@@ -11,6 +11,7 @@
 
 #include "blah2hip.h"
 #include "fft_wg.hpp"
+#include "trace.hpp"
 
 namespace blah2 {
 
@@ -237,7 +238,6 @@ struct Cfar2dTileArgs {
   Cfar2dArgs d;
   int32_t nCpi, tilesX, tilesY, rowsOut; // rowsOut = 64 - 2 hR output rows per tile
   int32_t alphaLds;                      // entries of the threshold table staged in LDS (the whole table, or 0: read from L2)
-  uint64_t *dbg;                         // trace builds only (tools/build_trace.sh): s_memtime ticks per phase
 };
 
 // One run of N window positions through a rotating register window: at step p the eight values LD(p + m), m < 8,
@@ -483,9 +483,8 @@ __global__ __launch_bounds__(64 * C2T_WAVES) void cfar2d_tile_kernel(Cfar2dTileA
     __syncthreads(); // S and AB are rewritten by the next tile
     C2_T(7)
   }
-#ifdef C2T_TRACE
-  if (lane == 0 && ta.dbg)
-    for (int k = 0; k < 10; k++) atomicAdd((unsigned long long *)&ta.dbg[k], (unsigned long long)tr[k]);
+#ifdef C2T_TRACE // buckets: loop + decode, fill, barrier 1, issue, row stores, barrier 2, tests, barrier 3, column sums, row sums
+  if (lane == 0) trace_finish("c2t", tr, blockIdx.x == 0 && threadIdx.x == 0);
 #endif
 }
 

@@ -24,6 +24,7 @@
 #include "fft_wave2.hpp"
 #include "fft_wave1k.hpp"
 #include "bufload.hpp"
+#include "trace.hpp"
 
 namespace blah2 {
 
@@ -49,7 +50,6 @@ struct RangeArgs {
   cf *out;             // tiled range map, see rmap_index()
   int64_t cpiStride;   // samples between consecutive CPIs of the batch
   int32_t nPulses;     // nCpi * nDoppler
-  uint64_t *dbg = nullptr; // trace builds only (tools/): cycle counts per phase
 };
 
 // segment s of the pulse at sample index pulseBase: v[k] = x'[t + T*k], yv[k] = y'[t + T*k]
@@ -377,9 +377,8 @@ __global__ __launch_bounds__(64 * RANGEW_WAVES, RANGEW_WAVES_PER_SIMD) void rang
     store_lags_w<OUT7 ? 7 : 32>(a.out, p, cpi, i, t, acc);
     RW_T(5)
   }
-#ifdef RANGEW_TRACE
-  if (t == 0 && a.dbg)
-    for (int k = 0; k < 6; k++) atomicAdd((unsigned long long *)&a.dbg[k], (unsigned long long)tr[k]);
+#ifdef RANGEW_TRACE // buckets: other, load, X, Y, inverse, store
+  if (t == 0) trace_finish("rangew", tr, blockIdx.x == 0 && threadIdx.x == 0);
 #endif
 }
 
@@ -549,8 +548,7 @@ __global__ __launch_bounds__(64 * RANGEW1K_WAVES, RANGEW1K_WAVES_PER_SIMD) void 
 #ifdef RANGEW_TRACE
       RW_T(5)
       if (!more) {
-        if (t == 0 && a.dbg)
-          for (int k = 0; k < 6; k++) atomicAdd((unsigned long long *)&a.dbg[k], (unsigned long long)tr[k]);
+        if (t == 0) trace_finish("rangew1k", tr, blockIdx.x == 0 && threadIdx.x == 0);
         break;
       }
 #else
@@ -565,123 +563,6 @@ __global__ __launch_bounds__(64 * RANGEW1K_WAVES, RANGEW1K_WAVES_PER_SIMD) void 
     s = ns;
     base = nbase;
   }
-}
-
-// --------------------------------------------------------------------------
-// Range kernel on the two-wave transform (fft_wave2.hpp, F = 4096): identical mathematics and interface, one PAIR of
-// waves per pulse, 32 points per thread, one LDS exchange and two two-wave barriers per transform.  A workgroup is one
-// pair (128 threads, 39.7 KB of LDS): four of them per CU, each walking its own pulses, synchronising with nobody else.
-// segment s of the pulse: v[k] = x'[T + 128*k], k < NX, yv[k] = y'[T + 128*k], T the thread's logical index
-template <class In, int NX>
-__device__ __forceinline__ void bufload_seg_w2(const In &in, const RangePlan &p, int64_t pulseBase, int s, int T, cf *v, cf *yv)
-{
-  static_assert(NX == 16 || NX == 32, "");
-  using B = BufLoad<In>;
-  using CX = typename B::X;
-  using CY = typename B::Y;
-  constexpr int STEPX = 128 * CX::STRIDE, STEPY = 128 * CY::STRIDE;
-  constexpr int NV = (31 * STEPY >> 12) + 1;
-  const int s0 = s * p.segLen;
-  const int cnt = min(p.segLen, p.nCorr - s0);
-  const b2_v4i xd = make_rsrc(B::xp(in, pulseBase + s0), cnt * CX::STRIDE);
-  const b2_v4i yd = make_rsrc(B::yp(in, pulseBase), p.nCorr * CY::STRIDE);
-  int vx[1] = {T * CX::STRIDE};
-  int vy[NV];
-#pragma unroll
-  for (int j = 0; j < NV; j++) vy[j] = (s0 + p.delayMin + T) * CY::STRIDE + j * 4096; // may be negative: reads as zero
-  typename CX::raw xr[NX];
-  typename CY::raw yr[32];
-  bufload_chan<CX, STEPX, NX, true>(xr, xd, vx);
-  bufload_chan<CY, STEPY, 32, false>(yr, yd, vy);
-  bufwait<32 + NX - 16, 16>(xr);
-  if constexpr (NX == 32) bufwait<32, 16>(xr + 16);
-#pragma unroll
-  for (int k = 0; k < NX; k++) v[k] = CX::cvt(xr[k]);
-  bufwait<16, 16>(yr);
-  bufwait<0, 16>(yr + 16);
-#pragma unroll
-  for (int k = 0; k < 32; k++) yv[k] = CY::cvt(yr[k]);
-}
-
-// lags z[T + 128*c] of one pulse into the tiled range map: thread T owns position T & 15 of tile (T >> 4) + 8*c
-__device__ __forceinline__ void store_lags_w2(cf *out, const RangePlan &p, int cpi, int pulse, int T, const cf *v)
-{
-  const int jt = T + (p.colOff & 15); // see store_lags_w
-  cf *o = out + (((int64_t)cpi * p.nTilesOut + (p.colOff >> 4) + (jt >> 4)) * p.nDoppler + pulse) * 16 + (jt & 15);
-  const int64_t step = (int64_t)p.nDoppler * 128; // eight tiles
-  int rem = p.nDelay - T;                         // thread T stores register c iff 128*c < rem
-  int nd = p.nDelay;
-  asm volatile("" : "+v"(rem), "+s"(nd)); // opaque per call, see store_lags_w
-#pragma unroll
-  for (int c = 0; c < 32; c++) {
-    if (128 * c >= nd) break; // uniform
-    if (128 * c < rem) *o = cmake(v[c].x * p.scale, v[c].y * p.scale);
-    o += step;
-  }
-}
-
-// XHALF: segLen <= 16*128 -- x' is zero from sample 2048 on (cfg 3: 1952 of 4096): 16 of the 32 x loads are not issued
-// and the first 32-point step of the x transform skips the zero inputs.
-template <class In, bool XHALF>
-__global__ __launch_bounds__(128, 2) void rangew2_kernel(RangeArgs a, In in)
-{
-  using W = Wave2Fft;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  cf *table = reinterpret_cast<cf *>(smem);
-  cf *X = table + W::TW_ELEMS;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int T = W::logical(wave, lane);
-  W::fill_table(threadIdx.x, W::NT, a.tw, table);
-  __syncthreads();
-  W::Tw w;
-  W::load_twiddles(wave, lane, a.tw, table, w);
-  const RangePlan p = a.plan;
-#ifdef RANGEW_TRACE
-  uint64_t tr[6] = {0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime();
-#endif
-  for (int pulse = blockIdx.x; pulse < a.nPulses; pulse += gridDim.x) {
-    const int cpi = pulse / p.nDoppler;
-    const int i = pulse - cpi * p.nDoppler;
-    const int64_t base = (int64_t)cpi * a.cpiStride + (int64_t)i * p.nCorr;
-    cf acc[32];
-#pragma unroll
-    for (int e = 0; e < 32; e++) acc[e] = cmake(0.f, 0.f);
-    for (int s = 0; s < p.nSeg; s++) {
-      cf v[32], yv[32];
-      constexpr int NX = XHALF ? 16 : 32;
-      RW_T(0)
-      bufload_seg_w2<In, NX>(in, p, base, s, T, v, yv);
-#ifdef RANGEW_TRACE
-      asm volatile("" : "+v"(v[0].x), "+v"(yv[31].y));
-#endif
-      RW_T(1)
-      W::transform<-1, NX>(wave, lane, v, w, X);  // v  = X spectrum
-#ifdef RANGEW_TRACE
-      asm volatile("" : "+v"(v[0].x));
-#endif
-      RW_T(2)
-      W::transform<-1, 32>(wave, lane, yv, w, X); // yv = Y spectrum
-#ifdef RANGEW_TRACE
-      asm volatile("" : "+v"(yv[0].x));
-#endif
-      RW_T(3)
-#pragma unroll
-      for (int e = 0; e < 32; e++) acc[e] = cmacc(acc[e], yv[e], v[e]);
-    }
-    RW_T(0)
-    W::transform<+1, 32>(wave, lane, acc, w, X);
-#ifdef RANGEW_TRACE
-    asm volatile("" : "+v"(acc[0].x));
-#endif
-    RW_T(4)
-    store_lags_w2(a.out, p, cpi, i, T, acc);
-    RW_T(5)
-  }
-#ifdef RANGEW_TRACE
-  if (lane == 0 && a.dbg)
-    for (int k = 0; k < 6; k++) atomicAdd((unsigned long long *)&a.dbg[k], (unsigned long long)tr[k]);
-#endif
 }
 
 // --------------------------------------------------------------------------
@@ -1188,7 +1069,7 @@ constexpr int DOPW_RS = WaveFft::X_ELEMS + 2;
 static_assert(DOPW_RS % 8 == 2, "");
 constexpr int DOPW_CHIRP_ELEMS = 1088; // rows t + 64*k, k < 17
 constexpr int DOPW_LDS_ELEMS = WaveFft::TW_ELEMS + DOPW_NCOL * DOPW_RS + DOPW_CHIRP_ELEMS;
-__global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(DopplerArgs a, int nCpi, uint64_t *dbg)
+__global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(DopplerArgs a, int nCpi)
 {
 #ifdef DOPW_TRACE
   uint64_t tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime();
@@ -1364,9 +1245,8 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
     }
     DW_T(1)
   }
-#ifdef DOPW_TRACE
-  if (t == 0 && dbg)
-    for (int k = 0; k < 8; k++) atomicAdd((unsigned long long *)&dbg[k], (unsigned long long)tr[k]);
+#ifdef DOPW_TRACE // buckets: fill, barriers, column read + issue, transforms, kernel-spectrum product, park, stores
+  if (t == 0) trace_finish("dopw", tr, blockIdx.x == 0);
 #endif
 }
 

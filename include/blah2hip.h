@@ -154,7 +154,7 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 #define BLAH2HIP_RANGE_E16 1   /* 16 points per thread, one workgroup per pulse (F = 4096; F = 2048 on request) */
 #define BLAH2HIP_RANGE_E8 2    /* 8 points per thread, last stage across lanes (F = 1024) */
 #define BLAH2HIP_RANGE_WAVE 3  /* one wave per pulse, 32 points per lane, no barriers (F = 2048) */
-#define BLAH2HIP_RANGE_WAVE2 4 /* a pair of waves per pulse, 32 points per thread, one exchange (F = 4096) */
+/* 4: was BLAH2HIP_RANGE_WAVE2 (a pair of waves per pulse at F = 4096; measured 5 % slower than _E16 and removed in round 4) */
 #define BLAH2HIP_RANGE_WAVE1K 5 /* one wave per pulse, 16 points per lane, four waves per SIMD (F = 1024) */
 /* BLAH2HIP_ERR_UNSUPPORTED when the kernel does not cover the handle's Doppler length */
 int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value);

@@ -236,15 +236,15 @@ def test_mixed_format_int16_reference_fp32_surveillance(b2, geom, fft_len):
                                             ((-24, 2023, -64, 64, 1_260_000, 1_260_000), "i16", True),
                                             ((-10, 89, -20, 20, 123_000, 123_000), "c32", False),
                                             ((1, 299, -100, 100, 1_000_000, 777_001), "c32", False)])
-def test_two_wave_range_kernel(b2, geom, fmt, xhalf):
-    """rangew2_kernel (a pair of waves per pulse on the two-wave 4096-point transform: v_permlane32_swap and
-    v_permlane16_swap radix-2 steps, one LDS exchange), forced, three CPIs per launch: the half-zero reference
-    segments of the configs[2] shape (16 of 32 x loads, pruned first step), full segments, a ragged pulse length with
-    a lag window that starts at a positive lag, and the int16 wire format."""
+def test_4096_point_range_kernel_shapes(b2, geom, fmt, xhalf):
+    """range_kernel<16> (F = 4096, the workgroup transform), three CPIs per launch: the half-zero reference segments of the
+    configs[2] shape (9 of 16 x loads, pruned first step), full segments, a ragged pulse length with a lag window that
+    starts at a positive lag, and the int16 wire format.  (Round 3 ran these shapes on the two-wave rangew2_kernel too;
+    it measured 5 % slower than this one, spilled, and was removed in round 4.)"""
     from blah2_amd import _lib
-    amb = run_batch(b2, geom, 3, "auto", seeds=(120, 121, 122), fmt=fmt, fft_len=4096, range_kernel=_lib.RANGE_WAVE2,
+    amb = run_batch(b2, geom, 3, "auto", seeds=(120, 121, 122), fmt=fmt, fft_len=4096, range_kernel=_lib.RANGE_E16,
                     expect=_expected_doppler3(geom), targets=((37, -13.0, 0.05),), cell_tol=1e-4)
-    assert amb.dims.fft_len == 4096 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE2
+    assert amb.dims.fft_len == 4096 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_E16
     assert (amb.dims.seg_len <= 2048) == xhalf
 
 

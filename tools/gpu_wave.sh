@@ -17,7 +17,7 @@ except Exception as e:
 PY
 }
 run base "" 
-run wave2 "" --range-kernel wave
+
 for f in tools/ab/lib_w*.so; do
   t=$(basename $f .so)
   run $t $REPO/$f --range-kernel wave; grep trace $OUT/bw_$t.err | tail -n 2
