@@ -276,11 +276,11 @@ def main(argv=None):
     ap.add_argument("--n-doppler", type=int, default=0,
                     help="explicit number of Doppler bins (extension; 0 = the reference constructor's rule, which gives "
                          "513 at the headline configuration; 512 gives the literal BASELINE wording)")
-    ap.add_argument("--doppler-kernel", default="auto", help="force a Doppler kernel (auto, tile8, tile16, tilew, tilem, column, direct)")
+    ap.add_argument("--doppler-kernel", default="auto", help="force a Doppler kernel (auto, tile8, tile16, sub4, tilew, tilew2, tilem, column, direct)")
     ap.add_argument("--prewarm-s", type=float, default=0.6,
                     help="seconds of untimed steps BEFORE the W warmup steps: the shader clock needs ~0.3 s of load to ramp up "
                          "from idle (measured: steps 5..25 of a cold run are 4-5 %% slower than steady state)")
-    ap.add_argument("--range-kernel", default="auto", choices=["auto", "wave", "wave1k", "e16", "e8"],
+    ap.add_argument("--range-kernel", default="auto", choices=["auto", "wave", "wave1k", "ps", "e16", "e8"],
                     help="range kernel: by transform length (F = 2048: the one-wave kernel, F = 4096: the two-wave kernel), or forced")
     ap.add_argument("--fft-len", type=int, default=0, choices=[0, 1024, 2048, 4096],
                     help="force the range transform length (0 = the planner's choice); diagnostics")
@@ -322,7 +322,7 @@ def main(argv=None):
         if a.fft_len:
             h_.set_fft_len(a.fft_len)
         if a.range_kernel != "auto":
-            h_.set_range_kernel({"wave": blah2_amd._lib.RANGE_WAVE, "wave1k": blah2_amd._lib.RANGE_WAVE1K, "e8": blah2_amd._lib.RANGE_E8,
+            h_.set_range_kernel({"wave": blah2_amd._lib.RANGE_WAVE, "wave1k": blah2_amd._lib.RANGE_WAVE1K, "ps": blah2_amd._lib.RANGE_PS, "e8": blah2_amd._lib.RANGE_E8,
                                  "e16": blah2_amd._lib.RANGE_E16}[a.range_kernel])
     amb = ambs[0]
     nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
@@ -471,7 +471,7 @@ def main(argv=None):
     # passes of this same command (tools/summarize_prof.py -> profiles/*_traffic.json)
     traffic, traffic_src = None, None
     import glob
-    ran_range = {1: "range_kernel", 2: "range8_kernel", 3: "rangew_kernel", 5: "rangew1k_kernel"}.get(
+    ran_range = {1: "range_kernel", 2: "range8_kernel", 3: "rangew_kernel", 5: "rangew1k_kernel", 6: "rangeps_kernel"}.get(
         amb.info(blah2_amd._lib.INFO_LAST_RANGE_KERNEL), "range_kernel")
     prof_names = {"range": (ran_range,), "doppler": ("doppler_",),  # the range kernel this run launched, no other
                   "metrics": ("metrics_kernel",), "cfar": ("cfar2d_tile_kernel", "cfar2d_kernel", "cfar1d_kernel"),
@@ -559,14 +559,14 @@ def main(argv=None):
                        "fft_len": amb.dims.fft_len, "n_seg": amb.dims.n_seg, "seg_len": amb.dims.seg_len,
                        "doppler_kernel": amb.last_doppler_kernel(),
                        "prewarm_s": a.prewarm_s, "prewarm_steps": n_pre,
-                       "range_kernel": {1: "e16", 2: "e8", 3: "wave", 5: "wave1k"}.get(amb.info(blah2_amd._lib.INFO_LAST_RANGE_KERNEL)),
+                       "range_kernel": {1: "e16", 2: "e8", 3: "wave", 5: "wave1k", 6: "ps"}.get(amb.info(blah2_amd._lib.INFO_LAST_RANGE_KERNEL)),
                        "ring_batches": ring, "streams_per_gpu": NS, "sharding": f"{world} independent CPI streams, one per GPU",
                        "ranks_seen_by_rccl": ranks_seen if dist is not None else None},
             "cells_per_s": total_cpis * cells / elapsed,
             "us_per_cpi": elapsed / (B * a.steps) * 1e6,
             "per_gpu_cpis_per_s": total_cpis / elapsed / world,
             "parity": parity,
-            "roofline": {"bound": "hbm", "kernel": {1: "range_kernel", 2: "range8_kernel", 3: "rangew_kernel", 5: "rangew1k_kernel"}.get(
+            "roofline": {"bound": "hbm", "kernel": {1: "range_kernel", 2: "range8_kernel", 3: "rangew_kernel", 5: "rangew1k_kernel", 6: "rangeps_kernel"}.get(
                              amb.info(blah2_amd._lib.INFO_LAST_RANGE_KERNEL), "range_kernel"), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes,

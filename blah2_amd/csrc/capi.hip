@@ -84,6 +84,7 @@ struct blah2hip_amb_s {
   cf *d_R = nullptr;
   cf *d_map = nullptr;
   double *d_partSum = nullptr;
+  uint32_t *d_tickets = nullptr; // arrival counters of the fused Map::set_metrics finish (doppler_sub1k_kernel), zero between launches
   float *d_partMax = nullptr;
   double *d_metrics = nullptr;
   double *d_doppler = nullptr;
@@ -212,7 +213,10 @@ bool choose_plan(blah2hip_amb_s *h)
     // launch has a pulse for each of its wave slots, is 1-2 % faster than the F = 2048 one-wave kernel (round 3, cfg 2 x 128
     // on four boxes, fp32 input; equal for int16)
     const bool w1k = (int64_t)h->dims.max_batch * h->dims.n_doppler_bins >= (int64_t)4 * RANGEW1K_WAVES_PER_SIMD * h->numCU;
-    const double cost = (2.0 * nSeg + 1.0) * F * std::log2((double)F) * (r3 == 4 ? (w1k ? 0.985 : 1.03) : 1.0);
+    // handles whose largest launch stays below that (a lone CPI) run F = 1024 on the pulse-per-workgroup kernel when a
+    // pulse has at most seven segments: cfg 2, one CPI per launch: 19.0 vs 21.7 us on the F = 2048 workgroup kernel (round 4)
+    const bool ps = r3 == 4 && nSeg <= RANGEPS_SEG && (int64_t)h->dims.max_batch * h->dims.n_doppler_bins <= (int64_t)4 * h->numCU;
+    const double cost = (2.0 * nSeg + 1.0) * F * std::log2((double)F) * (r3 == 4 ? (w1k ? 0.985 : (ps ? 0.6 : 1.03)) : 1.0);
     if (cost < best) {
       best = cost;
       found = true;
@@ -396,10 +400,35 @@ template <class In> int launch_rangew1k_t(blah2hip_amb_s *h, const RangeArgs &a,
   return BLAH2HIP_OK;
 }
 
+// F = 1024, at most seven segments, a launch that does not fill the one-wave kernel's slots (a lone CPI: 513 pulses): a
+// workgroup per pulse, its segments side by side (rangeps_kernel)
+bool use_ps_range(const blah2hip_amb_s *h, int nPulses)
+{
+  if (h->r3 != 4 || h->plan.nSeg > RANGEPS_SEG) return false;
+  if (h->rangeKernel == BLAH2HIP_RANGE_PS) return true;
+  return h->rangeKernel == 0 && nPulses <= 4 * h->numCU; // two rounds of its resident workgroups at most
+}
+
+template <class In> int launch_rangeps_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
+{
+  const size_t lds = (size_t)(Wave1kFft::TW_ELEMS + RANGEPS_WAVES * Wave1kFft::X_ELEMS) * sizeof(cf);
+  const bool shortx = a.plan.segLen <= 9 * 64;
+  const bool out7 = a.plan.nDelay <= 7 * 64;
+  auto kern = shortx ? (out7 ? rangeps_kernel<In, true, true> : rangeps_kernel<In, true, false>)
+                     : (out7 ? rangeps_kernel<In, false, true> : rangeps_kernel<In, false, false>);
+  LDSCFG(kern, lds);
+  const int grid = std::min<int>(a.nPulses, range_grid_cap(h, lds, RANGEPS_WAVES, 16));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RANGEPS_WAVES), lds, st, a, in);
+  HIPCHK(hipGetLastError());
+  h->lastRange = BLAH2HIP_RANGE_PS;
+  return BLAH2HIP_OK;
+}
+
 template <class In> int launch_range(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
 {
   if (use_wave_range(h, a.nPulses)) return launch_rangew_t(h, a, in, st);
   if (use_wave1k_range(h, a.nPulses)) return launch_rangew1k_t(h, a, in, st);
+  if (use_ps_range(h, a.nPulses)) return launch_rangeps_t(h, a, in, st);
   switch (h->r3) {
   case 4: return launch_range8_t<2>(h, a, in, st);
   case 8: return launch_range_t<8>(h, a, in, st);
@@ -461,6 +490,7 @@ bool doppler_kernel_applicable(const blah2hip_amb_s *h, int which)
   switch (which) {
   case BLAH2HIP_DOP_TILE8:
   case BLAH2HIP_DOP_TILE16WG:
+  case BLAH2HIP_DOP_SUB4:
   case BLAH2HIP_DOP_TILE16: return h->dopR3 == 4;
   case BLAH2HIP_DOP_TILEM: return (h->dopR3 == 8 && nD <= DopM<8>::MAX_ND) || (h->dopR3 == 16 && nD <= DopM<16>::MAX_ND);
   case BLAH2HIP_DOP_TILEW: return h->dopR3 == 8 && nD <= DOPW_MAX_ND;
@@ -483,6 +513,7 @@ int pick_doppler(const blah2hip_amb_s *h, uint32_t n_cpi)
   // a tile per CU (cfg 2 x 128: 1.49 vs 1.59 us/CPI); 8-column half tiles, two workgroups per CU, below
   if (h->dopR3 == 4 && (int)n_cpi * ((nDelay + 15) / 16) >= h->numCU) return BLAH2HIP_DOP_TILE16;
   if (fills && h->dopR3 == 4) return BLAH2HIP_DOP_TILE8;
+  if (h->dopR3 == 4) return BLAH2HIP_DOP_SUB4; // a lone CPI: every CU gets a 4-column piece
   if (fills && doppler_kernel_applicable(h, BLAH2HIP_DOP_TILEW)) return BLAH2HIP_DOP_TILEW;
   if (fills && doppler_kernel_applicable(h, BLAH2HIP_DOP_TILEW2)) return BLAH2HIP_DOP_TILEW2;
   if (fills && doppler_kernel_applicable(h, BLAH2HIP_DOP_TILEM)) return BLAH2HIP_DOP_TILEM;
@@ -647,6 +678,8 @@ int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler
   HIPCHK(hipMalloc(&h->d_map, cells * max_batch * sizeof(cf)));
   HIPCHK(hipMalloc(&h->d_partSum, (size_t)h->nParts * max_batch * sizeof(double)));
   HIPCHK(hipMalloc(&h->d_partMax, (size_t)h->nParts * max_batch * sizeof(float)));
+  HIPCHK(hipMalloc(&h->d_tickets, max_batch * sizeof(uint32_t)));
+  HIPCHK(hipMemset(h->d_tickets, 0, max_batch * sizeof(uint32_t)));
   HIPCHK(hipMalloc(&h->d_metrics, 2 * max_batch * sizeof(double)));
   HIPCHK(hipMalloc(&h->d_doppler, nD * sizeof(double)));
   HIPCHK(hipMalloc(&h->d_count, max_batch * sizeof(uint32_t)));
@@ -684,7 +717,7 @@ int blah2hip_amb_destroy(blah2hip_amb_t h)
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void *p : {(void *)h->d_tw, (void *)h->d_dopW, (void *)h->d_R, (void *)h->d_map,
-                  (void *)h->d_partSum, (void *)h->d_partMax, (void *)h->d_metrics,
+                  (void *)h->d_partSum, (void *)h->d_partMax, (void *)h->d_tickets, (void *)h->d_metrics,
                   (void *)h->d_doppler, h->d_in, (void *)h->d_rot,
                   (void *)h->d_hits, (void *)h->d_count, (void *)h->d_sat, (void *)h->d_dtw, (void *)h->d_chirp,
                   (void *)h->d_bf, (void *)h->d_bfn})
@@ -728,8 +761,10 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
     return BLAH2HIP_OK;
   case BLAH2HIP_OPT_RANGE_KERNEL:
     if (value != 0 && value != BLAH2HIP_RANGE_WAVE && value != BLAH2HIP_RANGE_E16 && value != BLAH2HIP_RANGE_WAVE1K &&
-        value != BLAH2HIP_RANGE_E8)
-      return fail(BLAH2HIP_ERR_INVALID, "range kernel: 0 (by transform length), BLAH2HIP_RANGE_E16, _E8, _WAVE or _WAVE1K");
+        value != BLAH2HIP_RANGE_E8 && value != BLAH2HIP_RANGE_PS)
+      return fail(BLAH2HIP_ERR_INVALID, "range kernel: 0 (by transform length), BLAH2HIP_RANGE_E16, _E8, _WAVE, _WAVE1K or _PS");
+    if (value == BLAH2HIP_RANGE_PS && (h->r3 != 4 || h->plan.nSeg > RANGEPS_SEG))
+      return fail(BLAH2HIP_ERR_UNSUPPORTED, "the pulse-per-workgroup range kernel is a 1024-point transform with at most 7 segments");
     if ((value == BLAH2HIP_RANGE_WAVE1K || value == BLAH2HIP_RANGE_E8) && h->r3 != 4)
       return fail(BLAH2HIP_ERR_UNSUPPORTED, "the 16-points-per-lane one-wave kernel and the 8-points-per-thread kernel are 1024-point transforms");
     if (value == BLAH2HIP_RANGE_WAVE && h->r3 != 8)
@@ -910,6 +945,17 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     nPartsUsed = grid;
     break;
   }
+  case BLAH2HIP_DOP_SUB4: {
+    const int subs = (int)((nDelay + DOPS_NCOL - 1) / DOPS_NCOL);
+    const size_t lds = (size_t)DOPS_LDS_ELEMS * sizeof(cf);
+    LDSCFG(doppler_sub1k_kernel, lds);
+    da.tickets = h->d_tickets;
+    da.metrics = met;
+    dopGrid = subs * (int)n_cpi; dopTiles = dopGrid;
+    hipLaunchKernelGGL(doppler_sub1k_kernel, dim3(subs * n_cpi), dim3(64 * DOPS_NCOL), lds, st, da, (int)n_cpi);
+    nPartsUsed = 0; // Map::set_metrics is finished inside the kernel
+    break;
+  }
   case BLAH2HIP_DOP_TILEW: {
     const int grid = (int)((nDelay + DOPW_NCOL - 1) / DOPW_NCOL);
     const size_t lds = (size_t)DOPW_LDS_ELEMS * sizeof(cf);
@@ -970,7 +1016,7 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   h->dopTilesLast = dopTiles;
   if ((rc = toc(h, BLAH2HIP_K_DOPPLER, st))) return rc;
 
-  {
+  if (nPartsUsed) {
     if ((rc = tic(h, BLAH2HIP_K_METRICS, st))) return rc;
     hipLaunchKernelGGL(metrics_kernel, dim3(n_cpi), dim3(256), 0, st, h->d_partSum, h->d_partMax,
                        nPartsUsed, (double)nD * (double)nDelay, met);

@@ -566,6 +566,75 @@ __global__ __launch_bounds__(64 * RANGEW1K_WAVES, RANGEW1K_WAVES_PER_SIMD) void 
 }
 
 // --------------------------------------------------------------------------
+// Range kernel for SMALL launches at F = 1024 (a lone CPI, the real-time shape of blah2.cpp:245-289: 513 pulses): the
+// one-wave kernel above gives a pulse to ONE wave, its segments in series -- with fewer pulses than wave slots the
+// chip is half empty and a pulse takes seven segments' time (41.8 us for a lone CPI at cfg 2); the workgroup kernels
+// put a pulse's segments in series too (22 us).  Here a pulse is a WORKGROUP and its segments run side by side: wave s
+// < nSeg loads and transforms segment s (x', y', the product Y conj X) and parks the product in its own exchange
+// region; the eighth wave sums the nSeg products (linearity: the inverse transform of the sum is the sum of the
+// segments' correlations), runs the one inverse and stores the lags -- while the segment waves are already on the
+// workgroup's next pulse.  Two barriers per pulse; 77 KB of LDS, two workgroups per CU.
+constexpr int RANGEPS_SEG = 7;               // segment waves
+constexpr int RANGEPS_WAVES = RANGEPS_SEG + 1;
+template <class In, bool SHORTX, bool OUT7>
+__global__ __launch_bounds__(64 * RANGEPS_WAVES, 4) void rangeps_kernel(RangeArgs a, In in)
+{
+  using W = Wave1kFft;
+  using RX = RawBuiltin<typename BufLoad<In>::X>;
+  using RY = RawBuiltin<typename BufLoad<In>::Y>;
+  constexpr int NX = SHORTX ? 9 : 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf *table = reinterpret_cast<cf *>(smem);
+  const int t = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  cf *regions = table + W::TW_ELEMS;
+  cf *X = regions + wave * W::X_ELEMS;
+  W::fill_table(threadIdx.x, 64 * RANGEPS_WAVES, a.tw, table);
+  __syncthreads();
+  W::Tw w;
+  W::load_twiddles(t, a.tw, table, w);
+  const RangePlan p = a.plan;
+  const bool segw = wave < p.nSeg;
+  for (int pulse = blockIdx.x; pulse < a.nPulses; pulse += gridDim.x) {
+    const int cpi = pulse / p.nDoppler;
+    const int i = pulse - cpi * p.nDoppler;
+    if (segw) {
+      const int64_t base = (int64_t)cpi * a.cpiStride + (int64_t)i * p.nCorr;
+      typename RX::raw rx[NX];
+      typename RY::raw ry[16];
+      w1k_issue_x<In, NX>(in, p, base, wave, t, true, rx);
+      w1k_issue_y<In>(in, p, base, wave, t, true, ry);
+      cf v[16], yv[16];
+#pragma unroll
+      for (int k = 0; k < NX; k++) v[k] = RX::cvt(rx[k]);
+      W::template transform<-1, NX>(t, v, w, X); // X spectrum
+#pragma unroll
+      for (int k = 0; k < 16; k++) yv[k] = RY::cvt(ry[k]);
+      W::template transform<-1, 16>(t, yv, w, X); // Y spectrum
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int e = 0; e < 16; e++) X[e * 64 + t] = cmacc(cmake(0.f, 0.f), yv[e], v[e]); // Y conj X, parked
+    }
+    __syncthreads(); // the products of this pulse are in the regions
+    cf acc[16];
+    if (wave == RANGEPS_SEG) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[e] = regions[e * 64 + t];
+      for (int sg = 1; sg < p.nSeg; sg++) {
+        const cf *r = regions + sg * W::X_ELEMS;
+#pragma unroll
+        for (int e = 0; e < 16; e++) { const cf q = r[e * 64 + t]; acc[e] = cmake(acc[e].x + q.x, acc[e].y + q.y); }
+      }
+    }
+    __syncthreads(); // the regions are free for the next pulse's transforms
+    if (wave == RANGEPS_SEG) {
+      W::template transform<+1, 16, OUT7>(t, acc, w, X);
+      store_lags_w<OUT7 ? 7 : 16>(a.out, p, cpi, i, t, acc);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
 // Doppler-centre shift, Ambiguity.cpp:95-102:  x[i] *= exp(+j 2 pi fMid i / fs),
 // i = index inside the CPI buffer.  fMid = m2/2 with m2 = dopplerMin+dopplerMax
 // an integer, so the phase is (m2*i mod 2fs)/(2fs) turns exactly; evaluated in
@@ -624,6 +693,9 @@ struct DopplerArgs {
   double *partSum;  // [nCpi][partsPerCpi]
   float *partMax;   // [nCpi][partsPerCpi]
   int32_t nD, nDelay, nTiles;
+  // small launches (doppler_sub1k_kernel): Map::set_metrics finished by the CPI's last workgroup, no third launch
+  uint32_t *tickets = nullptr; // [nCpi], zero between launches
+  double *metrics = nullptr;   // [nCpi][2]
 };
 
 // 10*log10|z| = 5*log10(re^2+im^2) = 5*log10(2) * log2(re^2+im^2)
@@ -1047,6 +1119,176 @@ __global__ __launch_bounds__(1024) void doppler_tile1k_kernel(DopplerArgs a, int
       a.partMax[part] = m;
     }
   }
+}
+
+// The reduction of metrics_kernel (below) by the 256 threads of a workgroup: the same order of operations, so that the
+// fused finish and the separate launch give the same bits.
+__device__ __forceinline__ void metrics_finish_256(const double *partSum, const float *partMax, int nParts, int cpi, double cells,
+                                                   double *metrics, double *ssum, float *smax)
+{
+  const int tid = threadIdx.x;
+  double s = 0.0;
+  float m = 0.f;
+  for (int i = tid; i < nParts; i += 256) { // the partials were stored write-through (sc1): L2-served loads see them, no fence
+    s += __hip_atomic_load(partSum + (size_t)cpi * nParts + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    m = fmaxf(m, __hip_atomic_load(partMax + (size_t)cpi * nParts + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+  ssum[tid] = s;
+  smax[tid] = m;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+      ssum[tid] += ssum[tid + off];
+      smax[tid] = fmaxf(smax[tid], smax[tid + off]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double noise = ssum[0] / cells;
+    metrics[2 * cpi + 0] = noise;
+    metrics[2 * cpi + 1] = (double)smax[0] - noise;
+  }
+}
+
+// The Doppler stage of a SMALL launch (a single CPI, the real-time shape of blah2.cpp:245-289; nD <= 513): the 16-column
+// tile kernel above keeps a CU busy for ~12 us per tile and a lone CPI has 26 tiles, the one-column-per-workgroup kernel
+// runs five barrier-separated phases per column behind 128-byte-stride gathers (16 us).  Here a workgroup is FOUR waves
+// = four columns (a quarter of a 16-column tile: 32-byte row pieces, the other three quarters are read by its siblings
+// out of the same lines), one wave per SIMD, no persistence: 103 workgroups at cfg 2, every CU busy, each wave alone
+// on its SIMD through both one-wave 1024-point transforms.  Map::set_metrics' partials are finished by the CPI's LAST
+// workgroup (one ticket per workgroup behind write-through partials, MI355X_MICROARCH.md "inter-workgroup visibility"),
+// so the chain of a lone CPI is two launches instead of three.
+constexpr int DOPS_NCOL = 4;
+constexpr int DOPS_LDS_ELEMS = DOPS_NCOL * DOPT_PITCH + Wave1kFft::TW_ELEMS + 1024;
+__global__ __launch_bounds__(64 * DOPS_NCOL) void doppler_sub1k_kernel(DopplerArgs a, int nCpi)
+{
+  using K = Wave1kFft;
+  constexpr int NCOL = DOPS_NCOL, T = 64, NR = 9, NT = 64 * NCOL, SH = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double ssum[256];
+  __shared__ float smax[256];
+  __shared__ int lastWg;
+  cf *lds = reinterpret_cast<cf *>(smem);
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, t = tid & 63; // wave = column of the sub-tile
+  const int nD = a.nD;
+  cf *region = lds + w * DOPT_PITCH;
+  cf *table = lds + NCOL * DOPT_PITCH;
+  cf *bfL = table + K::TW_ELEMS;
+  const int subsPerCpi = (a.nDelay + NCOL - 1) / NCOL;
+  const int cells = nD * NCOL;
+  const int it = blockIdx.x;
+  const int cpi = it / subsPerCpi, sub = it - cpi * subsPerCpi;
+  if (cpi >= nCpi) return;
+  const int col0 = sub * NCOL;
+
+  // the sub-tile: rows of four columns out of the 16-column tile's rows (requested before the tables are filled)
+  cf nt[NR];
+  {
+    const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, col0);
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+      const int idx = tid + NT * j;
+      const int c = idx & (NCOL - 1), row = idx >> SH;
+      nt[j] = Rt[idx < cells ? row * 16 + c : 0];
+    }
+  }
+  K::fill_table(tid, NT, a.tw, table);
+#pragma unroll
+  for (int j = 0; j < 1024 / NT; j++) bfL[tid + NT * j] = a.bfn[tid + NT * j];
+  cf ch[NR];
+  int oidx[NR], ridx[NR];
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    const int i = t + T * k;
+    ridx[k] = min(i, nD - 1);
+    const cf c = a.chirp[min(i, nD - 1)];
+    ch[k] = cmake(i < nD ? c.x : 0.f, i < nD ? c.y : 0.f);
+    int o = i - (nD / 2 + 1);
+    if (o < 0) o += nD;
+    oidx[k] = i < nD ? o : DOPT_PITCH - 1;
+  }
+  // phase 1: the sub-tile, transposed into the per-column regions
+  {
+    cf *dst = lds + (tid & (NCOL - 1)) * DOPT_PITCH + (tid >> SH); // idx + 256 j: same column, row + 64 j
+#pragma unroll
+    for (int j = 0; j < NR; j++)
+      if (tid + NT * j < cells) dst[T * j] = nt[j];
+  }
+  __syncthreads(); // tables and tile
+  K::Tw tw;
+  K::load_twiddles(t, a.tw, table, tw);
+
+  // phase 2: this wave's column (DC removal + chirp), both transforms
+  cf v[16];
+  const cf r0 = region[0];
+#pragma unroll
+  for (int k = 0; k < NR; k++) v[k] = cmul(csub(region[ridx[k]], r0), ch[k]);
+  __builtin_amdgcn_wave_barrier();
+  K::transform<-1, 9>(t, v, tw, region);
+#pragma unroll
+  for (int e = 0; e < 16; e++) v[e] = cmul(v[e], bfL[e * T + t]);
+  __builtin_amdgcn_wave_barrier();
+  K::transform<+1>(t, v, tw, region);
+  __builtin_amdgcn_wave_barrier();
+
+  // phase 3: chirp, rotate rows by nD/2 + 1, park the column back in its region
+#pragma unroll
+  for (int c = 0; c < NR; c++) {
+    cf d = cmul(v[c], ch[c]);
+    if (c == 0 && t == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
+    region[oidx[c]] = d;
+  }
+  __syncthreads();
+
+  // phase 4: row-piece stores (32 bytes) + Map::set_metrics partials
+  double lsum = 0.0;
+  float lmax = 0.f;
+  cf *mapb = a.map + (size_t)cpi * nD * a.nDelay + col0;
+  const int ncol = min(NCOL, a.nDelay - col0);
+  {
+    const int c = tid & (NCOL - 1), o0 = tid >> SH;
+    const cf *src = lds + c * DOPT_PITCH + o0;
+    cf *dstg = mapb + (size_t)o0 * a.nDelay + c;
+    const size_t gstep = (size_t)T * a.nDelay;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+      const bool ok = tid + NT * j < cells && c < ncol;
+      const cf d = src[min(T * j, nD - 1 - o0)];
+      if (ok) dstg[gstep * j] = d;
+      const float db = db_of(d);
+      lsum += ok ? (double)db : 0.0;
+      lmax = ok ? fmaxf(lmax, db) : lmax;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lsum += __shfl_xor(lsum, off);
+    lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+  }
+  if (t == 0) { ssum[w] = lsum; smax[w] = lmax; }
+  __syncthreads();
+  if (tid == 0) {
+    double sacc = 0.0;
+    float m = 0.f; // Map.cpp:193: the running max starts at 0
+    for (int i = 0; i < NCOL; i++) { sacc += ssum[i]; m = fmaxf(m, smax[i]); }
+    const size_t part = (size_t)cpi * subsPerCpi + sub;
+    // write-through (sc1) stores, the store queue drained, then the ticket: the form of the guide's hand-off that needs no
+    // release fence here (a fence writes back every dirty line of the XCD's L2 -- the map this launch has just stored)
+    // and no acquire on the reading side, whose loads are sc1 too
+    __hip_atomic_store(a.partSum + part, sacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.partMax + part, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int last = 0;
+    if (a.tickets) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned tk = __hip_atomic_fetch_add(a.tickets + cpi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = tk == (unsigned)subsPerCpi - 1u;
+      if (last) __hip_atomic_store(a.tickets + cpi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // for the next launch
+    }
+    lastWg = last;
+  }
+  __syncthreads();
+  if (lastWg) metrics_finish_256(a.partSum, a.partMax, subsPerCpi, cpi, (double)nD * (double)a.nDelay, a.metrics, ssum, smax);
 }
 
 // Tile variant for 513 < nD <= 1025 on the ONE-WAVE 2048-point transform (fft_wave.hpp): the phases of

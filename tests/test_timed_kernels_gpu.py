@@ -116,7 +116,7 @@ def test_one_wave_range_kernel_ragged_geometry(b2):
     geom = (1, 299, -100, 100, 1_000_000, 777_001)
     for B in (1, 2):
         amb = run_batch(b2, geom, B, "auto", seeds=range(80, 80 + B), range_kernel=_lib.RANGE_WAVE, fft_len=2048,
-                        expect="column", targets=((40, 30.0, 0.05),))
+                        expect="sub4", targets=((40, 30.0, 0.05),))
         assert amb.dims.fft_len == 2048 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE
 
 
@@ -124,7 +124,7 @@ def test_cfg2_batched_int16_wire_format(b2):
     run_batch(b2, CFG2, 3, "auto", seeds=(50, 51, 52), fmt="i16", expect="tile8")
 
 
-@pytest.mark.parametrize("kernel", ["tile8", "tile16", "column", "direct"])
+@pytest.mark.parametrize("kernel", ["tile8", "tile16", "sub4", "column", "direct"])
 def test_cfg2_every_doppler_kernel(b2, kernel):
     """The same two CPIs through each Doppler kernel that covers nD = 513, forced."""
     run_batch(b2, CFG2, 2, kernel, seeds=(60, 61))
@@ -162,8 +162,10 @@ def test_four_wave_tile_kernel(b2, fmax, n, nD):
     assert amb.info(_lib.INFO_DOPPLER_FFT_LEN) == 4096
 
 
-def test_auto_rule_small_launch_keeps_the_column_kernel(b2):
-    amb = run_batch(b2, CFG2, 1, "auto", seeds=(99,), expect="column")
+def test_auto_rule_small_launch_takes_the_four_column_kernel(b2):
+    """A lone CPI at nD <= 513: doppler_sub1k_kernel (four columns per workgroup, Map::set_metrics finished by the last
+    workgroup to arrive: no metrics launch); the handle is then reused, so the arrival counter must be back at zero."""
+    amb = run_batch(b2, CFG2, 1, "auto", seeds=(99,), expect="sub4")
     with pytest.raises(b2.Blah2HipError):  # nD = 513 is outside the multi-wave tile kernel's plan (M = 1024)
         amb.set_doppler_kernel("tilem")
 
@@ -175,8 +177,9 @@ def test_range_kernel_of_every_transform_length_batched(b2, geom, fft_len, kerne
     F = 2048 / 4096 -> the 16-point workgroup kernel (two CPIs are below the launch size at which F = 2048
     switches to the one-wave kernel); two distinct CPIs per launch."""
     from blah2_amd import _lib
+    # (F = 1024 in launches this small is the pulse-per-workgroup kernel's since round 4: the 8-point kernel is forced)
     amb = run_batch(b2, geom, 2, "auto", seeds=(5, 6), expect=_expected_doppler(b2, geom),
-                    targets=((37, -13.0, 0.05),), cell_tol=1e-4)
+                    targets=((37, -13.0, 0.05),), cell_tol=1e-4, range_kernel=_lib.RANGE_E8 if kernel == "e8" else 0)
     assert amb.dims.fft_len == fft_len
     assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == {"e8": _lib.RANGE_E8, "e16": _lib.RANGE_E16, "wave": _lib.RANGE_WAVE}[kernel]
 
@@ -188,7 +191,7 @@ def _expected_doppler(b2, geom):
     if d.n_doppler_bins <= 513:  # 256 CUs: whole tiles from one per CU on, half tiles from one per two CUs
         if 2 * -(-d.n_delay_bins // 16) >= 256:
             return "tile16"
-        return "tile8" if 2 * -(-d.n_delay_bins // 8) >= 128 else "column"
+        return "tile8" if 2 * -(-d.n_delay_bins // 8) >= 128 else "sub4"
     if d.n_doppler_bins <= 1025:
         return "tilew" if 2 * -(-d.n_delay_bins // 8) >= 128 else "column"
     return "tilew2" if 2 * -(-d.n_delay_bins // 4) >= 128 else "column"
@@ -254,7 +257,7 @@ def _expected_doppler3(geom):
     if d.n_doppler_bins <= 513:
         if 3 * -(-d.n_delay_bins // 16) >= 256:
             return "tile16"
-        return "tile8" if 3 * -(-d.n_delay_bins // 8) >= 128 else "column"
+        return "tile8" if 3 * -(-d.n_delay_bins // 8) >= 128 else "sub4"
     return "tilew" if 3 * -(-d.n_delay_bins // 8) >= 128 else "column"
 
 
@@ -264,7 +267,7 @@ def test_one_wave_range_kernel_long_segments(b2, geom, out7):
     computes only the seven wanted outputs per lane (the configs[4] shape: segLen 1627, 411 lags), with more all 32."""
     from blah2_amd import _lib
     amb = run_batch(b2, geom, 2, "auto", seeds=(140, 141), range_kernel=_lib.RANGE_WAVE, fft_len=2048,
-                    expect="column", targets=((37, -13.0, 0.05),))
+                    expect="sub4", targets=((37, -13.0, 0.05),))
     assert amb.dims.fft_len == 2048 and amb.dims.seg_len > 1536
     assert (amb.get_n_delay_bins() <= 448) == out7
     assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE
@@ -320,3 +323,61 @@ def test_tile16_on_both_transforms(b2):
         a = run_batch(b2, geom, B, "tile16", seeds=range(500, 500 + B))
         b = run_batch(b2, geom, B, "tile16wg", seeds=range(500, 500 + B))
         assert a.last_doppler_kernel() == "tile16" and b.last_doppler_kernel() == "tile16wg"
+
+
+def test_four_column_kernel_finishes_the_metrics_itself_launch_after_launch(b2):
+    """doppler_sub1k_kernel forced on ONE handle for launches of 1, 3 and 2 CPIs: Map::set_metrics comes out of the last
+    workgroup of each CPI (an arrival counter per CPI that must be back at zero for the next launch), the map from 103
+    four-column workgroups per CPI; every CPI of every launch against the oracle.  Ragged: 411 = 102 * 4 + 3."""
+    import torch
+    dmin, dmax, fmin, fmax, fs, n = (-10, 400, -100, 100, 1_000_000, 402_000)
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, max_batch=3)
+    amb.set_doppler_kernel("sub4")
+    d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
+    nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
+    st = torch.cuda.current_stream().cuda_stream
+    for rep, B in enumerate((1, 3, 2, 1)):
+        xs, ys = zip(*(O.synth_iq(n, seed=300 + 10 * rep + c, fs=fs, targets=((37, -13.0, 0.05),)) for c in range(B)))
+        x = torch.from_numpy(np.stack(xs).astype(np.complex64)).cuda()
+        y = torch.from_numpy(np.stack(ys).astype(np.complex64)).cuda()
+        out = torch.zeros((B, nD, nC), dtype=torch.complex64, device="cuda")
+        met = torch.full((B, 2), float("nan"), dtype=torch.float64, device="cuda")
+        amb.process_dev(b2.FMT_C32, x.data_ptr(), y.data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert amb.last_doppler_kernel() == "sub4"
+        o, m = out.cpu().numpy(), met.cpu().numpy()
+        for c in range(B):
+            assert_cpi(o[c], m[c], O.ambiguity_process(d, xs[c], ys[c]), f"launch {rep} cpi {c} of {B}")
+
+
+@pytest.mark.parametrize("geom,fmt,B", [(CFG2, "c32", 1), (CFG2, "i16", 2),
+                                        ((-10, 89, -100, 100, 1_000_000, 603_000), "c32", 2),    # 4 segments of 750: every x load, 7 outputs
+                                        ((-7, 492, -50, 50, 155_540, 155_540), "c32", 1),         # 500 lags: all 16 outputs
+                                        ((1, 299, -100, 100, 1_000_000, 777_001), "i16", 3)])     # ragged pulse, first lag positive
+def test_pulse_per_workgroup_range_kernel(b2, geom, fmt, B):
+    """rangeps_kernel (F = 1024, small launches): a workgroup per pulse, a wave per segment, the products summed and
+    inverted by the eighth wave -- forced, on the cfg 2 shape (seven segments of 576, pruned x', seven outputs), with
+    fewer and longer segments, with more than 448 lags, on a ragged geometry and on the int16 wire format; every CPI
+    against the oracle.  A lone CPI at cfg 2 is 513 pulses on 512 resident workgroups: one workgroup takes two."""
+    from blah2_amd import _lib
+    amb = run_batch(b2, geom, B, "auto", seeds=range(400, 400 + B), fmt=fmt, fft_len=1024, range_kernel=_lib.RANGE_PS,
+                    expect=None if B > 3 else _expected_small(geom, B), targets=((37, -13.0, 0.05),))
+    assert amb.dims.fft_len == 1024 and amb.dims.n_seg <= 7 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_PS
+
+
+def _expected_small(geom, B):
+    dmin, dmax, fmin, fmax, fs, n = geom
+    d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
+    if d.n_doppler_bins <= 513:
+        if B * -(-d.n_delay_bins // 16) >= 256:
+            return "tile16"
+        return "tile8" if B * -(-d.n_delay_bins // 8) >= 128 else "sub4"
+    return "column"
+
+
+def test_a_lone_cpi_takes_the_small_launch_kernels(b2):
+    """The planner's choice for a handle of one CPI at configs[1]: F = 1024 on the pulse-per-workgroup range kernel and the
+    four-column Doppler kernel (two launches for the whole chain)."""
+    from blah2_amd import _lib
+    amb = run_batch(b2, CFG2, 1, "auto", seeds=(77,), expect="sub4")
+    assert amb.dims.fft_len == 1024 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_PS
