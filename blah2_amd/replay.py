@@ -33,6 +33,8 @@ from __future__ import annotations
 
 import json
 import os
+import time
+import pickle
 import sys
 from concurrent.futures import ThreadPoolExecutor
 from typing import Callable, Iterator, List, Optional, Tuple
@@ -118,26 +120,62 @@ def _iter_local(capture: RspduoFile, processor, mine) -> Iterator[List[dict]]:
         yield [dict(r, cpi=k0 + i) for i, r in enumerate(out)]
 
 
+def _host_group(dist):
+    """A gloo group over the same ranks for host-resident bytes (the default group may be RCCL, whose tensors live in
+    HBM): results leave the device on their owning rank, so the gather moves host buffers."""
+    if dist.get_backend() == "gloo":
+        return None  # the default group will do
+    return dist.new_group(backend="gloo")
+
+
+def _gather_bytes(dist, group, payload: bytes, rank: int, world: int) -> Optional[List[bytes]]:
+    """One round's results as TENSORS: every rank's byte count first (one int64 each), then the payloads padded to the
+    longest.  What travels is what the owning rank serialised; rank 0 receives buffers, it does not unpickle objects it
+    then has to format."""
+    import torch
+    n = torch.tensor([len(payload)], dtype=torch.int64)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    longest = max(int(v.item()) for v in sizes)
+    buf = torch.zeros(max(longest, 1), dtype=torch.uint8)
+    if payload:
+        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+    parts = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, parts, dst=0, group=group)
+    if rank != 0:
+        return None
+    return [bytes(p[:int(sz.item())].numpy().tobytes()) for p, sz in zip(parts, sizes)]
+
+
 def replay(capture: RspduoFile, processor, batch: int = 1, dist=None, limit: Optional[int] = None,
-           emit: Optional[Callable[[dict], None]] = None) -> Optional[List[dict]]:
+           emit: Optional[Callable[[dict], None]] = None, serialise: Optional[Callable[[dict], dict]] = None,
+           stats: Optional[dict] = None) -> Optional[List[dict]]:
     """Processes every CPI of ``capture`` exactly once across the ranks of ``dist`` (a torch.distributed module with an
     initialised default group, or None for a single process).
 
     With ``emit``: rank 0 calls ``emit(result)`` for every CPI in file order, round by round, while later rounds are still
     being processed (bounded memory), and the function returns the number of CPIs on rank 0.  Without: the results are
-    collected and returned as a list on rank 0 (tests, small captures).  Other ranks return None."""
+    collected and returned as a list on rank 0 (tests, small captures).  Other ranks return None.
+
+    ``serialise`` runs on the rank that OWNS a CPI, before the gather: it turns the processor's result (which may hold a
+    16 MB map) into what rank 0 has to emit -- the JSON documents of blah2.cpp:299-321, say -- and must keep the "cpi"
+    key.  Rank 0's work per foreign CPI is then a receive and a write.  ``stats`` (a dict) receives this rank's seconds
+    spent serialising, in the gather and (rank 0) emitting."""
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
     n = capture.n_cpis if limit is None else min(limit, capture.n_cpis)
     mine = shard_batches(n, batch, rank, world)
-    n_batches = -(-n // batch) if n else 0
+    n_batches = n_batches_hint(n, batch)
     n_rounds = -(-n_batches // world) if n_batches else 0
     collected: Optional[List[dict]] = [] if (emit is None and rank == 0) else None
     expect = 0
     done = 0
+    t_ser = t_gather = t_emit = 0.0
+    group = _host_group(dist) if dist is not None else None
 
     def deliver(results: List[dict]):
-        nonlocal expect, done
+        nonlocal expect, done, t_emit
+        t0 = time.perf_counter()
         for r in results:
             if r["cpi"] != expect:
                 raise RuntimeError(f"replay order: CPI {r['cpi']} arrived where {expect} was due")
@@ -147,32 +185,42 @@ def replay(capture: RspduoFile, processor, batch: int = 1, dist=None, limit: Opt
                 emit(r)
             else:
                 collected.append(r)
+        t_emit += time.perf_counter() - t0
 
     local = _iter_local(capture, processor, mine)
     for g in range(n_rounds):
         own = next(local) if g * world + rank < n_batches else []
+        if serialise is not None:
+            t0 = time.perf_counter()
+            own = [serialise(r) for r in own]
+            t_ser += time.perf_counter() - t0
         if dist is None:
             deliver(own)
             continue
-        gathered = [None] * world if rank == 0 else None
-        dist.gather_object(own, gathered, dst=0)  # one round: `world` batches, rank order = file order
+        t0 = time.perf_counter()
+        parts = _gather_bytes(dist, group, pickle.dumps(own, protocol=pickle.HIGHEST_PROTOCOL) if own else b"", rank, world)
+        t_gather += time.perf_counter() - t0
         if rank == 0:
-            for part in gathered:
-                deliver(part)
+            for part in parts:  # one round: `world` batches, rank order = file order
+                deliver(pickle.loads(part) if part else [])
     if dist is not None:
         # a counter every rank agrees on (the throughput figure's numerator)
         import torch
         cnt = torch.tensor([sum(c for _, c in mine)], dtype=torch.int64)
-        if dist.get_backend() == "nccl":
-            cnt = cnt.cuda()
-        dist.all_reduce(cnt)
+        dist.all_reduce(cnt, group=group)
         if int(cnt.item()) != n:
             raise RuntimeError(f"replay processed {int(cnt.item())} CPIs, expected {n}")
+    if stats is not None:
+        stats.update(serialise_s=t_ser, gather_s=t_gather, emit_s=t_emit, cpis_owned=sum(c for _, c in mine))
     if rank != 0:
         return None
     if done != n:
         raise RuntimeError(f"replay emitted {done} CPIs, expected {n}")
     return done if emit is not None else collected
+
+
+def n_batches_hint(n: int, batch: int) -> int:
+    return -(-n // batch) if n else 0
 
 
 class GpuChain:
@@ -404,21 +452,26 @@ def main(argv=None):
             socks[name] = socket.create_connection((ip, int(y["network"]["ports"][name])))
     t_cpi_ms = int(round(1000.0 * n / fs))
 
-    def emit(r):  # rank 0, file order, as the rounds complete
+    def serialise(r):  # on the rank that owns the CPI: Map::to_json + delay_bin_to_km there, documents on the wire
+        if r.get("skipped") or not a.json:
+            return r
+        # replay has no wall clock: CPI k is stamped k * tCpi in ms (blah2.cpp uses the capture time in ms)
+        return {"cpi": r["cpi"], "frames": frames_for(r, proc.amb, fs, r["cpi"] * t_cpi_ms)}
+
+    def emit(r):  # rank 0, file order, as the rounds complete: a write per document
         if r.get("skipped"):
             return
         if not a.json:
             sys.stdout.write(json.dumps(r) + "\n")
             return
-        # replay has no wall clock: CPI k is stamped k * tCpi in ms (blah2.cpp uses the capture time in ms)
-        for name, doc in frames_for(r, proc.amb, fs, r["cpi"] * t_cpi_ms).items():
+        for name, doc in r["frames"].items():
             if socks:
                 send_frame(socks[name], doc)
             else:
                 sys.stdout.write(doc + "\n")
         sys.stdout.flush()
 
-    replay(RspduoFile(a.capture, n), proc, a.batch, dist, a.limit, emit=emit)
+    replay(RspduoFile(a.capture, n), proc, a.batch, dist, a.limit, emit=emit, serialise=serialise)
     for s in socks.values():
         s.close()
     proc.close()

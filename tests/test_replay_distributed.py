@@ -166,3 +166,51 @@ def test_two_rank_streaming_gather_gloo(tmp_path):
     assert seen[:, 0].tolist() == list(range(n_cpis))
     assert np.allclose(seen[:, 1], [w["noisePower"] for w in want])
     assert seen[0, 2] == 1 and seen[3, 2] == 1 and seen[4, 2] == 2  # round g is out after rank 0's g+1-th batch
+
+
+def _worker_serialise(rank, world, port, path, n_cpis, batch, out_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def processor(iq):  # a result with a large member that must never travel
+            return [dict(r, map=np.full(300_000, 7.0)) for r in stub(iq)]
+
+        def serialise(r):  # runs where the CPI was processed: the document leaves, the map stays
+            return {"cpi": r["cpi"], "by": rank, "doc": "x" * (1000 + 37 * r["cpi"]) + f"{r['noisePower']:.6f}"}
+
+        seen = []
+        stats = {}
+        n = R.replay(R.RspduoFile(path, N_SAMPLES), processor, batch=batch, dist=dist, emit=seen.append,
+                     serialise=serialise, stats=stats)
+        assert stats["cpis_owned"] == sum(c for _, c in R.shard_batches(n_cpis, batch, rank, world))
+        if rank == 0:
+            assert n == n_cpis
+            np.save(out_path, np.array([[r["cpi"], r["by"], len(r["doc"]), float(r["doc"][1000 + 37 * r["cpi"]:])] for r in seen]))
+            assert all("map" not in r for r in seen)
+        else:
+            assert n is None and not seen
+    finally:
+        dist.destroy_process_group()
+
+
+def test_results_are_serialised_on_the_rank_that_owns_them(tmp_path):
+    """--json replay: Map::to_json runs where the CPI was processed and rank 0 forwards documents (blah2.cpp:299-321);
+    the gather moves byte tensors, ragged per rank, in file order."""
+    import torch.multiprocessing as mp
+    n_cpis, batch = 11, 2
+    p = str(tmp_path / "c.rspduo")
+    make_capture(p, n_cpis)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "ser.npy")
+    mp.spawn(_worker_serialise, args=(2, port, p, n_cpis, batch, out), nprocs=2, join=True)
+    got = np.load(out)
+    f = R.RspduoFile(p, N_SAMPLES)
+    assert got[:, 0].tolist() == list(range(n_cpis))
+    for k in range(n_cpis):
+        assert got[k, 1] == (k // batch) % 2          # batch b is rank b % world's
+        assert got[k, 2] == 1000 + 37 * k + len(f"{stub(f.batch([k]))[0]['noisePower']:.6f}")
+        assert abs(got[k, 3] - stub(f.batch([k]))[0]["noisePower"]) < 1e-5
