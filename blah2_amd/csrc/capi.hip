@@ -108,7 +108,7 @@ struct blah2hip_amb_s {
   int cfar2dForce = 0;              // BLAH2HIP_OPT_CFAR2D_KERNEL
   int dopGridForce = 0;             // BLAH2HIP_OPT_DOPPLER_GRID (0 = residency of the persistent kernel)
   int dopGridLast = 0, dopTilesLast = 0; // BLAH2HIP_INFO_DOPPLER_GRID / _TILES
-  struct AlphaTable { double pfa; size_t n; double *d; };
+  struct AlphaTable { double pfa; size_t n; double *d; bool pinned; }; // pinned: handed out by *_prepare, never evicted
   std::vector<AlphaTable> alphaTables; // CFAR threshold factors, one per (pfa, size) seen
   cf *d_dtw = nullptr;              // exp(-2 pi i k/M)
   cf *d_chirp = nullptr;            // exp(-i pi n^2/nD)
@@ -524,14 +524,17 @@ int pick_doppler(const blah2hip_amb_s *h, uint32_t n_cpi)
 // same libm pow the reference calls (CfarDetector1D.cpp:76).  A small per-handle cache keyed by
 // (pfa, maxN), least recently used first out (a caller that adapts pfa per CPI does not grow device
 // memory): a hit only hands out the pointer; a miss allocates and uploads (blocking), which is
-// refused while `st` is being captured into a graph -- *_prepare is the call for that.
+// refused while `st` is being captured into a graph -- *_prepare is the call for that.  A table *_prepare has handed out
+// lives as long as the handle (`pin`): a graph captured afterwards has its address baked in, and no synchronisation
+// at eviction time protects a later replay.  Only unpinned tables are evicted.
 constexpr size_t ALPHA_TABLES_MAX = 8;
-int alpha_table(blah2hip_amb_s *h, double pfa, size_t maxN, const double **out, hipStream_t st = nullptr)
+int alpha_table(blah2hip_amb_s *h, double pfa, size_t maxN, const double **out, hipStream_t st = nullptr, bool pin = false)
 {
   auto &T = h->alphaTables;
   for (size_t i = 0; i < T.size(); i++)
     if (T[i].pfa == pfa && T[i].n >= maxN) {
-      const blah2hip_amb_s::AlphaTable t = T[i];
+      blah2hip_amb_s::AlphaTable t = T[i];
+      t.pinned = t.pinned || pin;
       T.erase(T.begin() + (long)i);
       T.push_back(t); // most recently used last
       *out = t.d;
@@ -546,12 +549,18 @@ int alpha_table(blah2hip_amb_s *h, double pfa, size_t maxN, const double **out, 
   std::vector<double> alpha(maxN + 1);
   alpha[0] = std::nan("");
   for (size_t n = 1; n <= maxN; n++) alpha[n] = (double)n * (pow(pfa, -1.0 / (double)n) - 1);
-  if (T.size() >= ALPHA_TABLES_MAX) {
-    HIPCHK(hipDeviceSynchronize()); // the oldest table may still be read by enqueued work
-    (void)hipFree(T.front().d);
-    T.erase(T.begin());
+  size_t unpinned = 0;
+  for (const auto &e : T) unpinned += e.pinned ? 0 : 1;
+  if (unpinned >= ALPHA_TABLES_MAX) {
+    HIPCHK(hipDeviceSynchronize()); // the oldest unpinned table may still be read by enqueued work
+    for (size_t i = 0; i < T.size(); i++)
+      if (!T[i].pinned) {
+        (void)hipFree(T[i].d);
+        T.erase(T.begin() + (long)i);
+        break;
+      }
   }
-  blah2hip_amb_s::AlphaTable t{pfa, maxN, nullptr};
+  blah2hip_amb_s::AlphaTable t{pfa, maxN, nullptr, pin};
   HIPCHK(hipMalloc(&t.d, (maxN + 1) * sizeof(double)));
   hipError_t e = hipMemcpy(t.d, alpha.data(), (maxN + 1) * sizeof(double), hipMemcpyHostToDevice);
   if (e != hipSuccess) { (void)hipFree(t.d); return fail(BLAH2HIP_ERR_HIP, std::string("alpha table upload: ") + hipGetErrorString(e)); }
@@ -1342,7 +1351,7 @@ int blah2hip_cfar1d_prepare(blah2hip_amb_t h, double pfa, int32_t n_train)
   if (n_train < 0 || n_train > 127) return fail(BLAH2HIP_ERR_INVALID, "nTrain outside int8 range");
   HIPCHK(hipSetDevice(h->device));
   const double *d = nullptr;
-  return alpha_table(h, pfa, (size_t)(2 * n_train), &d);
+  return alpha_table(h, pfa, (size_t)(2 * n_train), &d, nullptr, true);
 }
 
 int blah2hip_cfar2d_prepare(blah2hip_amb_t h, double pfa, int32_t ngd, int32_t ntd, int32_t ngf, int32_t ntf)
@@ -1356,7 +1365,7 @@ int blah2hip_cfar2d_prepare(blah2hip_amb_t h, double pfa, int32_t ngd, int32_t n
     return fail(BLAH2HIP_ERR_UNSUPPORTED, "2-D window beyond the tile kernel's halo (nGf + nTf <= 24, nGd + nTd <= 40)");
   if (!cfar2d_use_tile(h, ngd, ntd, ngf, ntf) && (rc = ensure_sat(h))) return rc;
   const double *d = nullptr;
-  return alpha_table(h, pfa, (size_t)(2 * (ngd + ntd) + 1) * (2 * (ngf + ntf) + 1), &d);
+  return alpha_table(h, pfa, (size_t)(2 * (ngd + ntd) + 1) * (2 * (ngf + ntf) + 1), &d, nullptr, true);
 }
 
 int blah2hip_cfar2d_process(blah2hip_amb_t h, uint32_t cpi, double pfa, int32_t ngd, int32_t ntd,

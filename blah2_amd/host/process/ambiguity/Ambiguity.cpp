@@ -39,9 +39,15 @@ Ambiguity::Ambiguity(int32_t delayMin, int32_t delayMax, int32_t dopplerMin, int
   map->delay.assign(delay.begin(), delay.end());
   map->doppler.assign(doppler.begin(), doppler.end());
 
-  DeviceContext &dc = DeviceContext::get();
-  mapF = (float *)dc.alloc_pinned(2 * (size_t)nDopplerBins * nDelayBins * sizeof(float));
-  metF = (double *)dc.alloc_pinned(2 * sizeof(double));
+  try { // a constructor that throws runs no destructor: give back what has been acquired
+    DeviceContext &dc = DeviceContext::get();
+    mapF = (float *)dc.alloc_pinned(2 * (size_t)nDopplerBins * nDelayBins * sizeof(float));
+    metF = (double *)dc.alloc_pinned(2 * sizeof(double));
+  } catch (...) {
+    if (mapF) DeviceContext::get().free_pinned(mapF);
+    blah2hip_amb_destroy(engine);
+    throw;
+  }
 }
 
 Ambiguity::~Ambiguity()

@@ -12,9 +12,15 @@ WienerHopf::WienerHopf(int32_t delayMin, int32_t delayMax, uint32_t _nSamples) :
 {
   if (blah2hip_clutter_create(delayMin, delayMax, _nSamples, Ambiguity::default_device(), 1, &engine) != BLAH2HIP_OK)
     throw std::runtime_error(std::string("WienerHopf: ") + blah2hip_last_error());
-  DeviceContext &dc = DeviceContext::get();
-  dOk = (int32_t *)dc.alloc_device(sizeof(int32_t));
-  hOk = (int32_t *)dc.alloc_pinned(sizeof(int32_t));
+  try { // a constructor that throws runs no destructor: give back what has been acquired
+    DeviceContext &dc = DeviceContext::get();
+    dOk = (int32_t *)dc.alloc_device(sizeof(int32_t));
+    hOk = (int32_t *)dc.alloc_pinned(sizeof(int32_t));
+  } catch (...) {
+    if (dOk) DeviceContext::get().free_device(dOk);
+    blah2hip_clutter_destroy(engine);
+    throw;
+  }
 }
 
 WienerHopf::~WienerHopf()

@@ -12,9 +12,15 @@ SpectrumAnalyser::SpectrumAnalyser(uint32_t _n, double _bandwidth) : n(_n), band
   if (blah2hip_spectrum_create(n, bandwidth, Ambiguity::default_device(), 1, &engine) != BLAH2HIP_OK)
     throw std::runtime_error(std::string("SpectrumAnalyser: ") + blah2hip_last_error());
   blah2hip_spectrum_get_dims(engine, &decimation, &nSpectrum, &nfft);
-  DeviceContext &dc = DeviceContext::get();
-  dSpec = (double *)dc.alloc_device(2 * (size_t)nSpectrum * sizeof(double));
-  hSpec = (double *)dc.alloc_pinned(2 * (size_t)nSpectrum * sizeof(double));
+  try { // a constructor that throws runs no destructor: give back what has been acquired
+    DeviceContext &dc = DeviceContext::get();
+    dSpec = (double *)dc.alloc_device(2 * (size_t)nSpectrum * sizeof(double));
+    hSpec = (double *)dc.alloc_pinned(2 * (size_t)nSpectrum * sizeof(double));
+  } catch (...) {
+    if (dSpec) DeviceContext::get().free_device(dSpec);
+    blah2hip_spectrum_destroy(engine);
+    throw;
+  }
 }
 
 SpectrumAnalyser::~SpectrumAnalyser()

@@ -59,6 +59,7 @@ void DeviceContext::free_pinned(void *p) { if (p) { (void)blah2hip_ctx_sync(ctx)
 void DeviceContext::forget(IqData *q)
 {
   DeviceContext &c = get();
+  std::lock_guard<std::recursive_mutex> api_(c.api);
   std::lock_guard<std::mutex> lk(c.mu);
   auto it = c.mirrors.find(q);
   if (it == c.mirrors.end()) return;
@@ -113,6 +114,7 @@ void DeviceContext::on_chunk(IqData *q, void *mirror)
 // the stretch of ring positions pushed since the last call goes to the same positions of the device ring
 void DeviceContext::flush_pending(IqData *q, Mirror &m)
 {
+  std::lock_guard<std::recursive_mutex> api_(api);
   size_t start = 0, cnt = 0;
   q->shadow_take_pending(start, cnt);
   while (cnt) {
@@ -129,9 +131,14 @@ void DeviceContext::try_attach(IqData *q, Mirror &m)
   const size_t n = q->get_n();
   static const bool off = std::getenv("BLAH2HIP_NO_EAGER_UPLOAD") != nullptr; // measurements: the per-CPI path only
   if (off || !n || n > SHADOW_MAX) return;
+  // best effort: the CPI at hand has already been served by the per-CPI path, so a failed allocation (64 M samples are
+  // 512 MB of HBM and of pinned memory) leaves this FIFO on that path instead of failing the call
   void *h = nullptr, *d = nullptr;
-  chk(blah2hip_ctx_malloc_host(ctx, n * 2 * sizeof(float), &h), "DeviceContext: pinned shadow");
-  chk(blah2hip_ctx_malloc(ctx, n * 2 * sizeof(float), &d), "DeviceContext: device ring");
+  if (blah2hip_ctx_malloc_host(ctx, n * 2 * sizeof(float), &h) != 0 || !h) return;
+  if (blah2hip_ctx_malloc(ctx, n * 2 * sizeof(float), &d) != 0 || !d) {
+    (void)blah2hip_ctx_free_host(ctx, h);
+    return;
+  }
   m.shadow = (float *)h;
   m.devRing = (float *)d;
   m.ringCap = n;
@@ -145,6 +152,7 @@ void DeviceContext::try_attach(IqData *q, Mirror &m)
 
 const void *DeviceContext::resident(IqData *q, uint32_t count)
 {
+  std::lock_guard<std::recursive_mutex> api_(api);
   Mirror &m = mirror_of(q);
   if (count > q->get_length()) throw std::runtime_error("Attempting to pop from an empty deque"); // what the reference's pops would throw
   if (m.gen == q->generation() && m.view && m.viewCount >= count) return m.view;
@@ -202,6 +210,7 @@ const void *DeviceContext::resident(IqData *q, uint32_t count)
 
 void *DeviceContext::front_buffer(IqData *q, uint32_t count)
 {
+  std::lock_guard<std::recursive_mutex> api_(api);
   Mirror &m = mirror_of(q);
   if (m.capFront < count) {
     sync();
@@ -218,6 +227,7 @@ void *DeviceContext::front_buffer(IqData *q, uint32_t count)
 
 void DeviceContext::adopt_front(IqData *q, uint32_t count)
 {
+  std::lock_guard<std::recursive_mutex> api_(api);
   Mirror &m = mirror_of(q);
   q->set_device_front(count, &m); // bumps the generation
   m.view = m.devFront;
@@ -227,6 +237,7 @@ void DeviceContext::adopt_front(IqData *q, uint32_t count)
 
 void DeviceContext::consumed(IqData *q, uint32_t count)
 {
+  std::lock_guard<std::recursive_mutex> api_(api);
   Mirror &m = mirror_of(q);
   if (!m.view) return;
   const uint32_t d = std::min(count, m.viewCount);
@@ -238,6 +249,7 @@ void DeviceContext::consumed(IqData *q, uint32_t count)
 // device-only front samples -> host doubles (IqData::materialise)
 void DeviceContext::Mirror::read(uint32_t first, uint32_t count, std::complex<double> *dst)
 {
+  std::lock_guard<std::recursive_mutex> api_(ctx->api);
   std::vector<float> tmp(2 * (size_t)count);
   ctx->d2h(tmp.data(), devFront + 2 * (size_t)first, tmp.size() * sizeof(float));
   ctx->sync();
@@ -268,6 +280,7 @@ void DeviceContext::worker()
 
 void DeviceContext::parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)> &fn)
 {
+  std::lock_guard<std::recursive_mutex> api_(api);
   if (n <= grain || workers.empty()) {
     if (n) fn(0, n);
     return;

@@ -80,6 +80,10 @@ private:
     void read(uint32_t first, uint32_t count, std::complex<double> *dst) override;
   };
   blah2hip_ctx_s *ctx = nullptr;
+  // One context per process: its staging buffers, worker job and mirrors are shared state.  Every public entry point (and
+  // the eager-upload hook IqData::push_back calls) holds `api`, so two processing chains on two threads -- or an IqData
+  // destroyed on another thread -- take turns instead of clobbering each other; within a chain nothing changes.
+  std::recursive_mutex api;
   std::mutex mu;
   std::map<IqData *, Mirror *> mirrors;
   // two pinned staging buffers, used in turn: while one channel's upload drains, the next channel is narrowed into the other

@@ -39,8 +39,11 @@ class Map:
         self._fp = self._fingerprint()
 
     def _fingerprint(self):
-        w = np.ascontiguousarray(self.data).view(np.uint64).ravel()
-        return (int(np.bitwise_xor.reduce(w)) if w.size else 0, int(w[::7].sum(dtype=np.uint64)) if w.size else 0, self.data.shape)
+        # position-dependent (CRC-32 of the bytes + Adler-32, with the shape): a swap of two cells, a roll or equal edits
+        # at two places change it, like the C++ Map::fingerprint
+        import zlib
+        raw = np.ascontiguousarray(self.data).view(np.uint8).ravel()
+        return (zlib.crc32(raw), zlib.adler32(raw), self.data.shape)
 
     def device_copy_is_current(self) -> bool:
         """True while the engine's device copy is still this map: no later process call on the engine and no change of

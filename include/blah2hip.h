@@ -209,7 +209,9 @@ int blah2hip_cfar1d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
                         uint32_t cap, uint32_t *d_count, void *stream);
 /* Builds the threshold table alpha[n] = n (pfa^(-1/n) - 1) for this (pfa, n_train) ahead of
  * time (one blocking upload).  blah2hip_cfar1d_dev does it on the first call with a new
- * tuple and only enqueues afterwards. */
+ * tuple and only enqueues afterwards.  A table built by *_prepare stays resident for the handle's lifetime (a graph
+ * captured after it may replay at any time); the tables the dev calls build on their own are a cache of eight, least
+ * recently used first out. */
 int blah2hip_cfar1d_prepare(blah2hip_amb_t h, double pfa, int32_t n_train);
 /* host: runs the detector on CPI `cpi` of the handle's internal map and
  * returns Detection's three vectors (delay bins, Doppler Hz, snr) in the
