@@ -720,13 +720,14 @@ namespace {
 // (create, and again when BLAH2HIP_CLUTTER_OPT_SOLVE_E changes).  Zeroed once: tags are launch epochs >= 1.
 int solve_la_alloc(blah2hip_clutter_s *h)
 {
+  // the mailbox layout depends on the slice width only; the largest batch a width can be chosen for is the handle's
   int64_t need = 0;
   for (int E : sla::kE) {
     if (h->solveE && E != h->solveE) continue;
-    const sla::Plan p = sla::make_plan(h->nBins, E);
+    const sla::Plan p4 = sla::make_plan(h->nBins, E, 4), p8 = sla::make_plan(h->nBins, E, 8);
     int64_t batch = h->maxBatch;
-    if (!h->solveE && E != 12) batch = std::min<int64_t>(batch, 8 * (h->numCU / (8 * p.G)));
-    need = std::max(need, p.stride * batch);
+    if (!h->solveE && E != 12) batch = std::min<int64_t>(batch, 8 * (h->numCU / (8 * std::min(p4.G, p8.G))));
+    need = std::max(need, p4.stride * batch);
   }
   if (need > h->mailWords) {
     if (h->d_mail) CHIP(hipFree(h->d_mail));
@@ -742,9 +743,10 @@ int solve_la_alloc(blah2hip_clutter_s *h)
   return BLAH2HIP_OK;
 }
 
-template <int E> void launch_solve_la(const sla::Args &a, int grid, hipStream_t st)
+template <int E> void launch_solve_la(const sla::Args &a, int grid, int nw, hipStream_t st)
 {
-  hipLaunchKernelGGL(sla::clutter_solve_la_kernel<E>, dim3(grid), dim3(256), 0, st, a);
+  if (nw == 4) hipLaunchKernelGGL((sla::clutter_solve_la_kernel<E, 4>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((sla::clutter_solve_la_kernel<E, 8>), dim3(grid), dim3(512), 0, st, a);
 }
 
 // Transform length, segmentation, correlation form and the buffers sized by them (create, and again when
@@ -814,10 +816,10 @@ int launch_solve(blah2hip_clutter_s *h, const SolveArgs &sa, uint32_t nCpi, hipS
     if (p.stride * (int64_t)nCpi > h->mailWords) CFAIL(BLAH2HIP_ERR_INVALID, "internal: solve mailbox too small for this launch");
     const int grid = ((int)nCpi + 7) / 8 * 8 * p.G;
     switch (p.E) {
-    case 2: launch_solve_la<2>(la, grid, st); break;
-    case 3: launch_solve_la<3>(la, grid, st); break;
-    case 6: launch_solve_la<6>(la, grid, st); break;
-    default: launch_solve_la<12>(la, grid, st); break;
+    case 2: launch_solve_la<2>(la, grid, p.NW, st); break;
+    case 3: launch_solve_la<3>(la, grid, p.NW, st); break;
+    case 6: launch_solve_la<6>(la, grid, p.NW, st); break;
+    default: launch_solve_la<12>(la, grid, p.NW, st); break;
     }
     h->lastForm = BLAH2HIP_CLUTTER_SOLVE_LOOKAHEAD; h->lastE = p.E; h->lastG = p.G;
   } else {

@@ -17,13 +17,18 @@
 // succeeds (WienerHopf.cpp:111); otherwise ok = 0 and the taps are zero.  fp64 throughout.
 // (Derivation and a wave-level NumPy model of exactly this index algebra: tools/proto/toeplitz_front_bulk.py.)
 //
-//   * The FRONT wave (wave 0 of a CPI's first workgroup) produces the coefficients.  It keeps two 64-lane sets of the
-//     32-index sub-windows W_b = [32b+1, 32b+32]:  A = [W_b | W_b+1],  B = [W_b+1 | W_b+2].  Phase 1 of block b runs the
-//     32 orders on A, reading (ef, dt) off the leading lane -- the one dependent chain of the whole solve -- and
-//     publishes them in chunks of 8 orders; phase 2 applies them to B.  Stale values creep up one lane per order from
-//     lane 0, so both upper halves stay valid:  A' = [A.hi | B.hi],  B' = [B.hi | feed-in], the feed-in being W_b+3 as
-//     the bulk wave that owns it holds it after block b.  It is needed only by phase 2 of block b+1, which is the
-//     slack that lets the bulk waves run a block behind without stalling the chain.
+//   * The FRONT (waves 0 and 1 of a CPI's first workgroup) produces the coefficients from the 32-index sub-windows
+//     W_b = [32b+1, 32b+32].  The CHAIN wave runs the 32 orders of block b on W_b, reading (ef, dt) off the leading lane
+//     -- the one dependent chain of the whole solve -- and publishes them in chunks of 8 orders (LDS for its companion,
+//     granules in L2 for the bulk).  Its COMPANION wave supplies every next triangle: stale values creep up one lane
+//     per order from lane 0 of a 64-lane set, so after 32 orders on [W_b | W_b+1] the upper half is still valid.  Per
+//     block b it (i) applies c_(b-1) to D = [W_b | W_b+1] valid through block b-2, whose upper half is the feed-in the
+//     bulk wave that owns W_b+1 published after ITS block b-2 -- two blocks of slack, so the bulk may run behind
+//     without stalling the chain -- and (ii) follows the chain wave's chunks of block b on C = [W_b | W_b+1] valid
+//     through b-1 (lower half: its own last hand-over, upper half: D's) and hands C.hi = W_b+1, valid through b, over
+//     through LDS.  (Rounds of measurement behind this split: a wave issues in order, an fp64 instruction of a lone
+//     wave costs 5-6 cycles, so the chain wave is bound by its instruction count -- 300 cycles per order with the
+//     catch-up orders in the same wave, against a dependent chain of ~150.)
 //   * BULK waves own S = 64 E - 32 consecutive indices (E per lane, lane-major: the shift is a register rename plus ONE
 //     DPP wave shift) and a halo of 32 below them.  Per block: wait for the coefficient chunks, 32 orders, publish the
 //     top 32 indices as the halo of the wave above, publish the front's feed-in if it lies here, refresh the own halo.
@@ -162,7 +167,7 @@ template <int E, bool FIX> __device__ __forceinline__ void apply_chunk(St<E> &s,
 {
   // narrow slices have little to overlap an LDS round trip with: all 8 records in registers first; wide ones (E = 12
   // sits at the register cap and has 144 independent multiply-adds per order) two at a time
-  constexpr int G = E <= 3 ? 8 : (E <= 6 ? 4 : 2);
+  constexpr int G = E <= 3 ? 8 : (E <= 6 ? 4 : 1);
 #pragma unroll 1
   for (int t0 = 0; t0 < 8; t0 += G) {
     Coef c[G];
@@ -204,8 +209,34 @@ __device__ __forceinline__ void put_coef(Coef *p, double efr, double efi, double
 #define SLA_LAP(acc) do { } while (0)
 #endif
 
-// ---- the front wave -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void front(const Args &a, int cpi, uint32_t tag, int lane, Coef *cl)
+// ---- the front: chain wave and companion wave ---------------------------------------------------------------------------
+// What the two exchange through LDS.  The chain wave writes a chunk's 8 records (the same 64 dwords it publishes as
+// granules) and then its chunk count, every lane into a slot of its own; the companion writes a hand-over's 32 x 6
+// doubles and then its count.  The LDS serves a wave's requests in order, so a count that has arrived has its data behind
+// it.  Records are double-buffered by block parity: the companion reads c_(b-1) while the chain wave writes c_b, and it
+// has finished with c_(b-1) before it hands over the window the chain wave needs to start block b+1.
+struct PairLds {
+  Coef rec[2][KB];
+  double hand[6][KB];
+  unsigned seq[64];      // chunks the chain wave has published
+  unsigned handseq[64];  // hand-overs the companion has made
+  unsigned bad;          // one of the two has given up (not positive definite, or a bounded wait ran out)
+};
+
+__device__ __forceinline__ bool lds_wait_count(const unsigned *p, unsigned want, const unsigned *bad, uint32_t *fault)
+{
+  for (unsigned spins = 0;;) {
+    const unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((int)(__builtin_amdgcn_readfirstlane(v) - want) >= 0) {
+      asm volatile("" ::: "memory"); // what the count announces is read after it
+      return true;
+    }
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) return false;
+    if (spin_fail(spins, fault)) return false;
+  }
+}
+
+__device__ __forceinline__ void front_chain(const Args &a, int cpi, uint32_t tag, int lane, PairLds *pl)
 {
   const int n = a.n, NB = a.NB;
   const dcx *r = a.rb + (size_t)cpi * 2 * n, *b = r + n;
@@ -218,18 +249,18 @@ __device__ __forceinline__ void front(const Args &a, int cpi, uint32_t tag, int 
   double inv_s = bad ? 0.0 : 1.0 / r0;
   const dcx b0 = b[0];
   const dcx x0 = {b0.x * inv_s, b0.y * inv_s};
-  St<1> A, B;
+  St<1> A; // lanes 0..31: W_blk; the upper lanes ride along unused
   init_index(r, b, n, x0, 1 + lane, A.Ur[0], A.Ui[0], A.Vr[0], A.Vi[0], A.Zr[0], A.Zi[0]);
-  init_index(r, b, n, x0, 1 + KB + lane, B.Ur[0], B.Ui[0], B.Vr[0], B.Vi[0], B.Zr[0], B.Zi[0]);
   const bool lo = lane < 32;
   const int f8 = lane & 7, g8 = lane >> 3;
   int blk = 0, cdone = 0; // chunks published so far
 #ifdef SLA_TRACE
-  unsigned long long tr1 = 0, tr2 = 0, trw = 0, trr = 0;
+  unsigned long long tr1 = 0, trw = 0;
   const unsigned long long wc0 = wall_clock64(), cy0 = __builtin_readcyclecounter();
 #endif
-  uint32_t *clw = reinterpret_cast<uint32_t *>(cl);
   for (; blk < NB && !bad; blk++) {
+    Coef *cl = pl->rec[blk & 1];
+    uint32_t *clw = reinterpret_cast<uint32_t *>(cl);
     SLA_T0;
     // phase 1: the 32 orders of this block on A, coefficients off the leading lane.  Orders beyond the last (the tail of
     // the last block) are identities.  This loop is the one dependent chain of the whole solve -- 1/s -> ef -> D -> 1/D
@@ -349,45 +380,29 @@ __device__ __forceinline__ void front(const Args &a, int cpi, uint32_t tag, int 
       // the chunk as 64 granules: lane L <-> dword L of the 8 records
       st64(coef + ((size_t)(KB * blk + 8 * c)) * 8 + lane, ((u64)tag << 32) | clw[64 * c + lane]);
       cdone++;
+      asm volatile("" ::: "memory");
+      __hip_atomic_store(&pl->seq[lane], (unsigned)cdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // behind the records: a wave's LDS requests are served in order
     }
     if (bad) break;
     SLA_LAP(tr1);
-    // B's upper half for this block's phase 2: W_{blk+2} as its owner holds it after block blk-1 (block 0: initial values)
-    if (blk > 0 && blk + 2 <= NB - 1) {
-      const int wb = blk + 2;
-      if (!wait_flag(mail + a.offFeedFlag + wb, tag, a.fault)) return;
-      if (!lo) {
-        const u64 *p = mail + a.offFeed + ((size_t)wb * KB + (lane - 32)) * 6;
-        B.Ur[0] = ld_d(p + 0); B.Ui[0] = ld_d(p + 1); B.Vr[0] = ld_d(p + 2);
-        B.Vi[0] = ld_d(p + 3); B.Zr[0] = ld_d(p + 4); B.Zi[0] = ld_d(p + 5);
-      }
+    if (blk + 1 >= NB) break;
+    // the next triangle: W_(blk+1), valid through this block, from the companion
+    if (!lds_wait_count(&pl->handseq[0], (unsigned)blk + 1u, &pl->bad, a.fault)) return;
+    {
+      const int l = lane & 31;
+      const double u0 = pl->hand[0][l], u1 = pl->hand[1][l], v0 = pl->hand[2][l], v1 = pl->hand[3][l], z0 = pl->hand[4][l], z1 = pl->hand[5][l];
+      A.Ur[0] = lo ? u0 : 0.0; A.Ui[0] = lo ? u1 : 0.0; A.Vr[0] = lo ? v0 : 0.0;
+      A.Vi[0] = lo ? v1 : 0.0; A.Zr[0] = lo ? z0 : 0.0; A.Zi[0] = lo ? z1 : 0.0;
     }
     SLA_LAP(trw);
-    // phase 2: the block applied to B
-#pragma unroll 1
-    for (int c = 0; c < 4; c++) apply_chunk<1, false>(B, cl + 8 * c, lane, 0);
-    SLA_LAP(tr2);
-    if (blk + 1 >= NB) break;
-    // A' = [A.hi | B.hi],  B' = [B.hi | W_{blk+3}, fetched before the next phase 2]
-    double t;
-    t = rot32(A.Ur[0], lane); A.Ur[0] = lo ? t : B.Ur[0];
-    t = rot32(A.Ui[0], lane); A.Ui[0] = lo ? t : B.Ui[0];
-    t = rot32(A.Vr[0], lane); A.Vr[0] = lo ? t : B.Vr[0];
-    t = rot32(A.Vi[0], lane); A.Vi[0] = lo ? t : B.Vi[0];
-    t = rot32(A.Zr[0], lane); A.Zr[0] = lo ? t : B.Zr[0];
-    t = rot32(A.Zi[0], lane); A.Zi[0] = lo ? t : B.Zi[0];
-    B.Ur[0] = rot32(B.Ur[0], lane); B.Ui[0] = rot32(B.Ui[0], lane);
-    B.Vr[0] = rot32(B.Vr[0], lane); B.Vi[0] = rot32(B.Vi[0], lane);
-    B.Zr[0] = rot32(B.Zr[0], lane); B.Zi[0] = rot32(B.Zi[0], lane);
-    SLA_LAP(trr);
   }
 #ifdef SLA_TRACE
   if (lane == 0 && cpi == 0)
-    printf("sla trace front: n %d NB %d  phase1 %.2f us/block  feed wait %.2f  phase2 %.2f  rotate %.2f  cycle counter %.0f MHz\n", n, NB,
-           0.01 * tr1 / NB, 0.01 * trw / NB, 0.01 * tr2 / NB, 0.01 * trr / NB,
-           100.0 * (double)(__builtin_readcyclecounter() - cy0) / (double)(wall_clock64() - wc0));
+    printf("sla trace chain: n %d NB %d  orders %.2f us/block  hand-over wait %.2f  cycle counter %.0f MHz\n", n, NB,
+           0.01 * tr1 / NB, 0.01 * trw / NB, 100.0 * (double)(__builtin_readcyclecounter() - cy0) / (double)(wall_clock64() - wc0));
 #endif
   if (bad) {
+    __hip_atomic_store(&pl->bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     // not positive definite: say so BEFORE the remaining coefficients go out as identities, so that a bulk wave that
     // has consumed its last chunk finds the status set
     st64(mail + a.offStatus, (u64)tag);
@@ -397,6 +412,76 @@ __device__ __forceinline__ void front(const Args &a, int cpi, uint32_t tag, int 
     return;
   }
   if (lane == 0) a.ok[cpi] = 1;
+}
+
+__device__ __forceinline__ void front_companion(const Args &a, int cpi, uint32_t tag, int lane, PairLds *pl)
+{
+  const int n = a.n, NB = a.NB;
+  const dcx *r = a.rb + (size_t)cpi * 2 * n, *b = r + n;
+  u64 *mail = a.mail + (size_t)cpi * a.mailStride;
+  __builtin_amdgcn_s_setprio(2);
+  const double r0 = r[0].x;
+  const double inv0 = (r0 > 0.0 && isfinite(r0)) ? 1.0 / r0 : 0.0;
+  const dcx b0 = b[0];
+  const dcx x0 = {b0.x * inv0, b0.y * inv0};
+  St<1> C, D;
+  init_index(r, b, n, x0, 1 + lane, C.Ur[0], C.Ui[0], C.Vr[0], C.Vi[0], C.Zr[0], C.Zi[0]);         // [W_0 | W_1]
+  init_index(r, b, n, x0, 1 + KB + lane, D.Ur[0], D.Ui[0], D.Vr[0], D.Vi[0], D.Zr[0], D.Zi[0]);    // [W_1 | W_2]
+  const bool lo = lane < 32;
+#ifdef SLA_TRACE
+  unsigned long long trf = 0, tr2 = 0, trc = 0;
+#endif
+  for (int blk = 0; blk + 1 < NB; blk++) {
+    SLA_T0;
+    if (blk >= 1) {
+      // (i) c_(blk-1) on D = [W_blk | W_(blk+1)] valid through blk-2; its upper half from the bulk (blk = 1: initial values)
+      if (blk >= 2) {
+        D.Ur[0] = rot32(D.Ur[0], lane); D.Ui[0] = rot32(D.Ui[0], lane); D.Vr[0] = rot32(D.Vr[0], lane);
+        D.Vi[0] = rot32(D.Vi[0], lane); D.Zr[0] = rot32(D.Zr[0], lane); D.Zi[0] = rot32(D.Zi[0], lane);
+        const int wb = blk + 1;
+        if (!wait_flag(mail + a.offFeedFlag + wb, tag, a.fault)) { __hip_atomic_store(&pl->bad, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
+        if (!lo) {
+          const u64 *p = mail + a.offFeed + ((size_t)wb * KB + (lane - 32)) * 6;
+          D.Ur[0] = ld_d(p + 0); D.Ui[0] = ld_d(p + 1); D.Vr[0] = ld_d(p + 2);
+          D.Vi[0] = ld_d(p + 3); D.Zr[0] = ld_d(p + 4); D.Zi[0] = ld_d(p + 5);
+        }
+      }
+      SLA_LAP(trf);
+      if (!lds_wait_count(&pl->seq[0], 4u * (unsigned)blk, &pl->bad, a.fault)) return;
+      const Coef *cp = pl->rec[(blk - 1) & 1];
+#pragma unroll 1
+      for (int c = 0; c < 4; c++) apply_chunk<1, false>(D, cp + 8 * c, lane, 0);
+      // C = [last hand-over (C.hi) | D.hi]
+      double t;
+      t = rot32(C.Ur[0], lane); C.Ur[0] = lo ? t : D.Ur[0];
+      t = rot32(C.Ui[0], lane); C.Ui[0] = lo ? t : D.Ui[0];
+      t = rot32(C.Vr[0], lane); C.Vr[0] = lo ? t : D.Vr[0];
+      t = rot32(C.Vi[0], lane); C.Vi[0] = lo ? t : D.Vi[0];
+      t = rot32(C.Zr[0], lane); C.Zr[0] = lo ? t : D.Zr[0];
+      t = rot32(C.Zi[0], lane); C.Zi[0] = lo ? t : D.Zi[0];
+      SLA_LAP(tr2);
+    }
+    // (ii) the chain wave's chunks of this block on C as they come
+    const Coef *cq = pl->rec[blk & 1];
+#pragma unroll 1
+    for (int c = 0; c < 4; c++) {
+      if (!lds_wait_count(&pl->seq[0], 4u * (unsigned)blk + (unsigned)c + 1u, &pl->bad, a.fault)) return;
+      apply_chunk<1, false>(C, cq + 8 * c, lane, 0);
+    }
+    // hand C.hi = W_(blk+1), valid through this block, over
+    if (!lo) {
+      const int l = lane - 32;
+      pl->hand[0][l] = C.Ur[0]; pl->hand[1][l] = C.Ui[0]; pl->hand[2][l] = C.Vr[0];
+      pl->hand[3][l] = C.Vi[0]; pl->hand[4][l] = C.Zr[0]; pl->hand[5][l] = C.Zi[0];
+    }
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(&pl->handseq[lane], (unsigned)blk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    SLA_LAP(trc);
+  }
+#ifdef SLA_TRACE
+  if (lane == 0 && cpi == 0)
+    printf("sla trace companion: feed wait %.2f us/block  catch-up orders %.2f  following + hand-over %.2f\n", 0.01 * trf / NB, 0.01 * tr2 / NB, 0.01 * trc / NB);
+#endif
 }
 
 // ---- a bulk wave ----------------------------------------------------------------------------------------------------
@@ -507,36 +592,49 @@ template <int E> __device__ __forceinline__ void bulk(const Args &a, int cpi, ui
   }
 }
 
-// grid: ceil(nCpi / 8) * 8 * G workgroups of 256 threads.  The G workgroups of a CPI take block ids congruent mod 8
-// (same XCD while the dispatcher keeps its round-robin: their exchange is then served by one L2 -- speed only)
-template <int E> __global__ __launch_bounds__(256) void clutter_solve_la_kernel(Args a)
+// grid: ceil(nCpi / 8) * 8 * G workgroups of NW waves.  The G workgroups of a CPI take block ids congruent mod 8 (same XCD
+// while the dispatcher keeps its round-robin: their exchange is then served by one L2 -- speed only).  Roles in a CPI's
+// first workgroup: wave 0 the chain wave, wave 1 its companion, then bulk waves (with 8 waves two of them share the front
+// waves' SIMDs: the eight-wave form is the packed one, for batches in which the bulk waves set the pace and the chain
+// wave, at the higher priority, mostly waits); every other workgroup is NW bulk waves.
+template <int E, int NW> __global__ __launch_bounds__(64 * NW) void clutter_solve_la_kernel(Args a)
 {
   const int G = a.G;
   const int chunk = blockIdx.x / (8 * G), within = blockIdx.x - chunk * 8 * G;
   const int member = within >> 3, cpi = chunk * 8 + (within & 7);
   if (cpi >= a.nCpi) return;
-  const int lane = threadIdx.x & 63;
-  const int gw = member * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t tag = *a.epoch;
-  __shared__ Coef lds[4][KB]; // a wave's own copy of the block's coefficients (1 KB each; no exchange through it)
-  Coef *cl = lds[threadIdx.x >> 6];
-  if (gw == 0) front(a, cpi, tag, lane, cl);
-  else if (gw - 1 < a.nbulk) bulk<E>(a, cpi, tag, lane, gw - 1, cl);
+  __shared__ Coef lds[NW][KB]; // a bulk wave's own copy of the block's coefficients (1 KB each; no exchange through it)
+  __shared__ PairLds pl;       // the front's two waves (a CPI's first workgroup)
+  if (threadIdx.x < 64) { pl.seq[threadIdx.x] = 0; pl.handseq[threadIdx.x] = 0; }
+  if (threadIdx.x == 0) pl.bad = 0;
+  __syncthreads();
+  int q;
+  if (member == 0) {
+    if (w == 0) { front_chain(a, cpi, tag, lane, &pl); return; }
+    if (w == 1) { front_companion(a, cpi, tag, lane, &pl); return; }
+    q = w - 2;
+  } else {
+    q = NW - 2 + (member - 1) * NW + w;
+  }
+  if (q < a.nbulk) bulk<E>(a, cpi, tag, lane, q, lds[w]);
 }
 
 // ---- host side: the plan of a launch --------------------------------------------------------------------------------
 struct Plan {
-  int E = 0, G = 0, nbulk = 0, NB = 0;
+  int E = 0, NW = 4, G = 0, nbulk = 0, NB = 0;
   int64_t stride = 0, offHalo = 0, offFeed = 0, offHaloFlag = 0, offFeedFlag = 0, offStatus = 0;
 };
-inline Plan make_plan(int n, int E)
+inline Plan make_plan(int n, int E, int NW)
 {
   Plan p;
-  p.E = E;
+  p.E = E; p.NW = NW;
   const int S = 64 * E - KB;
   p.nbulk = std::max(1, (n - 1 + S - 1) / S);
   p.NB = std::max(1, (n - 1 + KB - 1) / KB);
-  p.G = (p.nbulk + 1 + 3) / 4;
+  const int first = NW - 2; // bulk waves beside the front's two in a CPI's first workgroup
+  p.G = 1 + (std::max(0, p.nbulk - first) + NW - 1) / NW;
   int64_t o = (int64_t)p.NB * KB * 8;
   p.offHalo = o; o += (int64_t)p.nbulk * p.NB * KB * 6;
   p.offFeed = o; o += (int64_t)p.NB * KB * 6;
@@ -547,26 +645,19 @@ inline Plan make_plan(int n, int E)
   return p;
 }
 constexpr int kE[4] = {2, 3, 6, 12};
-// smallest E (lowest latency per block) whose workgroups all get a CU of their own; the widest slices otherwise
+// narrowest slices (lowest latency per block) whose workgroups all get a CU of their own, four waves per workgroup before
+// eight; the widest slices otherwise
 inline Plan choose_plan(int n, int nCpi, int numCU, int forceE)
 {
-  if (forceE) return make_plan(n, forceE);
+  const int64_t groups = (nCpi + 7) / 8 * 8;
   for (int E : kE) {
-    const Plan p = make_plan(n, E);
-    if ((int64_t)p.G * ((nCpi + 7) / 8 * 8) <= numCU) return p;
+    if (forceE && E != forceE) continue;
+    for (int NW : {4, 8}) {
+      const Plan p = make_plan(n, E, NW);
+      if ((int64_t)p.G * groups <= numCU) return p;
+    }
   }
-  return make_plan(n, 12);
-}
-// u64 words of mailbox a handle needs for launches of up to maxBatch CPIs under any plan choose_plan can return
-inline int64_t mail_words(int n, int maxBatch, int numCU)
-{
-  int64_t need = 0;
-  for (int E : kE) {
-    const Plan p = make_plan(n, E);
-    need = std::max(need, p.stride * (int64_t)maxBatch);
-  }
-  (void)numCU;
-  return need;
+  return make_plan(n, forceE ? forceE : 12, 8);
 }
 
 } // namespace sla

@@ -87,3 +87,15 @@ def test_front_bulk_model_refuses_what_is_not_positive_definite():
     r = np.array([1.0, 0.9, 1.2, 0.1, 0.0, 0.3], complex)
     assert not FB.solve_front_bulk(r, np.ones(6), 2)[1]
     assert not FB.solve_front_bulk(np.array([-1.0, 0.1], complex), np.ones(2), 3)[1]
+
+
+@pytest.mark.parametrize("n,colour", [(2, 0.0), (34, 0.5), (97, 0.9), (300, 0.9), (411, 0.5)])
+@pytest.mark.parametrize("E", [2, 3, 12])
+def test_two_wave_front_model_equals_the_one_wave_front(n, colour, E):
+    """The front as a chain wave (triangle only) and a companion wave (catch-up one block later + following): the
+    hand-over and feed-in schedule of csrc/solve_la.hpp's front_chain / front_companion."""
+    r, b = coloured_normal_equations(n, colour, 5 * n + E)
+    w1, ok1 = FB.solve_front_bulk(r, b, E)
+    w2, ok2 = FB.solve_front_pair_bulk(r, b, E)
+    assert ok1 and ok2
+    assert np.linalg.norm(w2 - w1) <= 1e-9 * np.linalg.norm(w1)

@@ -128,6 +128,101 @@ class Bulk:
         return [a[p:p + K].copy() for a in self.st]
 
 
+class FrontPair:
+    """The front as TWO waves (round 4): the chain wave keeps only the 32-index triangle W_b; its companion wave
+    supplies every next triangle.  Per block b the companion (i) applies c_{b-1} to D = [W_b | W_b+1] valid through b-2
+    (the old phase 2, one block later: its feed-in from the bulk has a whole block of slack more), then (ii) follows the
+    chain wave's orders of block b on C = [W_b | W_b+1] valid through b-1 and hands C.hi = W_b+1 valid through b over."""
+
+    def __init__(self, r, b):
+        self.r, self.b, self.n = r, b, r.size
+        self.inv_s = 1.0 / r[0].real
+        self.T = self._load(1, K)                      # W_0
+        self.C = self._load(1, 2 * K)                  # [W_0 | W_1]
+        self.Dhi_prev = self._load(1 + K, K)           # W_1, "valid through -2": initial
+        self.blk = 0
+
+    def _load(self, j0, cnt):
+        vals = [_init_index(self.r, self.b, j) for j in range(j0, j0 + cnt)]
+        return [np.array([v[i] for v in vals]) for i in range(3)]
+
+    def block(self, feed):
+        """feed: W_{blk+1} valid through block blk-2 from the bulk (blk >= 2), else None (initial values)."""
+        b, n = self.blk, self.n
+        # companion, step (i)
+        if b >= 1:
+            hi = feed if feed is not None else (self._load(1 + K * (b + 1), K) if b < 2 else [np.zeros(K, complex)] * 3)
+            D = [np.concatenate((lo, h)) for lo, h in zip(self.Dhi_prev, hi)]
+            for ef, dt in zip(*self.prev_coef):
+                D = list(_step(*D, ef, dt))
+            self.Dhi_prev = [a[K:].copy() for a in D]
+            self.C = [np.concatenate((c_lo, d_hi)) for c_lo, d_hi in zip(self.Chi_prev, self.Dhi_prev)]
+        # chain wave: the triangle alone
+        U, V, Z = self.T
+        efs, dts = [], []
+        for i in range(K):
+            m = K * b + i
+            if m > n - 2:
+                efs.append(0j); dts.append(0j)
+                U, V, Z = _step(U, V, Z, 0j, 0j)
+                continue
+            ef = U[i] * self.inv_s
+            D_ = 1.0 - abs(ef) ** 2
+            if not (D_ > 0.0) or not np.isfinite(D_):
+                return None
+            self.inv_s = self.inv_s / D_
+            dt = -Z[i] * self.inv_s
+            U, V, Z = _step(U, V, Z, ef, dt)
+            efs.append(ef); dts.append(dt)
+        # companion, step (ii): the same orders on C
+        C = self.C
+        for ef, dt in zip(efs, dts):
+            C = list(_step(*C, ef, dt))
+        self.Chi_prev = [a[K:].copy() for a in C]
+        self.T = [a.copy() for a in self.Chi_prev]     # the hand-over
+        self.prev_coef = (efs, dts)
+        self.blk += 1
+        return efs, dts
+
+
+def solve_front_pair_bulk(r, b, E=3):
+    """solve_front_bulk with the two-wave front: same bulk, same feed-in schedule (W_{k+3} after the bulk's block k)."""
+    r = np.asarray(r, dtype=np.complex128)
+    b = np.asarray(b, dtype=np.complex128)
+    n = r.size
+    if not (r[0].real > 0) or not np.isfinite(r[0].real):
+        return np.zeros(n, complex), False
+    S = 64 * E - K
+    nbulk = max(1, -(-(n - 1) // S))
+    NB = max(1, -(-(n - 1) // K))
+    front = FrontPair(r, b)
+    bulk = [Bulk(r, b, q, E) for q in range(nbulk)]
+    feeds = {}
+    for blk in range(NB):
+        c = front.block(feeds.get(blk + 1))
+        if c is None:
+            return np.zeros(n, complex), False
+        efs, dts = c
+        for w in bulk:
+            w.block(blk, efs, dts)
+        tops = [w.top() for w in bulk]
+        for q in range(1, nbulk):
+            for a in bulk[q].st:
+                a[:K] = np.nan
+            bulk[q].refresh_halo(tops[q - 1])
+        for w in bulk:                                   # W_{blk+3} valid through blk
+            f = w.window(blk + 3)
+            if f is not None:
+                feeds[blk + 3] = f
+    x = np.zeros(n, complex)
+    for w in bulk:
+        for p in range(K - 1 if w.q == 0 else K, 64 * E):
+            j = w.j0 + p
+            if 0 <= j < n:
+                x[j] = w.st[2][p]
+    return x, True
+
+
 def solve_front_bulk(r, b, E=3, check_halo_garbage=True):
     r = np.asarray(r, dtype=np.complex128)
     b = np.asarray(b, dtype=np.complex128)
@@ -188,6 +283,8 @@ def _selftest():
         for E in (1, 2, 3, 6, 12):
             w2, ok2 = solve_front_bulk(r, bb, E)
             assert ok2
+            w3, ok3 = solve_front_pair_bulk(r, bb, E)
+            assert ok3 and np.linalg.norm(w3 - w2) <= 1e-9 * np.linalg.norm(w2), (n, E)
             d = np.linalg.norm(w2 - w1) / np.linalg.norm(w1)
             T = la._toeplitz(r)
             res = np.linalg.norm(T @ w2 - bb) / np.linalg.norm(bb)
