@@ -30,11 +30,11 @@ for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"bench_r{n}*.log"
         if (names.get(bc.get("config")), bc.get("batch"), bc.get("fmt"), bc.get("chain", "amb")) != cfgk:
             continue
         sys.path.insert(0, ROOT)
-        prof_names = {"range": ("rangew2_kernel", "rangew_kernel", "range_kernel", "range8_kernel"), "doppler": ("doppler_",),
+        prof_names = {"range": ("rangeps_kernel", "rangew_kernel", "range_kernel", "range8_kernel"), "doppler": ("doppler_",),
                       "metrics": ("metrics_kernel",), "cfar": ("cfar2d_tile_kernel", "cfar2d_kernel", "cfar1d_kernel"),
                       "sat_rows": ("sat_rows_kernel",), "sat_cols": ("sat_cols_kernel",), "rotate": ("rotate_kernel",),
                       "clutter_corr": ("clutter_corr_half_kernel", "clutter_corr_kernel"), "clutter_fir": ("clutter_fir_kernel",),
-                      "clutter_solve": ("clutter_solve_kernel",), "clutter_reduce": ("clutter_reduce_kernel",)}
+                      "clutter_solve": ("clutter_solve_la_kernel", "clutter_solve_kernel"), "clutter_reduce": ("clutter_reduce_kernel",)}
         rk = j["roofline"].get("kernel", "range_kernel")  # the range kernel this line ran, no other
         prof_names["range"] = tuple(k for k in tj["kernels"] if k == rk or k.startswith(rk + "<"))
         for e in j["roofline"]["kernels"]:
