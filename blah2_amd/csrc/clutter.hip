@@ -399,28 +399,42 @@ struct SolveArgs {
   uint32_t *epoch;   // launch epoch of the look-ahead solve's mailboxes (solve_la.hpp), bumped here
 };
 
-// grid (ceil(nBins/256), 2, nCpi): fixed-order fp64 sum over the jobs
+// grid (ceil(nBins/16), 2, nCpi) x 256: fixed-order fp64 sum over the jobs.  A block takes 16 bins (128-byte rows) and cuts the
+// jobs into sixteen interleaved slices (thread = bin + 16 slice): a lone CPI has up to 512 partials per bin, which one thread per bin
+// summed as 64 dependent rounds of L2 latency (27.8 us of the 171 us a lone CPI's full chain took at configs[1], round 4);
+// the slices' sums meet in LDS and are added in slice order -- the same order every run.
 __global__ __launch_bounds__(256) void clutter_reduce_kernel(SolveArgs a)
 {
-  const int k = blockIdx.x * 256 + threadIdx.x, mode = blockIdx.y, cpi = blockIdx.z;
-  if (a.epoch && k == 0 && mode == 0 && cpi == 0) { // one thread per launch; the solve kernel behind the boundary reads it
+  __shared__ double sx[16][16], sy[16][16];
+  const int bin = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + bin, mode = blockIdx.y, cpi = blockIdx.z;
+  if (a.epoch && blockIdx.x == 0 && threadIdx.x == 0 && mode == 0 && cpi == 0) { // one thread per launch; the solve kernel behind the boundary reads it
     const uint32_t e = *a.epoch + 1u;
     *a.epoch = e ? e : 1u;
   }
-  if (k >= a.nBins) return;
-  const cf *p = a.partial + ((size_t)cpi * 2 + mode) * a.nJobs * a.nBins + k;
-  // four interleaved accumulators: the loads of a group of 8 are independent (fixed order -> deterministic)
-  double sx[4] = {0, 0, 0, 0}, sy[4] = {0, 0, 0, 0};
-  int j = 0;
-  for (; j + 8 <= a.nJobs; j += 8) {
-    cf v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = p[(size_t)(j + u) * a.nBins];
-#pragma unroll
-    for (int u = 0; u < 8; u++) { sx[u & 3] += (double)v[u].x; sy[u & 3] += (double)v[u].y; }
+  double ax = 0.0, ay = 0.0;
+  if (k < a.nBins) {
+    const cf *p = a.partial + ((size_t)cpi * 2 + mode) * a.nJobs * a.nBins + k;
+    // two interleaved accumulators: the loads of a pair of rounds are independent
+    double bx = 0.0, by = 0.0;
+    int j = slice;
+    for (; j + 16 < a.nJobs; j += 32) {
+      const cf u = p[(size_t)j * a.nBins], v = p[(size_t)(j + 16) * a.nBins];
+      ax += (double)u.x; ay += (double)u.y;
+      bx += (double)v.x; by += (double)v.y;
+    }
+    if (j < a.nJobs) { const cf u = p[(size_t)j * a.nBins]; ax += (double)u.x; ay += (double)u.y; }
+    ax += bx; ay += by;
   }
-  for (; j < a.nJobs; j++) { const cf v = p[(size_t)j * a.nBins]; sx[0] += (double)v.x; sy[0] += (double)v.y; }
-  a.rb[((size_t)cpi * 2 + mode) * a.nBins + k] = {(sx[0] + sx[1]) + (sx[2] + sx[3]), (sy[0] + sy[1]) + (sy[2] + sy[3])};
+  sx[slice][bin] = ax;
+  sy[slice][bin] = ay;
+  __syncthreads();
+  if (slice == 0 && k < a.nBins) {
+    double tx = sx[0][bin], ty = sy[0][bin];
+#pragma unroll
+    for (int q = 1; q < 16; q++) { tx += sx[q][bin]; ty += sy[q][bin]; }
+    a.rb[((size_t)cpi * 2 + mode) * a.nBins + k] = {tx, ty};
+  }
 }
 
 // Hermitian Toeplitz solve A w = b, A[i][j] = r[i-j], by the Levinson recursion with its inner
@@ -889,7 +903,7 @@ template <int R3, class In> int launch_clutter(blah2hip_clutter_s *h, const void
   sa.partial = h->d_partial; sa.rb = h->d_rb; sa.w = h->d_w; sa.ok = ok; sa.nBins = h->nBins; sa.nJobs = nJobs;
   sa.epoch = h->d_epoch;
   CHIP(h->timer.tic(BLAH2HIP_CK_REDUCE, st));
-  hipLaunchKernelGGL(clutter_reduce_kernel, dim3((h->nBins + 255) / 256, 2, nCpi), dim3(256), 0, st, sa);
+  hipLaunchKernelGGL(clutter_reduce_kernel, dim3((h->nBins + 15) / 16, 2, nCpi), dim3(256), 0, st, sa);
   CHIP(h->timer.toc(BLAH2HIP_CK_REDUCE, st));
   { const int rc_ = launch_solve(h, sa, nCpi, st); if (rc_) return rc_; }
 
