@@ -576,6 +576,61 @@ bool cfar2d_use_tile(const blah2hip_amb_s *h, int ngd, int ntd, int ngf, int ntf
   return ngf + ntf <= C2T_MAX_HR && ngd + ntd <= C2T_MAX_HC;
 }
 
+// the stream kernel exists for the window shapes of C2S_SHAPES (cfar_kernels.hpp)
+bool cfar2d_stream_shape(int ngd, int ntd, int ngf, int ntf)
+{
+#define B2_X(TD, GD, TF, GF) if (ntd == TD && ngd == GD && ntf == TF && ngf == GF) return true;
+  C2S_SHAPES(B2_X)
+#undef B2_X
+  return false;
+}
+// The rows the detector skips (|doppler| < minDoppler, CfarDetector1D.cpp:40) as ONE interval [lo, hi) of the handle's Doppler axis
+// (monotonic: Ambiguity.cpp:60-66), which the stream kernel tests with scalar compares; false if they are not one interval.
+bool cfar2d_dead_rows(const blah2hip_amb_s *h, double min_doppler, int *lo, int *hi)
+{
+  const int nD = (int)h->dims.n_doppler_bins;
+  int first = nD, last = -1, count = 0;
+  for (int i = 0; i < nD; i++)
+    if (std::fabs(h->dopplerAxis[i]) < min_doppler) { first = std::min(first, i); last = i; count++; }
+  if (count == 0) { *lo = *hi = 0; return true; }
+  *lo = first; *hi = last + 1;
+  return count == last + 1 - first;
+}
+bool cfar2d_use_stream(const blah2hip_amb_s *h, int ngd, int ntd, int ngf, int ntf, double min_doppler)
+{
+  if (h->cfar2dForce == BLAH2HIP_CFAR2D_SAT || h->cfar2dForce == BLAH2HIP_CFAR2D_TILE) return false;
+  int lo, hi;
+  return cfar2d_stream_shape(ngd, ntd, ngf, ntf) && cfar2d_dead_rows(h, min_doppler, &lo, &hi);
+}
+
+// rows per segment: the fewest rounds of (segment + its 2 hR halo rows) over the wave slots of the chip
+void cfar2d_stream_launch(const blah2hip_amb_s *h, const Cfar2dArgs &a, uint32_t n_cpi, hipStream_t st)
+{
+  Cfar2dStreamArgs ta;
+  ta.d = a;
+  ta.nCpi = (int32_t)n_cpi;
+  const int hC = a.ngD + a.ntD, hR = a.ngF + a.ntF;
+  ta.strips = (a.nDelay + (64 - 2 * hC) - 1) / (64 - 2 * hC);
+  const int64_t slots = (int64_t)h->numCU * 4 * 5; // about five waves per SIMD at ~ 100 VGPRs
+  int64_t best = INT64_MAX;
+  for (int R : {32, 64, 128, 256, 512, 1024, (int)a.nD}) {
+    if (R > a.nD && R != a.nD) continue;
+    const int64_t segs = (a.nD + R - 1) / R, tasks = segs * ta.strips * n_cpi;
+    const int64_t cost = ((tasks + slots - 1) / slots) * (std::min(R, (int)a.nD) + 2 * hR + 16); // 16: start-up of a wave, in rows
+    if (cost < best) { best = cost; ta.rowsPerSeg = std::min(R, (int)a.nD); ta.segs = (int32_t)segs; }
+  }
+  ta.nTasks = ta.nCpi * ta.segs * ta.strips;
+  cfar2d_dead_rows(h, a.minDoppler, &ta.deadLo, &ta.deadHi);
+  const int grid = (((ta.nTasks + 3) / 4) + 7) & ~7;
+#define B2_X(TD, GD, TF, GF) \
+  if (a.ntD == TD && a.ngD == GD && a.ntF == TF && a.ngF == GF) { \
+    hipLaunchKernelGGL((cfar2d_stream_kernel<TD, GD, TF, GF>), dim3(grid), dim3(256), 0, st, ta); \
+    return; \
+  }
+  C2S_SHAPES(B2_X)
+#undef B2_X
+}
+
 int ensure_sat(blah2hip_amb_s *h)
 {
   if (h->d_sat) return BLAH2HIP_OK;
@@ -783,7 +838,7 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
     h->rangeKernel = (int)value;
     return BLAH2HIP_OK;
   case BLAH2HIP_OPT_CFAR2D_KERNEL:
-    if (value < BLAH2HIP_CFAR2D_AUTO || value > BLAH2HIP_CFAR2D_SAT) return fail(BLAH2HIP_ERR_INVALID, "2-D detector: AUTO, TILE or SAT");
+    if (value < BLAH2HIP_CFAR2D_AUTO || value > BLAH2HIP_CFAR2D_STREAM) return fail(BLAH2HIP_ERR_INVALID, "2-D detector: AUTO, TILE, SAT or STREAM");
     h->cfar2dForce = (int)value;
     return BLAH2HIP_OK;
   case BLAH2HIP_OPT_DOPPLER_GRID:
@@ -1288,7 +1343,9 @@ int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
   int rc;
   if (h->cfar2dForce == BLAH2HIP_CFAR2D_TILE && !cfar2d_use_tile(h, ngd, ntd, ngf, ntf))
     return fail(BLAH2HIP_ERR_UNSUPPORTED, "2-D window beyond the tile kernel's halo (nGf + nTf <= 24, nGd + nTd <= 40)");
-  if (!cfar2d_use_tile(h, ngd, ntd, ngf, ntf) && (rc = ensure_sat(h))) return rc; // no-op once allocated
+  if (h->cfar2dForce == BLAH2HIP_CFAR2D_STREAM && !cfar2d_stream_shape(ngd, ntd, ngf, ntf))
+    return fail(BLAH2HIP_ERR_UNSUPPORTED, "the stream kernel is not instantiated for this 2-D window (C2S_SHAPES in cfar_kernels.hpp)");
+  if (!cfar2d_use_stream(h, ngd, ntd, ngf, ntf, min_doppler) && !cfar2d_use_tile(h, ngd, ntd, ngf, ntf) && (rc = ensure_sat(h))) return rc; // no-op once allocated
   const double *d_alpha = nullptr;
   if ((rc = alpha_table(h, pfa, (size_t)(2 * (ngd + ntd) + 1) * (2 * (ngf + ntf) + 1), &d_alpha, st))) return rc;
   HIPCHK(hipMemsetAsync(d_count, 0, n_cpi * sizeof(uint32_t), st));
@@ -1304,6 +1361,13 @@ int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
   a.ngD = ngd; a.ntD = ntd; a.ngF = ngf; a.ntF = ntf; a.minDelay = min_delay;
   a.minDoppler = min_doppler;
   a.cap = cap;
+  if (cfar2d_use_stream(h, ngd, ntd, ngf, ntf, min_doppler)) {
+    if ((rc = tic(h, BLAH2HIP_K_CFAR, st))) return rc;
+    cfar2d_stream_launch(h, a, n_cpi, st);
+    HIPCHK(hipGetLastError());
+    if ((rc = toc(h, BLAH2HIP_K_CFAR, st))) return rc;
+    return BLAH2HIP_OK;
+  }
   if (cfar2d_use_tile(h, ngd, ntd, ngf, ntf)) {
     Cfar2dTileArgs ta;
     ta.d = a;
@@ -1363,7 +1427,9 @@ int blah2hip_cfar2d_prepare(blah2hip_amb_t h, double pfa, int32_t ngd, int32_t n
   int rc;
   if (h->cfar2dForce == BLAH2HIP_CFAR2D_TILE && !cfar2d_use_tile(h, ngd, ntd, ngf, ntf))
     return fail(BLAH2HIP_ERR_UNSUPPORTED, "2-D window beyond the tile kernel's halo (nGf + nTf <= 24, nGd + nTd <= 40)");
-  if (!cfar2d_use_tile(h, ngd, ntd, ngf, ntf) && (rc = ensure_sat(h))) return rc;
+  if (h->cfar2dForce == BLAH2HIP_CFAR2D_STREAM && !cfar2d_stream_shape(ngd, ntd, ngf, ntf))
+    return fail(BLAH2HIP_ERR_UNSUPPORTED, "the stream kernel is not instantiated for this 2-D window (C2S_SHAPES in cfar_kernels.hpp)");
+  if (!cfar2d_use_stream(h, ngd, ntd, ngf, ntf, 0.0) && !cfar2d_use_tile(h, ngd, ntd, ngf, ntf) && (rc = ensure_sat(h))) return rc;
   const double *d = nullptr;
   return alpha_table(h, pfa, (size_t)(2 * (ngd + ntd) + 1) * (2 * (ngf + ntf) + 1), &d, nullptr, true);
 }

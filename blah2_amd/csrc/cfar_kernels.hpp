@@ -2,6 +2,7 @@
 //
 //   cfar1d_kernel                  CfarDetector1D::process            CfarDetector1D.cpp:23-100
 //   cfar2d_tile_kernel             2-D CA-CFAR (BASELINE configs[2]; extension): one read of the map
+//   cfar2d_stream_kernel           the same in one pass without LDS arrays: a wave per strip of columns walks down the rows
 //   sat_rows / sat_cols / cfar2d   the same detector through a summed-area table (windows beyond the tile kernel's halo)
 //
 // All paths are relative to /root/reference/src.
@@ -487,5 +488,207 @@ __global__ __launch_bounds__(64 * C2T_WAVES) void cfar2d_tile_kernel(Cfar2dTileA
   if (lane == 0) trace_finish("c2t", tr, blockIdx.x == 0 && threadIdx.x == 0);
 #endif
 }
+
+// --------------------------------------------------------------------------
+// The one-pass detector as a STREAM, without LDS arrays and without barriers (round 4; the default for the window
+// shapes instantiated in C2S_SHAPES, the tile kernel above takes the others).  A WAVE owns a strip of 64 - 2 hC
+// output columns (lane <-> column, hC halo lanes on either side) and walks down a segment of Doppler rows, one
+// 512-byte row piece per step, U row pieces requested ahead.  Per row and lane, everything in fp64 and ADDITIVE
+// (no running differences) like in the tile kernel:
+//   along the row (across lanes, ds_bpermute shifts: the LDS crossbar, no LDS memory): run sums of 1, 2, 4, ...
+//   columns by doubling (P[b+1](j) = P[b](j) + P[b](j + 2^b)); the nTd training columns of one side are the set
+//   bits of nTd (TS), the other side is the same sum shifted; likewise the 2 nGd + 1 guard columns:
+//     A(r, j) = TS(j - hC) + TS(j + nGd + 1)         training columns of row r
+//     B(r, j) = A + the guard columns                 the whole window of row r
+//   down the column (in registers, a ring per quantity whose slots are compile-time after unrolling U rows):
+//     TB(r) = B(r) + ... + B(r - nTf + 1),  TA(r) = A(r) + ... + A(r - 2 nGf)
+//     tot(i = r - hR) = TB(r) + TA(r - nTf) + TB(r - nTf - 2 nGf - 1)
+//   (the block of nTf rows is summed once and used twice, like TS): 7 shifts and 12 additions per cell for the
+//   17 x 9 window, where the tile kernel makes 26 additions out of LDS.
+// The cell under test is the lane's own |z|^2 of hR rows ago; n, alpha[n] and the test are the tile kernel's
+// (sq n > alpha tot; n = 0 -> alpha = NaN -> never).  n depends on the row only through the clipped row counts,
+// which are wave-uniform: alpha[n] is fetched when they change (the first and last hR rows of the map).
+// Four waves (four neighbouring strips) share a workgroup only for the halo columns' sake (one L1); workgroups
+// are laid out so that an XCD walks a contiguous range of strips and segments (neighbours' halos in its L2).
+// What bounds it: VALU issue (about 20 fp64 instructions per row and wave) and the 14 bpermutes.
+#ifndef C2S_V
+#define C2S_V 2 /* rows whose shifts along the row are in flight together (tools/ builds other values for comparison) */
+#endif
+// ring length: a whole number of blocks of C2S_V rows that holds a block and the nTf + 2 nGf + 1 rows behind it
+constexpr int c2s_ring(int ntf, int ngf) { return (C2S_V + ntf + 2 * ngf + 1 + C2S_V - 1) / C2S_V * C2S_V; }
+constexpr int C2S_PITCH = 64 + 32;
+// what the lanes of this wave wrote to LDS is visible to its other lanes (no instruction: DS operations of a wave execute in
+// order; the fences keep the compiler from moving, merging or forwarding the accesses across this point)
+// one ds_read_b64 (2 cycles of the CU's LDS on gfx950; as plain loads the compiler pairs them into ds_read2_b64: 8 cycles)
+#define C2S_LD(P) __hip_atomic_load((P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
+#define C2S_LANES_SEE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+struct Cfar2dStreamArgs {
+  Cfar2dArgs d;
+  int32_t nCpi, strips, segs, rowsPerSeg, nTasks;
+  int32_t deadLo, deadHi; // the rows [deadLo, deadHi) are not tested: |doppler| < minDoppler there and nowhere else (CfarDetector1D.cpp:40)
+};
+
+template <int NTD, int NGD, int NTF, int NGF>
+__global__ __launch_bounds__(256) void cfar2d_stream_kernel(Cfar2dStreamArgs ta)
+{
+  const Cfar2dArgs &a = ta.d;
+  constexpr int HC = NTD + NGD, HR = NTF + NGF, OUTW = 64 - 2 * HC;
+  constexpr int GW = 2 * NGD + 1, GH = 2 * NGF + 1;
+  constexpr int V = C2S_V, U = c2s_ring(NTF, NGF); // U: ring length = rows per round of the unrolled loop = row pieces requested ahead
+  static_assert(OUTW >= 16 && HC + 1 <= 16, "window too wide for a one-wave strip");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // the threshold table in LDS: read when the clipped row counts change, and an LDS read does not wait for the row pieces in flight
+  constexpr int NALPHA = (2 * HC + 1) * (2 * HR + 1) + 1;
+  __shared__ double alphaL[NALPHA];
+  for (int e = threadIdx.x; e < NALPHA; e += 256) alphaL[e] = a.alpha[e];
+  __syncthreads();
+  const int chunk = gridDim.x >> 3; // gridDim.x is a multiple of 8: XCD x walks workgroups [x chunk, (x + 1) chunk)
+  const int task = (((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3)) * 4 + wave;
+  if (task >= ta.nTasks) return;
+  __shared__ double rowL[4][C2S_V][2][C2S_PITCH]; // per wave and row in flight: |z|^2 and the pair sums, a pad of 16 on either side
+  double *lds1 = &rowL[wave][0][0][16 + lane];
+  const int perCpi = ta.segs * ta.strips;
+  const int cpi = task / perCpi, rem = task - cpi * perCpi;
+  const int seg = rem / ta.strips, strip = rem - seg * ta.strips;
+  const int nD = a.nD, nC = a.nDelay;
+  const int i0 = seg * ta.rowsPerSeg, i1 = min(i0 + ta.rowsPerSeg, nD);
+  const int j = strip * OUTW - HC + lane;
+  const int voff = j * 8;
+  // per-lane constants: the clipped column counts of the cell this lane tests (0: it tests none)
+  auto clampi = [](int v_, int lo, int hi) { return v_ < lo ? lo : (v_ > hi ? hi : v_); };
+  auto cols = [](int c0_, int c1_) { return max(c1_, 1) - max(c0_, 1); }; // column 0 never trains (CfarDetector1D.cpp:61)
+  const bool jok = lane >= HC && lane < 64 - HC && j < nC && j + a.delayMin >= a.minDelay; // CfarDetector1D.cpp:53
+  const int nColsAll = jok ? cols(clampi(j - HC, 0, nC), clampi(j + HC + 1, 0, nC)) : 0;
+  const int nColsGuard = jok ? cols(clampi(j - NGD, 0, nC), clampi(j + NGD + 1, 0, nC)) : 0;
+  const bool isCol0 = j == 0;
+  const cf *mapc = a.map + (size_t)cpi * nD * nC;
+
+  const int rStart = i0 - HR, rLast = i1 - 1 + HR; // rows streamed; row r completes output row r - HR
+  c2t_v2u pf[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int r = rStart + u;
+    const bool rok = r >= 0 && r < nD && r <= rLast;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(mapc + (size_t)(rok ? r : 0) * nC), (short)0, rok ? nC * 8 : 0, 0x00020000);
+    pf[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+  }
+  double Bh[U], Ah[U], TBh[U], TAh[U], sqh[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) Bh[u] = Ah[u] = TBh[u] = TAh[u] = sqh[u] = 0.0;
+  int keyA = -1, keyG = -1;
+  double nf = 0.0, al = 0.0;
+
+  // The only vector-memory operations of the loop are the row pieces: any other load would have to be waited for with
+  // everything requested before it (loads return in order), i.e. with the whole ring.
+  for (int rb = rStart; rb <= rLast; rb += U) {
+    uint32_t hitRows = 0;
+#pragma unroll
+    for (int ub = 0; ub < U; ub += V) {
+      // ---- along the row, V rows side by side.  The lane's |z|^2 and its sum with the right neighbour's go to the wave's own
+      // piece of LDS (ds_write_b64), the neighbours' come back through ds_read_b64 at immediate offsets: on gfx950 a 64-lane
+      // ds_read_b64 takes 2 cycles of the CU's LDS, a ds_bpermute_b32 six (tools/membench/ldsrate.hip) -- the first version
+      // of this kernel shifted registers through 14 bpermutes per row and was bound by exactly those.  Lanes of one wave
+      // only: no barrier, DS operations of a wave execute in order.  Lanes outside [hC, 64 - hC) read the pads (anything):
+      // they test nothing.
+      double s1[V];
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        const int u = ub + v;
+        const double x = (double)__uint_as_float(pf[u].x), y = (double)__uint_as_float(pf[u].y);
+        const double sq = x * x + y * y;
+        {
+          const int rn = rb + u + U;
+          const bool rok = rn >= 0 && rn < nD && rn <= rLast;
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(mapc + (size_t)(rok ? rn : 0) * nC), (short)0, rok ? nC * 8 : 0, 0x00020000);
+          pf[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+        }
+        sqh[u] = sq;
+        s1[v] = isCol0 ? 0.0 : sq;
+        lds1[v * 2 * C2S_PITCH] = s1[v];
+      }
+      C2S_LANES_SEE();
+#pragma unroll
+      for (int v = 0; v < V; v++) lds1[(v * 2 + 1) * C2S_PITCH] = s1[v] + C2S_LD(lds1 + v * 2 * C2S_PITCH + 1);
+      C2S_LANES_SEE();
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        const int u = ub + v;
+        const double *p1 = lds1 + v * 2 * C2S_PITCH, *p2 = p1 + C2S_PITCH;
+        double A = 0.0, G = C2S_LD(p1 - NGD);
+#pragma unroll
+        for (int m = 0; m < NGD; m++) G += C2S_LD(p2 - NGD + 1 + 2 * m); // the 2 nGd + 1 guard columns: one cell and nGd pairs
+        if (NTD > 0) {
+          double L = 0.0, R = 0.0;                                       // nTd columns left and right of them: pairs (and one cell if nTd is odd)
+#pragma unroll
+          for (int m = 0; m < NTD / 2; m++) {
+            const double l = C2S_LD(p2 - HC + 2 * m), r = C2S_LD(p2 + NGD + 1 + 2 * m);
+            L = m ? L + l : l;
+            R = m ? R + r : r;
+          }
+          if (NTD & 1) {
+            const double l = C2S_LD(p1 - NGD - 1), r = C2S_LD(p1 + HC);
+            L = NTD > 1 ? L + l : l;
+            R = NTD > 1 ? R + r : r;
+          }
+          A = L + R;
+        }
+        Bh[u] = A + G; Ah[u] = A;
+      }
+      // ---- down the column, and the tests
+#pragma unroll
+      for (int u = ub; u < ub + V; u++) {
+        double TB = 0.0, TA = Ah[u];
+        if (NTF > 0) {
+          TB = Bh[u];
+#pragma unroll
+          for (int k = 1; k < NTF; k++) TB += Bh[(u - k + 8 * U) % U];
+        }
+#pragma unroll
+        for (int k = 1; k < GH; k++) TA += Ah[(u - k + 8 * U) % U];
+        TBh[u] = TB; TAh[u] = TA;
+        double tot = TAh[(u - NTF + 8 * U) % U];
+        if (NTF > 0) tot = (TB + tot) + TBh[(u - NTF - GH + 8 * U) % U];
+        const double cut = sqh[(u - HR + 8 * U) % U];
+        // the test of output row i (wave-uniform: is the row tested at all, and with which row counts)
+        const int i = rb + u - HR;
+        if (i >= i0 && i < i1 && (i < ta.deadLo || i >= ta.deadHi)) {
+          const int rA = min(i + HR + 1, nD) - max(i - HR, 0), rG = min(i + NGF + 1, nD) - max(i - NGF, 0);
+          if (rA != keyA || rG != keyG) {
+            keyA = rA; keyG = rG;
+            const int nn = rA * nColsAll - rG * nColsGuard; // >= 0: the guard box lies inside the window
+            nf = (double)nn;
+            al = alphaL[nn];
+          }
+          hitRows |= (cut * nf > al * tot) ? (1u << u) : 0u;
+        }
+      }
+    }
+    // the (rare) hits of these U rows, in one place: the cell is read again, its |z|^2 is the same arithmetic
+    if (hitRows) {
+      for (int u = 0; u < U; u++) {
+        if (!((hitRows >> u) & 1u)) continue;
+        const int i = rb + u - HR;
+        const cf c = mapc[(size_t)i * nC + j];
+        const double cut = (double)c.x * (double)c.x + (double)c.y * (double)c.y;
+        const uint32_t slot = atomicAdd(&a.count[cpi], 1u);
+        if (slot < a.cap) {
+          blah2hip_hit_t h;
+          h.row = i;
+          h.col = j;
+          h.snr = 5.0 * log10(cut) - a.metrics[2 * cpi];
+          a.hits[(size_t)cpi * a.cap + slot] = h;
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) HERE: left pending, the store would turn every wait of the loop into vmcnt(0)
+    }
+  }
+}
+
+// the window shapes (nTd, nGd, nTf, nGf) the stream kernel is instantiated for; one line per shape
+#define C2S_SHAPES(X) \
+  X(6, 2, 3, 1) /* config.yml:36-40 along delay + Doppler guard 1 / train 3: the bench's 17 x 9 window */ \
+  X(6, 2, 0, 0) X(8, 2, 4, 1) X(4, 1, 2, 1) X(3, 1, 2, 1) X(1, 0, 0, 0) X(0, 0, 1, 0) X(2, 0, 1, 0) X(5, 2, 6, 2)
 
 } // namespace blah2

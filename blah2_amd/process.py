@@ -217,7 +217,7 @@ class Ambiguity:
     def set_cfar2d_kernel(self, which):
         """'auto' / 'tile' (one pass over the map) / 'sat' (summed-area table) for :class:`CfarDetector2D`."""
         if isinstance(which, str):
-            which = {"auto": _lib.CFAR2D_AUTO, "tile": _lib.CFAR2D_TILE, "sat": _lib.CFAR2D_SAT}[which]
+            which = {"auto": _lib.CFAR2D_AUTO, "tile": _lib.CFAR2D_TILE, "sat": _lib.CFAR2D_SAT, "stream": _lib.CFAR2D_STREAM}[which]
         check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_CFAR2D_KERNEL, int(which)))
 
     def set_fft_len(self, F):

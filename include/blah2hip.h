@@ -137,11 +137,14 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 #define BLAH2HIP_OPT_FFT_LEN 5        /* range transform length F in {1024, 2048, 4096}; 0 = the planner's choice (cost model).  Re-plans the
                                        * segmentation and re-uploads the root table (blocking); BLAH2HIP_ERR_UNSUPPORTED when the lag window
                                        * does not fit F.  Replaces the BLAH2HIP_FFT_LEN environment variable of earlier versions */
-#define BLAH2HIP_OPT_CFAR2D_KERNEL 6  /* 2-D detector: BLAH2HIP_CFAR2D_AUTO (the one-pass tile kernel when nGf + nTf <= 24 and nGd + nTd <= 40,
-                                       * else the summed-area table), _TILE (BLAH2HIP_ERR_UNSUPPORTED at the call for larger windows) or _SAT */
+#define BLAH2HIP_OPT_CFAR2D_KERNEL 6  /* 2-D detector: BLAH2HIP_CFAR2D_AUTO (the one-pass stream kernel for the window shapes it is instantiated
+                                       * for -- C2S_SHAPES in csrc/cfar_kernels.hpp, among them config.yml's 2 / 6 along delay with 1 / 3 along
+                                       * Doppler --, the one-pass tile kernel for other windows with nGf + nTf <= 24 and nGd + nTd <= 40, else the
+                                       * summed-area table), _STREAM / _TILE (BLAH2HIP_ERR_UNSUPPORTED at the call for other windows) or _SAT */
 #define BLAH2HIP_CFAR2D_AUTO 0
 #define BLAH2HIP_CFAR2D_TILE 1
 #define BLAH2HIP_CFAR2D_SAT 2
+#define BLAH2HIP_CFAR2D_STREAM 3
 #define BLAH2HIP_DOP_AUTO 0
 #define BLAH2HIP_DOP_TILE8 1   /* nD <= 513: 8-column tiles, one wave per column */
 #define BLAH2HIP_DOP_TILE16 2  /* nD <= 513: 16-column tiles, one wave per column on the one-wave 1024-point transform */

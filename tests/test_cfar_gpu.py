@@ -91,6 +91,8 @@ def test_cfar_parameters_are_int8_like_the_reference(b2):
 
 
 # ---- 2-D CA-CFAR (BASELINE configs[2]; defined in SURVEY.md 8g, oracle cfar2d) ----
+# (nGd, nTd, nGf, nTf) the stream kernel is instantiated for: C2S_SHAPES in csrc/cfar_kernels.hpp, there as (nTd, nGd, nTf, nGf)
+STREAM_SHAPES = {(2, 6, 1, 3), (2, 6, 0, 0), (2, 8, 1, 4), (1, 4, 1, 2), (1, 3, 1, 2), (0, 1, 0, 0), (0, 0, 0, 1), (0, 2, 0, 1), (2, 5, 2, 6)}
 def check_2d(b2, amb, m, m_ref, noise, params):
     pfa, ngd, ntd, ngf, ntf, md, mdop = params
     det = b2.CfarDetector2D(pfa, ngd, ntd, ngf, ntf, md, mdop).process(m)
@@ -146,36 +148,44 @@ def test_cfar2d_reduces_to_1d(b2):
     (1e-2, 1, 3, 1, 2, -10, 0.0),
 ])
 def test_cfar2d_tile_kernel_equals_sat_kernel(b2, params):
-    """Forced kernels on the same device map: identical detection sets (both sum the same fp64 squares;
-    only the summation order differs), on a 201 x 111 map whose tiles are ragged in both directions."""
+    """Forced kernels on the same device map: identical detection sets (all sum the same fp64 squares;
+    only the summation order differs), on a 201 x 111 map whose tiles, strips and row segments are ragged in both
+    directions.  The stream kernel takes part for the window shapes it is instantiated for and refuses the others."""
     g = load_golden("medium")
     fs, n, dmin, dmax, fmin, fmax, rh = (int(v) for v in g["params"])
     amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, bool(rh))
     m = amb.process(g["x"], g["y"])
     out = {}
-    for which in ("tile", "sat"):
+    for which in ("tile", "sat", "stream"):
         amb.set_cfar2d_kernel(which)
+        if which == "stream" and tuple(params[1:5]) not in STREAM_SHAPES:
+            with pytest.raises(b2.Blah2HipError):
+                b2.CfarDetector2D(*params).process(m)
+            continue
         d = b2.CfarDetector2D(*params).process(m)
         out[which] = {(a, b): s for a, b, s in zip(d.get_delay(), d.get_doppler(), d.get_snr())}
+    assert ("stream" in out) == (tuple(params[1:5]) in STREAM_SHAPES)
     got = m.data.astype(np.complex128)
     _, _, _, margin = O.cfar2d(got, amb.delay, amb.doppler, m.noisePower, *params, return_margin=True)
     row = {f: i for i, f in enumerate(amb.doppler)}
-    for key in set(out["tile"]) ^ set(out["sat"]):
-        i, j = row[key[1]], int(key[0] - amb.delay[0])
-        assert abs(margin[i, j] - 1) < 1e-9, (key, margin[i, j])
-    for key in set(out["tile"]) & set(out["sat"]):
-        assert out["tile"][key] == out["sat"][key]
+    for which in out:
+        for key in set(out[which]) ^ set(out["sat"]):
+            i, j = row[key[1]], int(key[0] - amb.delay[0])
+            assert abs(margin[i, j] - 1) < 1e-9, (which, key, margin[i, j])
+        for key in set(out[which]) & set(out["sat"]):
+            assert out[which][key] == out["sat"][key]
     assert len(out["tile"]) > 0
 
 
-def test_cfar2d_tile_kernel_vs_bruteforce_oracle(b2):
+@pytest.mark.parametrize("which", ["tile", "stream"])
+def test_cfar2d_tile_kernel_vs_bruteforce_oracle(b2, which):
     """The literal four-loop definition (oracle cfar2d_bruteforce) on the device's own small map, incl. delay
     column 0 as a test cell (it never trains) and every clipped-window case."""
     g = load_golden("small_sym")
     fs, n, dmin, dmax, fmin, fmax, rh = (int(v) for v in g["params"])
     amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, bool(rh))
     m = amb.process(g["x"], g["y"])
-    amb.set_cfar2d_kernel("tile")
+    amb.set_cfar2d_kernel(which)
     got = m.data.astype(np.complex128)
     for params in [(1e-2, 1, 3, 1, 2, -100, 0.0), (0.2, 0, 2, 0, 1, -100, 0.0), (1e-3, 2, 5, 2, 6, 0, 0.0)]:
         d = b2.CfarDetector2D(*params).process(m)

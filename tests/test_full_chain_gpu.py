@@ -199,9 +199,11 @@ def test_cfar2d_on_the_cfg3_map_without_filter(b2, cfg3_data):
     m_ref = O.ambiguity_process(d, x, y)
     noise_ref, _ = O.map_metrics(m_ref)
     for name, detector, oracle, params in [
-            ("2-D", b2.CfarDetector2D, O.cfar2d, (1e-6, 2, 6, 1, 3, 5, 15.0)),
-            ("2-D wide", b2.CfarDetector2D, O.cfar2d, (1e-4, 4, 16, 2, 8, -24, 0.0)),
+            ("2-D stream", b2.CfarDetector2D, O.cfar2d, (1e-6, 2, 6, 1, 3, 5, 15.0)),  # the planner's choice for this window
+            ("2-D tile", b2.CfarDetector2D, O.cfar2d, (1e-6, 2, 6, 1, 3, 5, 15.0)),
+            ("2-D wide", b2.CfarDetector2D, O.cfar2d, (1e-4, 4, 16, 2, 8, -24, 0.0)),    # not instantiated: tile kernel
     ]:
+        amb.set_cfar2d_kernel(name.split()[1] if name.split()[1] in ("stream", "tile") else "auto")
         det = detector(*params).process(m)
         got_set = set(zip(det.get_delay(), det.get_doppler()))
         dl, dp, _, mg_own = oracle(got, d.delay, d.doppler, m.noisePower, *params, return_margin=True)
