@@ -474,7 +474,7 @@ def main(argv=None):
     ran_range = {1: "range_kernel", 2: "range8_kernel", 3: "rangew_kernel", 5: "rangew1k_kernel", 6: "rangeps_kernel"}.get(
         amb.info(blah2_amd._lib.INFO_LAST_RANGE_KERNEL), "range_kernel")
     prof_names = {"range": (ran_range,), "doppler": ("doppler_",),  # the range kernel this run launched, no other
-                  "metrics": ("metrics_kernel",), "cfar": ("cfar2d_tile_kernel", "cfar2d_kernel", "cfar1d_kernel"),
+                  "metrics": ("metrics_kernel",), "cfar": ("cfar2d_stream_kernel", "cfar2d_tile_kernel", "cfar2d_kernel", "cfar1d_kernel"),
                   "sat_rows": ("sat_rows_kernel",), "sat_cols": ("sat_cols_kernel",), "rotate": ("rotate_kernel",),
                   "clutter_corr": ("clutter_corr_half_kernel", "clutter_corr_kernel"), "clutter_fir": ("clutter_fir_kernel",),
                   "clutter_solve": ("clutter_solve_kernel",), "clutter_reduce": ("clutter_reduce_kernel",)}

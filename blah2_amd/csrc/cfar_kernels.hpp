@@ -511,6 +511,9 @@ __global__ __launch_bounds__(64 * C2T_WAVES) void cfar2d_tile_kernel(Cfar2dTileA
 // Four waves (four neighbouring strips) share a workgroup only for the halo columns' sake (one L1); workgroups
 // are laid out so that an XCD walks a contiguous range of strips and segments (neighbours' halos in its L2).
 // What bounds it: VALU issue (about 20 fp64 instructions per row and wave) and the 14 bpermutes.
+#ifndef C2S_ABLATE
+#define C2S_ABLATE 0 /* tools/ only: 1 = every row piece is the segment's first (cache hits), 2 = no sums along the row */
+#endif
 #ifndef C2S_V
 #define C2S_V 2 /* rows whose shifts along the row are in flight together (tools/ builds other values for comparison) */
 #endif
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(256) void cfar2d_stream_kernel(Cfar2dStreamArgs ta)
         const double x = (double)__uint_as_float(pf[u].x), y = (double)__uint_as_float(pf[u].y);
         const double sq = x * x + y * y;
         {
-          const int rn = rb + u + U;
+          const int rn = (C2S_ABLATE & 1) ? max(rStart, 0) : rb + u + U;
           const bool rok = rn >= 0 && rn < nD && rn <= rLast;
           const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(mapc + (size_t)(rok ? rn : 0) * nC), (short)0, rok ? nC * 8 : 0, 0x00020000);
           pf[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
@@ -608,6 +611,10 @@ __global__ __launch_bounds__(256) void cfar2d_stream_kernel(Cfar2dStreamArgs ta)
         s1[v] = isCol0 ? 0.0 : sq;
         lds1[v * 2 * C2S_PITCH] = s1[v];
       }
+#if C2S_ABLATE & 2
+#pragma unroll
+      for (int v = 0; v < V; v++) { Bh[ub + v] = s1[v] * 3.0; Ah[ub + v] = s1[v]; }
+#else
       C2S_LANES_SEE();
 #pragma unroll
       for (int v = 0; v < V; v++) lds1[(v * 2 + 1) * C2S_PITCH] = s1[v] + C2S_LD(lds1 + v * 2 * C2S_PITCH + 1);
@@ -636,6 +643,7 @@ __global__ __launch_bounds__(256) void cfar2d_stream_kernel(Cfar2dStreamArgs ta)
         }
         Bh[u] = A + G; Ah[u] = A;
       }
+#endif
       // ---- down the column, and the tests
 #pragma unroll
       for (int u = ub; u < ub + V; u++) {

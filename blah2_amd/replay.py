@@ -18,9 +18,11 @@ output streams while the capture is still being processed and every rank
 holds one round of results at most.
 
 On a rank the batches flow through a pipeline (:class:`GpuChain`): reader
-threads fill a ring of pinned host buffers straight from the file (pread), a
-copy stream uploads batch k+1 and brings back the results of batch k-1 while
-the kernels of batch k run on the compute stream; HIP events order the three.
+threads copy the next batch out of the memory-mapped file into a ring of pinned
+host buffers (or, ``read_mode="mapped"``, only register its pages with the
+device: no CPU copy), a copy stream uploads batch k+1 and brings back the
+results of batch k-1 while the kernels of batch k run on the compute stream;
+HIP events order the three.
 At 16 MB of int16 per 1 s CPI the GPU needs 9 us for what PCIe needs 290 us to
 deliver: a replay is bound by the host link, and the pipeline's job is to keep
 that link busy (tools/replay_bench.py measures both).
@@ -31,6 +33,7 @@ which has no GPU dependency -- any callable ``(int16 array [B, nSamples, 4])
 """
 from __future__ import annotations
 
+import ctypes as C
 import json
 import os
 import time
@@ -42,6 +45,10 @@ from typing import Callable, Iterator, List, Optional, Tuple
 import numpy as np
 
 BYTES_PER_SAMPLE = 8  # int16 I1 Q1 I2 Q2
+PAGE = 4096
+_MADV_POPULATE_READ = 22  # Linux 5.14+
+_LIBC = C.CDLL(None, use_errno=True)
+_LIBC.madvise.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
 
 
 class RspduoFile:
@@ -64,23 +71,37 @@ class RspduoFile:
     def batch(self, ks) -> np.ndarray:
         return np.stack([self.cpi(k) for k in ks]) if len(ks) else np.zeros((0, self.n_samples, 4), dtype=np.int16)
 
-    def read_into(self, k0: int, count: int, dst: np.ndarray, pool: Optional[ThreadPoolExecutor] = None, parts: int = 8):
+    def read_into(self, k0: int, count: int, dst: np.ndarray, pool: Optional[ThreadPoolExecutor] = None, parts: int = 8,
+                  how: str = "memmove"):
         """CPIs k0 .. k0+count-1 (contiguous in the file) into the first bytes of ``dst`` (any writable buffer, e.g. a
-        pinned one) with pread, split over ``pool``'s threads: a page-cache copy runs at ~10 GB/s per thread, PCIe
-        takes 50+."""
-        if self._fd is None:
-            self._fd = os.open(self.path, os.O_RDONLY)
+        pinned one), split over ``pool``'s threads.  ``how="memmove"``: out of the shared mapping -- each thread has the
+        kernel fill the page tables of its piece (madvise MADV_POPULATE_READ: 47 GB/s per thread, against a fault per 64 KB)
+        and copies it with memmove (non-temporal stores for large sizes): 12.5 GB/s per thread on the MI355X host;
+        ``how="pread"``: the kernel's copy_to_user, 9.5 GB/s per thread.  PCIe takes 57."""
         nbytes = count * self.n_samples * BYTES_PER_SAMPLE
         off0 = k0 * self.n_samples * BYTES_PER_SAMPLE
-        mv = memoryview(dst).cast("B")[:nbytes]
+        if how == "pread":
+            if self._fd is None:
+                self._fd = os.open(self.path, os.O_RDONLY)
+            mv = memoryview(dst).cast("B")[:nbytes]
 
-        def rd(a, b):
-            pos = a
-            while pos < b:
-                got = os.preadv(self._fd, [mv[pos:b]], off0 + pos)
-                if got <= 0:
-                    raise IOError(f"short read from {self.path} at {off0 + pos}")
-                pos += got
+            def rd(a, b):
+                pos = a
+                while pos < b:
+                    got = os.preadv(self._fd, [mv[pos:b]], off0 + pos)
+                    if got <= 0:
+                        raise IOError(f"short read from {self.path} at {off0 + pos}")
+                    pos += got
+        else:
+            src = self._mm.ctypes.data + off0
+            dstp = dst.ctypes.data
+            if dst.nbytes < nbytes:
+                raise ValueError("destination smaller than the CPIs asked for")
+
+            def rd(a, b):
+                lo = (src + a) // PAGE * PAGE  # madvise wants a page-aligned start; a failure only means the copy faults the pages in
+                _LIBC.madvise(lo, src + b - lo, _MADV_POPULATE_READ)
+                C.memmove(dstp + a, src + a, b - a)
 
         if pool is None or parts <= 1 or nbytes < (1 << 22):
             rd(0, nbytes)
@@ -91,10 +112,39 @@ class RspduoFile:
         for f in futs:
             f.result()
 
+    def window(self, k0: int, count: int) -> Tuple[int, int]:
+        """(address, bytes) of CPIs k0 .. k0+count-1 inside the read-only shared mapping of the file: the page cache's own
+        pages, which the zero-copy read path registers with the device and uploads from (``GpuChain(read_mode="mapped")``)."""
+        nbytes = count * self.n_samples * BYTES_PER_SAMPLE
+        off0 = k0 * self.n_samples * BYTES_PER_SAMPLE
+        return self._mm.ctypes.data + off0, nbytes
+
     def close(self):
         if self._fd is not None:
             os.close(self._fd)
             self._fd = None
+        self._mm = np.zeros(0, dtype="<i2")  # the mapping goes with its last reference (anything registered of it must be released first)
+
+
+def page_split(addr: int, nbytes: int, parts: int, page: int = PAGE):
+    """The byte range [addr, addr + nbytes) as (head, [whole-page pieces], tail): ``head`` and ``tail`` are the ragged
+    ends (offset, length) relative to ``addr`` that do not fill a page, the pieces are at most ``parts`` page-aligned
+    (offset, length) runs between them.  The pieces are what gets registered with the device (two neighbouring
+    batches never share a page that way); the ends, under a page each, travel through a small pinned buffer."""
+    end = addr + nbytes
+    lo = min(-(-addr // page) * page, end)
+    hi = max(end // page * page, lo)
+    head = (0, lo - addr)
+    tail = (hi - addr, end - hi)
+    pieces = []
+    pages = (hi - lo) // page
+    if pages > 0:
+        parts = max(1, min(int(parts), pages))
+        per = -(-pages // parts)
+        for k in range(0, pages, per):
+            cnt = min(per, pages - k)
+            pieces.append((lo - addr + k * page, cnt * page))
+    return head, pieces, tail
 
 
 def shard_cpis(n_cpis: int, rank: int, world: int) -> List[int]:
@@ -223,6 +273,21 @@ def n_batches_hint(n: int, batch: int) -> int:
     return -(-n // batch) if n else 0
 
 
+def _hip_runtime(torch):
+    """libamdhip64 of the running torch, for hipHostRegister / hipHostUnregister / hipMemcpyAsync on raw addresses (torch
+    has no tensor over read-only memory); None if it cannot be loaded."""
+    try:
+        hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+        hip.hipHostUnregister.argtypes = [C.c_void_p]
+        hip.hipSetDevice.argtypes = [C.c_int]
+        hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        hip.hipGetErrorString.restype = C.c_char_p
+        return hip
+    except OSError:
+        return None
+
+
 class GpuChain:
     """blah2.cpp:268-287 on the HIP engine for batches of CPIs, device resident from the int16 upload to the hit lists:
     clutter filter (optional; reads the .rspduo words directly) -> ambiguity -> metrics -> CFAR (blah2hip_cfar1d_dev),
@@ -239,7 +304,7 @@ class GpuChain:
     (``if (!filter->process(x, y)) continue;`` blah2.cpp:270-273): its result is ``{"skipped": True}``."""
 
     def __init__(self, cfg: dict, device: int = 0, batch: int = 1, want_map: bool = False, depth: int = 3,
-                 reader_threads: int = 8, hit_copy: int = 4096):
+                 reader_threads: int = 8, hit_copy: int = 4096, read_mode: str = "memmove"):
         import torch
 
         import blah2_amd
@@ -269,12 +334,30 @@ class GpuChain:
         self.copy = torch.cuda.Stream(device=dev)
         self.pool = ThreadPoolExecutor(max_workers=max(1, reader_threads))
         self.reader_threads = max(1, reader_threads)
+        # How a batch gets from the page cache to the copy engine (tools/gpu_hostreg.py, tools/replay_bench.py; MI355X host):
+        #   "memmove"  reader threads copy out of the file's shared mapping into a pinned ring (page tables filled by madvise
+        #              first): 12.5 GB/s per thread, 8 threads saturate the link (57 GB/s); three passes over DRAM
+        #   "pread"    the same through the kernel's copy_to_user: 9.5 GB/s per thread
+        #   "mapped"   no CPU copy and ONE pass over DRAM: the threads only REGISTER whole-page pieces of the mapping with the
+        #              device (hipHostRegister) and the copy engine reads the page cache's own pages.  A third of the host CPU
+        #              time -- but the driver registers 4 KB pages at 17-25 GB/s whatever the thread count (12-15 GB/s with the
+        #              page-table fill of a first pass), so a replay that touches every page once runs at a quarter of the link.
+        #              For captures replayed repeatedly out of a mapping that stays (warm page tables) it reaches 0.90 of it
+        #              with one thread.
+        if read_mode not in ("memmove", "pread", "mapped"):
+            raise ValueError("read_mode: 'memmove', 'pread' or 'mapped'")
+        self.read_mode = read_mode
+        self._hip = _hip_runtime(torch) if read_mode == "mapped" else None
+        if read_mode == "mapped" and self._hip is None:
+            self.read_mode = "memmove"
         # the filtered surveillance channel (one buffer: the compute stream is in order)
         self.yf = torch.empty((B, n), dtype=torch.complex64, device=dev) if self.wh is not None else None
         self.slots = []
         for _ in range(self.depth):
             s = {
-                "h_iq": torch.empty((B, n, 4), dtype=torch.int16).pin_memory(),
+                "h_iq": None,  # pinned staging batch of the pread path, allocated when that path first runs
+                "h_ends": torch.empty(2 * PAGE, dtype=torch.uint8).pin_memory(),  # the ragged ends of a mapped batch
+                "registered": [],
                 "d_iq": torch.empty((B, n, 4), dtype=torch.int16, device=dev),
                 "d_met": torch.zeros((B, 2), dtype=torch.float64, device=dev),
                 "d_ok": torch.ones(B, dtype=torch.int32, device=dev),
@@ -292,12 +375,55 @@ class GpuChain:
 
     # -- the three stages of one batch -------------------------------------------------
     def _read(self, capture: RspduoFile, slot: dict, k0: int, cnt: int):
-        capture.read_into(k0, cnt, slot["h_iq"].numpy(), self.pool, self.reader_threads)
+        slot["mapped"] = None
+        if self.read_mode == "mapped":
+            addr, nbytes = capture.window(k0, cnt)
+            head, pieces, tail = page_split(addr, nbytes, self.reader_threads)
+            hip, dev = self._hip, self.dev.index
+
+            def register(pc):
+                hip.hipSetDevice(dev)  # the pool's threads start on device 0
+                return hip.hipHostRegister(addr + pc[0], pc[1], 0)
+
+            rcs = list(self.pool.map(register, pieces))
+            done = [pc for pc, rc in zip(pieces, rcs) if rc == 0]
+            if len(done) == len(pieces):
+                ends = slot["h_ends"].numpy()
+                for (o, ln), at in ((head, 0), (tail, PAGE)):  # under a page each: a copy
+                    if ln:
+                        C.memmove(ends.ctypes.data + at, addr + o, ln)
+                slot["registered"] = [addr + o for o, _ in pieces]
+                slot["mapped"] = (addr, head, pieces, tail)
+                return
+            for o, _ in done:
+                hip.hipHostUnregister(addr + o)
+            self.read_mode = "memmove"  # this runtime / this file system does not register file mappings
+            print(f"[blah2_amd.replay] hipHostRegister of the mapped capture failed ({hip.hipGetErrorString(max(rcs)).decode()}): "
+                  "copying into a pinned buffer instead", file=sys.stderr)
+        if slot["h_iq"] is None:
+            slot["h_iq"] = self.torch.empty((self.batch, self.n, 4), dtype=self.torch.int16).pin_memory()
+        capture.read_into(k0, cnt, slot["h_iq"].numpy(), self.pool, self.reader_threads, how=self.read_mode)
+
+    def _release(self, slot: dict):
+        """The pieces of the mapping registered for this slot's batch (its upload has completed)."""
+        for p in slot["registered"]:
+            self._hip.hipHostUnregister(p)
+        slot["registered"] = []
 
     def _submit(self, slot: dict, cnt: int):
         torch, b2, n, amb = self.torch, self.b2, self.n, self.amb
         with torch.cuda.stream(self.copy):
-            slot["d_iq"][:cnt].copy_(slot["h_iq"][:cnt], non_blocking=True)
+            if slot["mapped"] is not None:
+                addr, head, pieces, tail = slot["mapped"]
+                dst, st, hip = slot["d_iq"].data_ptr(), self.copy.cuda_stream, self._hip
+                ends = slot["h_ends"].data_ptr()
+                for src, (o, ln) in [(addr + o, (o, ln)) for o, ln in pieces] + [(ends, head), (ends + PAGE, tail)]:
+                    if ln:
+                        rc = hip.hipMemcpyAsync(dst + o, src, ln, 1, st)  # hipMemcpyHostToDevice
+                        if rc:
+                            raise RuntimeError(f"hipMemcpyAsync from the mapped capture: {hip.hipGetErrorString(rc).decode()}")
+            else:
+                slot["d_iq"][:cnt].copy_(slot["h_iq"][:cnt], non_blocking=True)
             slot["uploaded"].record(self.copy)
         with torch.cuda.stream(self.compute):
             self.compute.wait_event(slot["uploaded"])
@@ -328,6 +454,7 @@ class GpuChain:
     def _collect(self, slot: dict, k0: int, cnt: int) -> List[dict]:
         b2, amb = self.b2, self.amb
         slot["downloaded"].synchronize()
+        self._release(slot)
         met_h = slot["h_met"].numpy()
         ok_h = slot["h_ok"].numpy() if self.wh is not None else np.ones(cnt, dtype=np.int32)
         res = []
@@ -374,15 +501,25 @@ class GpuChain:
         """One batch, synchronously, from a host array [B, nSamples, 4] (tests; a caller that has the samples in memory)."""
         cnt = iq.shape[0]
         slot = self.slots[0]
+        if slot["h_iq"] is None:
+            slot["h_iq"] = self.torch.empty((self.batch, self.n, 4), dtype=self.torch.int16).pin_memory()
         slot["h_iq"][:cnt].copy_(self.torch.from_numpy(np.ascontiguousarray(iq)))
+        slot["mapped"] = None
         self._submit(slot, cnt)
         out = self._collect(slot, 0, cnt)
         for r in out:
             r.pop("cpi", None)
         return out
 
+    def release_all(self):
+        """Unregister whatever is still registered (before the capture's mapping goes away)."""
+        self.torch.cuda.synchronize(self.dev)
+        for slot in self.slots:
+            self._release(slot)
+
     def close(self):
         self.pool.shutdown(wait=True)
+        self.release_all()
 
 
 def gpu_processor(cfg: dict, device: int = 0, batch: int = 1, want_map: bool = False, **kw) -> GpuChain:

@@ -117,10 +117,14 @@ def test_read_into_matches_the_memory_map(tmp_path):
     p = str(tmp_path / "a.rspduo")
     a = make_capture(p, 6)
     f = R.RspduoFile(p, N_SAMPLES)
-    dst = np.zeros((4, N_SAMPLES, 4), dtype=np.int16)
-    with ThreadPoolExecutor(3) as pool:
-        f.read_into(1, 3, dst, pool, parts=3)
-    assert np.array_equal(dst[:3].reshape(-1, 4), a[N_SAMPLES:4 * N_SAMPLES]) and not dst[3].any()
+    for how in ("memmove", "pread"):
+        dst = np.zeros((4, N_SAMPLES, 4), dtype=np.int16)
+        with ThreadPoolExecutor(3) as pool:
+            f.read_into(1, 3, dst, pool, parts=3, how=how)
+        assert np.array_equal(dst[:3].reshape(-1, 4), a[N_SAMPLES:4 * N_SAMPLES]) and not dst[3].any()
+        dst[:] = 0
+        f.read_into(2, 1, dst, how=how)  # one piece, no pool
+        assert np.array_equal(dst[0].reshape(-1, 4), a[2 * N_SAMPLES:3 * N_SAMPLES]) and not dst[1:].any()
     f.close()
 
 
@@ -146,6 +150,47 @@ def _stream_worker(rank, world, port, path, n_cpis, batch, out_path):
             assert res is None and not seen
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("addr,nbytes,parts", [
+    (0, 16000000, 4), (16000000, 16000000, 4), (4096 * 7 + 3, 5, 4), (4096 * 7 + 4090, 10, 2), (4096 * 3, 4096 * 5, 8),
+    (4096 * 3 + 1, 4096 * 5, 3), (1000, 0, 4), (8 * 2000000 * 5, 8 * 2000000 * 16, 4), (12345, 4096 * 2 - 1, 1),
+])
+def test_page_split_covers_the_window_once_with_whole_pages(addr, nbytes, parts):
+    """The zero-copy read path registers whole pages of the mapped capture and sends the ragged ends through a small pinned
+    buffer: head + pieces + tail tile [addr, addr + nbytes) exactly, the pieces start and end on page boundaries, the ends
+    stay under a page, and two neighbouring windows never register the same page."""
+    head, pieces, tail = R.page_split(addr, nbytes, parts)
+    runs = [head] + pieces + [tail]
+    pos = 0
+    for o, ln in runs:
+        assert o == pos or ln == 0
+        assert ln >= 0
+        pos = o + ln if ln else pos
+    assert pos == nbytes
+    assert head[1] < R.PAGE and tail[1] < R.PAGE and len(pieces) <= max(parts, 1)
+    for o, ln in pieces:
+        assert (addr + o) % R.PAGE == 0 and ln % R.PAGE == 0 and ln > 0
+    # the next window's pieces start at or after this one's last registered page
+    h2, p2, _ = R.page_split(addr + nbytes, nbytes, parts)
+    if pieces and p2:
+        assert addr + pieces[-1][0] + pieces[-1][1] <= addr + nbytes + p2[0][0]
+
+
+def test_window_is_the_mapped_file(tmp_path):
+    n = 1000
+    rng = np.random.default_rng(3)
+    data = rng.integers(-2048, 2047, (7, n, 4), dtype=np.int16)
+    path = str(tmp_path / "w.rspduo")
+    data.tofile(path)
+    cap = R.RspduoFile(path, n)
+    import ctypes
+    for k0, cnt in [(0, 7), (2, 3), (6, 1)]:
+        addr, nbytes = cap.window(k0, cnt)
+        assert nbytes == cnt * n * 8
+        got = np.frombuffer((ctypes.c_char * nbytes).from_address(addr), dtype=np.int16).reshape(cnt, n, 4)
+        assert np.array_equal(got, data[k0:k0 + cnt])
+    cap.close()
 
 
 def test_two_rank_streaming_gather_gloo(tmp_path):

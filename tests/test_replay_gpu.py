@@ -47,6 +47,38 @@ def test_replay_int16_capture(built_lib, tmp_path):
         assert set(zip(r["delay"], r["doppler"])) == set(zip(g["chain_cfar"][0], g["chain_cfar"][1]))
 
 
+def test_replay_uploads_out_of_the_page_cache(built_lib):
+    """read_mode="mapped": whole pages of the mapped capture are registered with the device and uploaded from,
+    the ragged ends of a batch (the fixture's CPI is not a whole number of pages) through the small pinned buffer; seven
+    CPIs in batches of three leave a ragged last batch too.  Same results as the pinned-ring path, and the mode must have
+    stayed "mapped" (a runtime that refuses the registration falls back to pread -- on /dev/shm it must not)."""
+    import os
+    from blah2_amd import replay as R
+    g = load_golden("medium")
+    n = int(g["params"][1])
+    path = f"/dev/shm/blah2_test_mapped_{os.getpid()}.rspduo"
+    rng = np.random.default_rng(5)
+    cpis = [g["iq"], -g["iq"]] + [np.roll(g["iq"], int(k), axis=0) for k in rng.integers(1, 50, 5)]
+    np.concatenate(cpis).tofile(path)
+    try:
+        cfg = medium_cfg(g)
+        out = {}
+        for mode in ("mapped", "memmove", "pread"):
+            cap = R.RspduoFile(path, n)
+            chain = R.GpuChain(cfg, 0, batch=3, reader_threads=3, read_mode=mode)
+            out[mode] = R.replay(cap, chain, batch=3)
+            assert chain.read_mode == mode
+            chain.close()
+            cap.close()
+        assert [r["cpi"] for r in out["mapped"]] == list(range(7))
+        for a, b, c in zip(out["mapped"], out["pread"], out["memmove"]):
+            assert a == b == c
+        for r in out["mapped"][:2]:
+            assert r["delay"] == g["cfar"][0].tolist() and r["doppler"] == g["cfar"][1].tolist()
+    finally:
+        os.remove(path)
+
+
 def test_replay_skips_cpis_whose_clutter_filter_fails(built_lib, tmp_path):
     """blah2.cpp:270-273: `if (!filter->process(x, y)) continue;` -- an all-zero reference channel makes the
     normal equations singular; that CPI is dropped, its neighbours in the same batch are not."""

@@ -31,7 +31,7 @@ for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"bench_r{n}*.log"
             continue
         sys.path.insert(0, ROOT)
         prof_names = {"range": ("rangeps_kernel", "rangew_kernel", "range_kernel", "range8_kernel"), "doppler": ("doppler_",),
-                      "metrics": ("metrics_kernel",), "cfar": ("cfar2d_tile_kernel", "cfar2d_kernel", "cfar1d_kernel"),
+                      "metrics": ("metrics_kernel",), "cfar": ("cfar2d_stream_kernel", "cfar2d_tile_kernel", "cfar2d_kernel", "cfar1d_kernel"),
                       "sat_rows": ("sat_rows_kernel",), "sat_cols": ("sat_cols_kernel",), "rotate": ("rotate_kernel",),
                       "clutter_corr": ("clutter_corr_half_kernel", "clutter_corr_kernel"), "clutter_fir": ("clutter_fir_kernel",),
                       "clutter_solve": ("clutter_solve_la_kernel", "clutter_solve_kernel"), "clutter_reduce": ("clutter_reduce_kernel",)}

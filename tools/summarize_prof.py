@@ -27,7 +27,7 @@ SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 
 KERNELS = ("rangeps_kernel", "rangew1k_kernel", "rangew_kernel", "range8_kernel", "range_kernel", "doppler_tilew2_kernel", "doppler_tilew_kernel", "doppler_tilem_kernel", "doppler_tile1k_kernel", "doppler_sub1k_kernel", "doppler_tile_kernel", "doppler_fft_kernel",
-           "doppler_dft_kernel", "metrics_kernel", "cfar1d_kernel", "cfar2d_tile_kernel", "cfar2d_kernel", "sat_rows_kernel", "sat_cols_kernel",
+           "doppler_dft_kernel", "metrics_kernel", "cfar1d_kernel", "cfar2d_stream_kernel", "cfar2d_tile_kernel", "cfar2d_kernel", "sat_rows_kernel", "sat_cols_kernel",
            "rotate_kernel", "clutter_corr_half_kernel", "clutter_corr_kernel", "clutter_fir_kernel", "clutter_solve_la_kernel", "clutter_solve_kernel", "solve_epoch_kernel", "clutter_reduce_kernel",
            "db_map_kernel", "cal_")
 
