@@ -314,7 +314,7 @@ def main(argv=None):
     cfg, cfg_desc = CONFIGS[a.config]
     dmin, dmax, fmin, fmax, fs, n = cfg
     B = a.batch if a.batch > 0 else ({"cfg3": 256 if a.chain == "full" else 32, "cfg5": 8, "small": 1024}.get(a.config, 256))
-    NS = max(1, a.streams) if a.chain == "amb" else 1
+    NS = max(1, a.streams)  # independent batches in flight, each on its own stream with its own handles and result buffers
     ambs = [blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B, n_doppler_bins=a.n_doppler)
             for _ in range(NS)]
     for h_ in ambs:
@@ -352,11 +352,15 @@ def main(argv=None):
     if a.chain == "full":
         if a.fmt not in ("c32", "i16"):
             raise SystemExit("--chain full needs --fmt c32 or i16")
-        wh = blah2_amd.WienerHopf(dmin, dmax, n, device=local, max_batch=B)  # config.yml uses the same lag window
-        yfilt = torch.empty((B, n), dtype=torch.complex64, device=dev)
-        okflag = torch.zeros(B, dtype=torch.int32, device=dev)
-        hits = torch.zeros((B, CAP, 2), dtype=torch.float64, device=dev)  # 16-byte records
-        hitcnt = torch.zeros(B, dtype=torch.int32, device=dev)
+        # one filter handle and one set of intermediate / result buffers per stream: with --streams 2 the (latency-bound, few
+        # workgroups) Toeplitz solve of one batch runs beside the transforms of the other
+        whs = [blah2_amd.WienerHopf(dmin, dmax, n, device=local, max_batch=B) for _ in range(NS)]  # config.yml uses the same lag window
+        wh = whs[0]
+        yfilts = [torch.empty((B, n), dtype=torch.complex64, device=dev) for _ in range(NS)]
+        okflags = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NS)]
+        hitss = [torch.zeros((B, CAP, 2), dtype=torch.float64, device=dev) for _ in range(NS)]  # 16-byte records
+        hitcnts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NS)]
+        yfilt, okflag, hits, hitcnt = yfilts[0], okflags[0], hitss[0], hitcnts[0]
         det = (blah2_amd.CfarDetector2D(1e-5, 2, 6, 1, 3, 5, 15.0) if a.cfar == "2d"
                else blah2_amd.CfarDetector1D(1e-5, 2, 6, 5, 15.0))  # config.yml:36-40 (+ Doppler guard 1, train 3)
     outs = [torch.zeros((B, nD, nC), dtype=torch.complex64, device=dev) for _ in range(NS)]
@@ -369,14 +373,16 @@ def main(argv=None):
 
     def step(i):
         r = i % ring
-        if wh is not None and a.fmt == "i16":  # the replay format: the filter and the range kernel read the .rspduo words
-            wh.process_dev_fmt(blah2_amd.FMT_I16, iqs[r].data_ptr(), None, B, n, yfilt.data_ptr(), n, okflag.data_ptr(), st)
-            amb.process_dev(blah2_amd.FMT_I16X_C32Y, iqs[r].data_ptr(), yfilt.data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
-            det.process_dev(amb, B, hits.data_ptr(), CAP, hitcnt.data_ptr(), out.data_ptr(), met.data_ptr(), st)
-        elif wh is not None:
-            wh.process_dev(xs[r].data_ptr(), ys[r].data_ptr(), B, n, yfilt.data_ptr(), okflag.data_ptr(), st)
-            amb.process_dev(blah2_amd.FMT_C32, xs[r].data_ptr(), yfilt.data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
-            det.process_dev(amb, B, hits.data_ptr(), CAP, hitcnt.data_ptr(), out.data_ptr(), met.data_ptr(), st)
+        if wh is not None:
+            q = i % NS
+            w_, a_, s_, yf_, ok_, o_, m_, h_, c_ = whs[q], ambs[q], sts[q], yfilts[q], okflags[q], outs[q], mets[q], hitss[q], hitcnts[q]
+            if a.fmt == "i16":  # the replay format: the filter and the range kernel read the .rspduo words
+                w_.process_dev_fmt(blah2_amd.FMT_I16, iqs[r].data_ptr(), None, B, n, yf_.data_ptr(), n, ok_.data_ptr(), s_)
+                a_.process_dev(blah2_amd.FMT_I16X_C32Y, iqs[r].data_ptr(), yf_.data_ptr(), B, n, o_.data_ptr(), m_.data_ptr(), s_)
+            else:
+                w_.process_dev(xs[r].data_ptr(), ys[r].data_ptr(), B, n, yf_.data_ptr(), ok_.data_ptr(), s_)
+                a_.process_dev(blah2_amd.FMT_C32, xs[r].data_ptr(), yf_.data_ptr(), B, n, o_.data_ptr(), m_.data_ptr(), s_)
+            det.process_dev(a_, B, h_.data_ptr(), CAP, c_.data_ptr(), o_.data_ptr(), m_.data_ptr(), s_)
         elif a.fmt in ("c32", "f16"):
             q = i % NS
             ambs[q].process_dev(blah2_amd.FMT_C32 if a.fmt == "c32" else blah2_amd.FMT_F16, xs[r].data_ptr(), ys[r].data_ptr(),
@@ -431,13 +437,13 @@ def main(argv=None):
         torch.cuda.synchronize()
     for h_ in ambs:
         h_.set_timing(True)
-    if wh is not None:
-        wh.set_timing(True)
+    for w_ in (whs if wh is not None else []):
+        w_.set_timing(True)
     for i in range(a.steps):
         step(a.warmup + i)
     torch.cuda.synchronize()
     kt = {}
-    for h_ in ambs + ([wh] if wh is not None else []):
+    for h_ in ambs + (whs if wh is not None else []):
         for k_, (ms_, n_) in h_.get_timing().items():
             kt[k_] = (kt.get(k_, (0.0, 0))[0] + ms_, kt.get(k_, (0.0, 0))[1] + n_)
         h_.set_timing(False)
