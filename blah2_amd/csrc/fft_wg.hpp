@@ -396,6 +396,21 @@ template <int R, int SIGN> B2_HD void dftR(cf *v)
   else dft4<SIGN>(v[0], v[1], v[2], v[3]);
 }
 
+// One value out of an exchange buffer as ONE ds_read_b64.  Left to the compiler, neighbouring reads are paired into
+// ds_read2_b64 / ds_read2st64_b64, which on gfx950 take 8 cycles of the CU's LDS per 64 lanes where two ds_read_b64 take 4.3
+// (the doubled read path serves b64 and b128 only; tools/membench/ldsrate.hip).  A wavefront-scope relaxed atomic load is a
+// plain ds_read_b64 that the merging passes leave alone.  The workgroup transforms gain 3-4 % from it; the one-wave
+// transforms (fft_wave*.hpp) LOSE as much when their pairs are split -- they are bound by instruction issue -- and keep them.
+B2_HD cf lds_ld(const cf *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long q = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  return cmake(__uint_as_float((unsigned)q), __uint_as_float((unsigned)(q >> 32)));
+#else
+  return *p;
+#endif
+}
+
 template <int R3> struct WgFft {
   static constexpr int T = 16 * R3;   // threads per transform
   static constexpr int F = 256 * R3;  // transform length
@@ -453,7 +468,7 @@ template <int R3> struct WgFft {
   {
     const int q = t / R3, u = t % R3;
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = A[q * PA + u + R3 * k];
+    for (int k = 0; k < 16; k++) v[k] = lds_ld(A + q * PA + u + R3 * k);
   }
   B2_HD static void fwd_s2_store(int t, const cf *v, cf *B)
   {
@@ -476,7 +491,7 @@ template <int R3> struct WgFft {
       const int q = (t >> 4) + R3 * j;
       cf *w = v + j * R3;
 #pragma unroll
-      for (int u = 0; u < R3; u++) w[u] = B[q * PB + u * SU + r];
+      for (int u = 0; u < R3; u++) w[u] = lds_ld(B + q * PB + u * SU + r);
 #pragma unroll
       for (int u = 1; u < R3; u++) w[u] = cmul(w[u], tw3[u - 1]);
       dftR<R3, -1>(w);
@@ -502,7 +517,7 @@ template <int R3> struct WgFft {
   {
     const int q = t / R3, a = t % R3;
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = B[q * PB + a * SU + r];
+    for (int r = 0; r < 16; r++) v[r] = lds_ld(B + q * PB + a * SU + r);
   }
   B2_HD static void inv_s2_store(int t, const cf *v, cf *A)
   {
@@ -520,7 +535,7 @@ template <int R3> struct WgFft {
   B2_HD static void inv_s3(int t, cf *v, const cf *tw1, const cf *A)
   {
 #pragma unroll
-    for (int q = 0; q < 16; q++) v[q] = A[q * PA + t];
+    for (int q = 0; q < 16; q++) v[q] = lds_ld(A + q * PA + t);
 #pragma unroll
     for (int q = 1; q < 16; q++) v[q] = cmulc(v[q], tw1[q - 1]);
     dft16<+1>(v);

@@ -30,14 +30,13 @@ __global__ __launch_bounds__(1024) void k_bperm(int *out, unsigned long long *cy
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
-// MODE 0: ds_read_b64, 1: ds_read2_b64 (two offsets), 2: ds_write_b64
+// MODE 0: ds_read_b64, 1: ds_read2_b64 (two offsets), 2: ds_write_b64, 3: ds_read2st64_b64, 4: ds_write2_b64, 5: ds_read_b128, 6: ds_write_b128
 template <int MODE> __global__ __launch_bounds__(1024) void k_lds(double *out, unsigned long long *cyc)
 {
-  __shared__ double buf[16][64 + 32];
+  __shared__ double buf[16][64 * 2 + 32 + 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double *p = &buf[wave][lane + 8];
-  buf[wave][lane] = lane;
-  if (lane < 32) buf[wave][64 + lane] = lane;
+  double *p = &buf[wave][(MODE >= 5 ? 2 * lane : lane) + 8];
+  for (int i = lane; i < 64 * 2 + 32 + 64; i += 64) buf[wave][i] = i;
   double x[ILP];
 #pragma unroll
   for (int i = 0; i < ILP; i++) x[i] = threadIdx.x + i;
@@ -50,6 +49,10 @@ template <int MODE> __global__ __launch_bounds__(1024) void k_lds(double *out, u
       if (MODE == 0) { double v; asm volatile("ds_read_b64 %0, %1 offset:24" : "=v"(v) : "v"((unsigned)(size_t)p)); x[i] = v; }
       if (MODE == 1) { double __attribute__((ext_vector_type(2))) v; asm volatile("ds_read2_b64 %0, %1 offset0:3 offset1:5" : "=v"(v) : "v"((unsigned)(size_t)p)); x[i] = v.x; }
       if (MODE == 2) { asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(size_t)p), "v"(x[i])); }
+      if (MODE == 3) { double __attribute__((ext_vector_type(2))) v; asm volatile("ds_read2st64_b64 %0, %1 offset0:0 offset1:1" : "=v"(v) : "v"((unsigned)(size_t)p)); x[i] = v.x; }
+      if (MODE == 4) { asm volatile("ds_write2_b64 %0, %1, %2 offset0:0 offset1:80" ::"v"((unsigned)(size_t)p), "v"(x[i]), "v"(x[(i + 1) % ILP])); }
+      if (MODE == 5) { double __attribute__((ext_vector_type(2))) v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)p)); x[i] = v.x; }
+      if (MODE == 6) { double __attribute__((ext_vector_type(2))) v = {x[i], x[(i + 1) % ILP]}; asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(size_t)p), "v"(v)); }
     }
     asm volatile("s_waitcnt lgkmcnt(0)");
   }
@@ -127,6 +130,10 @@ int main()
     hipLaunchKernelGGL(k_lds<0>, dim3(256), dim3(1024), 0, 0, (double *)out, cyc); report("ds_read_b64", 1);
     hipLaunchKernelGGL(k_lds<1>, dim3(256), dim3(1024), 0, 0, (double *)out, cyc); report("ds_read2_b64", 1);
     hipLaunchKernelGGL(k_lds<2>, dim3(256), dim3(1024), 0, 0, (double *)out, cyc); report("ds_write_b64", 1);
+    hipLaunchKernelGGL(k_lds<3>, dim3(256), dim3(1024), 0, 0, (double *)out, cyc); report("ds_read2st64_b64", 1);
+    hipLaunchKernelGGL(k_lds<4>, dim3(256), dim3(1024), 0, 0, (double *)out, cyc); report("ds_write2_b64", 1);
+    hipLaunchKernelGGL(k_lds<5>, dim3(256), dim3(1024), 0, 0, (double *)out, cyc); report("ds_read_b128", 1);
+    hipLaunchKernelGGL(k_lds<6>, dim3(256), dim3(1024), 0, 0, (double *)out, cyc); report("ds_write_b128", 1);
     hipLaunchKernelGGL(k_dpp, dim3(256), dim3(1024), 0, 0, (int *)out, cyc); report("v_mov_b32_dpp wave_shl:1", 1);
     hipLaunchKernelGGL(k_mix<1>, dim3(256), dim3(1024), 0, 0, (double *)out, cyc); report("bpermute + 1 v_add_f64", 1);
     hipLaunchKernelGGL(k_mix<2>, dim3(256), dim3(1024), 0, 0, (double *)out, cyc); report("bpermute + 2 v_add_f64", 1);
