@@ -590,6 +590,7 @@ struct FirArgs {
   const int32_t *ok; // [nCpi]
   const cf *tw;
   float scale;
+  int32_t carry;     // segLen = F/2: the upper half of a block's x window is the lower half of the next block's (see the kernel)
 };
 
 template <int R3, class In> __global__ __launch_bounds__(16 * R3, 2) void clutter_fir_kernel(FirArgs a)
@@ -626,14 +627,62 @@ template <int R3, class In> __global__ __launch_bounds__(16 * R3, 2) void clutte
 
   const int hist = a.nBins - 1; // samples of history in front of each block
   const int N = (int)a.N;       // < 2^31 - 8192 (checked at create): 32-bit sample indices throughout
+  // CARRY (a.carry, filters with nBins - 1 close below F/2, i.e. cfg 3's 2047 taps on F = 4096): the planner makes the blocks
+  // exactly F/2 = 8 T samples long, a workgroup walks CONSECUTIVE blocks, and the upper half of a block's window
+  // [n0 - hist, n0 - hist + F) is the lower half of the next block's, register for register (x'[t + T (k + 8)] -> x'[t + T k]):
+  // eight loads per thread and block instead of sixteen, and x is read once.  (With blocks of F - hist samples every
+  // sample of x was requested twice, and 43 % of the second requests went to HBM: 1.145 x the algorithmic bytes.)  It is a traffic
+  // measure, not a speed-up: the kernel's time did not move (58.0 against 57.7 us/CPI at cfg 3) -- what bounds it is the
+  // barrier-separated phases of two workgroups per CU, not the loads.  Otherwise: the XCD-aware strided walk, whole windows.
   const SegWalk sw = seg_walk(a.nSeg);
-  for (int r = sw.first; r < sw.count; r += sw.step) {
+  int rFirst = sw.first, rStep = sw.step, rEnd = sw.count;
+  if (a.carry) { // this workgroup's contiguous run inside its XCD's eighth
+    const int per = (max(sw.count, 0) + sw.step - 1) / sw.step;
+    rFirst = sw.first * per;
+    rEnd = min(rFirst + per, sw.count);
+    rStep = 1;
+  }
+  cf keep[8];
+  bool have = false;
+  // eight values v[k0 .. k0 + 7] of the window that starts at sample src0 of xs: x'[src0 + t + T k], zero outside [0, N)
+  auto load_half = [&](cf *dst, int src0) {
+    uint32_t j0;
+    int xcnt;
+    if (xs_window_plain(src0, 8 * T, a.xs, &j0, &xcnt)) {
+      using CX = typename BufChanOf<In>::X;
+      const __amdgpu_buffer_rsrc_t xd = make_rsrc_b(BufChanOf<In>::x(a.x, a.y, (int64_t)cpi * a.cpiStride + j0), xcnt * CX::STRIDE);
+#pragma unroll
+      for (int k = 0; k < 8; k++) dst[k] = RawBuiltin<CX>::cvt(RawBuiltin<CX>::ld(xd, (t + T * k) * CX::STRIDE, 0));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int src = src0 + t + T * k;
+        const bool inr = src >= 0 && src < N;
+        const cf xv = X[xs_index(inr ? (uint32_t)src : 0u, a.xs)];
+        dst[k] = inr ? xv : cmake(0.f, 0.f);
+      }
+    }
+  };
+  for (int r = rFirst; r < rEnd; r += rStep) {
     const int g = sw.base + r;
     const int n0 = g * a.segLen;
     cf v[16], yv[16];
     uint32_t j0;
     int xcnt;
-    if (xs_window_plain(n0 - hist, 16 * T, a.xs, &j0, &xcnt)) { // all but the first and last windows of a CPI
+    if (a.carry) {
+      if (have) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = keep[k];
+      } else {
+        load_half(v, n0 - hist);
+      }
+      load_half(v + 8, n0 - hist + 8 * T);
+#pragma unroll
+      for (int k = 0; k < 8; k++) keep[k] = v[8 + k];
+      have = true;
+      // (requesting the NEXT block's new half here, into eight more registers, so that it lands during this block's two
+      // transforms, measured 60.8 against 58.0 us/CPI at cfg 3: not adopted)
+    } else if (xs_window_plain(n0 - hist, 16 * T, a.xs, &j0, &xcnt)) { // all but the first and last windows of a CPI
       using CX = typename BufChanOf<In>::X;
       const __amdgpu_buffer_rsrc_t xd = make_rsrc_b(BufChanOf<In>::x(a.x, a.y, (int64_t)cpi * a.cpiStride + j0), xcnt * CX::STRIDE);
 #pragma unroll
@@ -706,6 +755,8 @@ struct blah2hip_clutter_s {
   int32_t nBins = 0;
   int r3 = 8;
   int F = 2048, segLen = 0, nSeg = 0, nJobs = 0, firGrid = 0, numCU = 256;
+  bool firCarry = false;     // blocks of F/2 samples, the window overlap carried in registers (plan)
+  bool firNoCarry = false;   // BLAH2HIP_CLUTTER_OPT_FIR_CARRY = 0
   hipStream_t stream = nullptr;
   cf *d_tw = nullptr;
   cf *d_partial = nullptr;
@@ -782,6 +833,10 @@ int clutter_plan(blah2hip_clutter_s *h)
   if (!bestR3) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip transform lengths (<= 4096)");
   h->r3 = bestR3; h->F = 256 * bestR3;
   h->segLen = h->F - nBins + 1;
+  // a filter whose history is just under half the transform: blocks of exactly F/2 samples, so that consecutive windows
+  // overlap by whole registers and the FIR kernel carries the overlap instead of reading it again (clutter_fir_kernel)
+  h->firCarry = h->segLen >= h->F / 2 && h->segLen <= h->F / 2 + h->F / 64 && !h->firNoCarry;
+  if (h->firCarry) h->segLen = h->F / 2;
   h->nSeg = (int)((h->N + (uint32_t)h->segLen - 1) / (uint32_t)h->segLen);
   // correlations: windowed form 3 transforms per segLen samples, half-window form 2 per F/2
   // (needs nBins - 1 <= F/2 and at least nBins samples)
@@ -911,6 +966,7 @@ template <int R3, class In> int launch_clutter(blah2hip_clutter_s *h, const void
   fa.x = px; fa.y = py; fa.yout = yout; fa.cpiStride = stride; fa.outStride = outStride; fa.N = h->N; fa.xs = xs;
   fa.nBins = h->nBins; fa.segLen = h->segLen; fa.nSeg = h->nSeg; fa.w = h->d_w; fa.ok = ok; fa.tw = h->d_tw;
   fa.scale = 1.0f / (float)h->F;
+  fa.carry = h->firCarry ? 1 : 0;
   CHIP(h->timer.tic(BLAH2HIP_CK_FIR, st));
   hipLaunchKernelGGL((clutter_fir_kernel<R3, In>), dim3(firGrid, nCpi), dim3(W::T), lds, st, fa);
   CHIP(hipGetLastError());
@@ -1051,6 +1107,16 @@ int blah2hip_clutter_set_option(blah2hip_clutter_t h, int option, int64_t value)
     CHIP(hipDeviceSynchronize()); // the mailboxes may still be in use by enqueued work
     const int rc = solve_la_alloc(h);
     if (rc) h->solveE = prev;
+    return rc;
+  }
+  case BLAH2HIP_CLUTTER_OPT_FIR_CARRY: {
+    if (value != 0 && value != 1) CFAIL(BLAH2HIP_ERR_INVALID, "FIR carry: 0 or 1");
+    const bool prev = h->firNoCarry;
+    h->firNoCarry = value == 0;
+    CHIP(hipSetDevice(h->device));
+    CHIP(hipDeviceSynchronize()); // the buffers may still be in use by enqueued work
+    const int rc = clutter_plan(h);
+    if (rc) { h->firNoCarry = prev; (void)clutter_plan(h); }
     return rc;
   }
   case BLAH2HIP_CLUTTER_OPT_FFT_LEN:

@@ -441,6 +441,10 @@ class WienerHopf:
         check(self._L.blah2hip_clutter_set_option(self._h, _lib.CLUTTER_OPT_FFT_LEN, int(F)))
         self._refresh_dims()
 
+    def set_fir_carry(self, on):
+        """Blocks of F/2 samples with the window overlap carried in registers (filters with nBins - 1 just under F/2); re-plans."""
+        check(self._L.blah2hip_clutter_set_option(self._h, _lib.CLUTTER_OPT_FIR_CARRY, 1 if on else 0))
+
     def set_corr_form(self, which):
         """'auto' / 'half' / 'window' (``_lib.CLUTTER_CORR_*``)."""
         if isinstance(which, str):

@@ -310,6 +310,10 @@ int blah2hip_clutter_process_dev_fmt(blah2hip_clutter_t h, int fmt, const void *
  * (2, 3, 6 or 12: 96 ... 736 indices per wave; 0 = the smallest whose workgroups each get a CU at the launch's batch). */
 #define BLAH2HIP_CLUTTER_OPT_SOLVE_FORM 4
 #define BLAH2HIP_CLUTTER_OPT_SOLVE_E 5
+/* FIR_CARRY (planner, re-plans like FFT_LEN): 1 (default) = a filter whose history nBins - 1 is just under F/2 (cfg 3: 2047 taps on
+ * F = 4096) runs on blocks of exactly F/2 samples and the FIR kernel carries the window overlap in registers; 0 = blocks of
+ * F - nBins + 1 samples, every window read whole (tests, A/B timing). */
+#define BLAH2HIP_CLUTTER_OPT_FIR_CARRY 6
 #define BLAH2HIP_CLUTTER_SOLVE_AUTO 0
 #define BLAH2HIP_CLUTTER_SOLVE_STEPWISE 1
 #define BLAH2HIP_CLUTTER_SOLVE_LOOKAHEAD 2

@@ -97,6 +97,36 @@ def test_clutter_correlation_forms_agree_with_the_oracle(b2, mode, n, taps):
     assert np.max(np.abs(yf.astype(np.complex128) - y_ref)) / np.max(np.abs(y_ref)) <= Y_TOL
 
 
+@pytest.mark.parametrize("n,taps", [(1_000_000, 2047),   # cfg 3's filter: F = 4096, history 2047 -> blocks of 2048, sixteen-points-per-thread kernel
+                                    (400_003, 1015),     # F = 2048, history 1015 -> blocks of 1024; a CPI that ends inside a block
+                                    (20_000, 2040),      # ten blocks: a workgroup's run is one or two blocks long, most of the grid idle
+                                    (2_500, 2047)])      # a CPI shorter than two blocks: every window runs over an end of the CPI
+def test_fir_carries_the_window_overlap(b2, n, taps):
+    """clutter_fir_kernel with blocks of exactly F/2 samples (filters whose history is just under half the transform): the
+    upper half of a block's window is kept in registers as the lower half of the next block's.  The taps (the correlation
+    and solve kernels do not change) and the filtered channel within fp32 rounding of the whole-window form
+    (BLAH2HIP_CLUTTER_OPT_FIR_CARRY = 0) and of the oracle; three launches on one handle."""
+    x, y = O.synth_iq(n, seed=n % 89 + taps, fs=1_000_000, targets=((20, 40.0, 0.05),))
+    dmin, dmax = -7, taps - 7
+    ok_ref, y_ref = O.wiener_hopf(x, y, dmin, dmax)[:2]
+    assert ok_ref
+    out = {}
+    for carry in (True, False):
+        wh = b2.WienerHopf(dmin, dmax, n)
+        wh.set_fir_carry(carry)
+        for rep in range(3 if carry else 1):
+            ok, yf = wh.process(x.astype(np.complex64), y.astype(np.complex64))
+            assert ok
+            if rep:
+                assert np.array_equal(yf, out[carry][0])
+            else:
+                out[carry] = (yf, wh.read_last(0)[1])
+        assert np.max(np.abs(yf.astype(np.complex128) - y_ref)) / np.max(np.abs(y_ref)) <= Y_TOL
+    # the taps: the same kernels, but the number of partial correlations per CPI follows the block count (fp32 rounding)
+    assert np.max(np.abs(out[True][1] - out[False][1])) <= 1e-5 * np.max(np.abs(out[False][1]))
+    assert np.max(np.abs(out[True][0] - out[False][0])) / np.max(np.abs(y_ref)) <= 2e-5
+
+
 @pytest.mark.parametrize("n,taps,corr", [(300_000, 410, "auto"), (300_000, 700, "half"), (1_000_000, 2047, "auto"), (100_000, 60, "auto")])
 def test_clutter_int16_wire_format_equals_fp32_planes(b2, n, taps, corr):
     """blah2hip_clutter_process_dev_fmt(FMT_I16): the correlation and FIR kernels read the .rspduo words (I1 Q1 I2 Q2,
