@@ -614,7 +614,7 @@ void cfar2d_stream_launch(const blah2hip_amb_s *h, const Cfar2dArgs &a, uint32_t
   const int64_t slots = (int64_t)h->numCU * 4 * 5; // about five waves per SIMD at ~ 100 VGPRs
   int64_t best = INT64_MAX;
   for (int R : {8, 16, 32, 64, 128, 256, 512, 1024, (int)a.nD}) { // a lone CPI: short segments, every SIMD a wave
-    if (R > a.nD && R != a.nD) continue;
+    if (R > a.nD) continue;
     const int64_t segs = (a.nD + R - 1) / R, tasks = segs * ta.strips * n_cpi;
     const int64_t cost = ((tasks + slots - 1) / slots) * (std::min(R, (int)a.nD) + 2 * hR + 16); // 16: start-up of a wave, in rows
     if (cost < best) { best = cost; ta.rowsPerSeg = std::min(R, (int)a.nD); ta.segs = (int32_t)segs; }

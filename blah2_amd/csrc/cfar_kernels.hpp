@@ -490,27 +490,28 @@ __global__ __launch_bounds__(64 * C2T_WAVES) void cfar2d_tile_kernel(Cfar2dTileA
 }
 
 // --------------------------------------------------------------------------
-// The one-pass detector as a STREAM, without LDS arrays and without barriers (round 4; the default for the window
-// shapes instantiated in C2S_SHAPES, the tile kernel above takes the others).  A WAVE owns a strip of 64 - 2 hC
-// output columns (lane <-> column, hC halo lanes on either side) and walks down a segment of Doppler rows, one
-// 512-byte row piece per step, U row pieces requested ahead.  Per row and lane, everything in fp64 and ADDITIVE
-// (no running differences) like in the tile kernel:
-//   along the row (across lanes, ds_bpermute shifts: the LDS crossbar, no LDS memory): run sums of 1, 2, 4, ...
-//   columns by doubling (P[b+1](j) = P[b](j) + P[b](j + 2^b)); the nTd training columns of one side are the set
-//   bits of nTd (TS), the other side is the same sum shifted; likewise the 2 nGd + 1 guard columns:
-//     A(r, j) = TS(j - hC) + TS(j + nGd + 1)         training columns of row r
-//     B(r, j) = A + the guard columns                 the whole window of row r
+// The one-pass detector as a STREAM, without barriers (round 4; the default for the window shapes instantiated in
+// C2S_SHAPES, the tile kernel above takes the others).  A WAVE owns a strip of 64 - 2 hC output columns (lane <-> column,
+// hC halo lanes on either side) and walks down a segment of Doppler rows, one 512-byte row piece per step, U row pieces
+// requested ahead.  Per row and lane, everything in fp64 and ADDITIVE (no running differences) like in the tile kernel:
+//   along the row (across lanes): the lane's |z|^2 and its sum with the right neighbour's go to the wave's own piece of
+//   LDS; the nTd training columns either side of the guard and the 2 nGd + 1 guard columns come back as pair sums
+//   (and one cell where a count is odd) through ds_read_b64 at immediate offsets:
+//     A(r, j) = the training columns of row r          B(r, j) = A + the guard columns = the whole window of row r
+//   (2 writes + 10 reads and 10 additions for the 17-column window; see the comment in the kernel for why not
+//   ds_bpermute and not ds_read2_b64)
 //   down the column (in registers, a ring per quantity whose slots are compile-time after unrolling U rows):
 //     TB(r) = B(r) + ... + B(r - nTf + 1),  TA(r) = A(r) + ... + A(r - 2 nGf)
 //     tot(i = r - hR) = TB(r) + TA(r - nTf) + TB(r - nTf - 2 nGf - 1)
-//   (the block of nTf rows is summed once and used twice, like TS): 7 shifts and 12 additions per cell for the
-//   17 x 9 window, where the tile kernel makes 26 additions out of LDS.
+//   (the block of nTf rows is summed once and used twice): 6 additions per cell for the 9 rows of the 17 x 9 window.
+// The tile kernel makes 26 additions per cell out of LDS between three workgroup barriers per tile.
 // The cell under test is the lane's own |z|^2 of hR rows ago; n, alpha[n] and the test are the tile kernel's
 // (sq n > alpha tot; n = 0 -> alpha = NaN -> never).  n depends on the row only through the clipped row counts,
-// which are wave-uniform: alpha[n] is fetched when they change (the first and last hR rows of the map).
+// which are wave-uniform: alpha[n] is fetched (from LDS) when they change (the first and last hR rows of the map).
 // Four waves (four neighbouring strips) share a workgroup only for the halo columns' sake (one L1); workgroups
 // are laid out so that an XCD walks a contiguous range of strips and segments (neighbours' halos in its L2).
-// What bounds it: VALU issue (about 20 fp64 instructions per row and wave) and the 14 bpermutes.
+// What bounds it: the map's HBM stream and the LDS / VALU work, each about half of the time,
+// not fully overlapped at four waves per SIMD.
 #ifndef C2S_ABLATE
 #define C2S_ABLATE 0 /* tools/ only: 1 = every row piece is the segment's first (cache hits), 2 = no sums along the row */
 #endif

@@ -41,6 +41,11 @@ python bench.py --config cfg5 --fmt f16 --steps 10 --warmup 2 --no-cpu-baseline 
 python bench.py --config cfg5 --fmt f16 --batch 32 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_r4_cfg5_b32.log 2>&1
 python bench.py --config cfg3 --chain full --batch 32 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_r4_cfg3_full_b32.log 2>&1
 python bench.py --chain full --batch 1 --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_r4_full_b1.log 2>&1
+# two batches in flight (a filter handle and result buffers per stream)
+python bench.py --chain full --batch 64 --streams 2 --steps 40 --no-cpu-baseline > $OUT/bench_r4_full_b64_s2.log 2>&1
+python bench.py --config cfg3 --chain full --streams 2 --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_r4_cfg3_full_s2.log 2>&1
+python bench.py --config cfg3 --chain full --batch 32 --streams 2 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_r4_cfg3_full_b32_s2.log 2>&1
+python bench.py --config cfg3 --chain full --batch 64 --streams 2 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_r4_cfg3_full_b64_s2.log 2>&1
 python bench.py --config small --steps 40 --warmup 3 --no-cpu-baseline > $OUT/bench_r4_small.log 2>&1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_r4_torchrun.log 2>&1
 python tools/replay_bench.py --out $OUT/replay.json > $OUT/replay_bench.log 2>&1
