@@ -273,6 +273,38 @@ def n_batches_hint(n: int, batch: int) -> int:
     return -(-n // batch) if n else 0
 
 
+def device_numa_cpus(torch, device: int = 0):
+    """The CPUs of the NUMA node the GPU hangs off (sysfs, through the device's PCI address), or None when it cannot be told
+    (one node, no sysfs, a container that hides it)."""
+    try:
+        bus = torch.cuda.get_device_properties(device).pci_bus_id  # torch >= 2.2
+        dom = getattr(torch.cuda.get_device_properties(device), "pci_domain_id", 0)
+        dev = getattr(torch.cuda.get_device_properties(device), "pci_device_id", 0)
+        path = f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{dev:02x}.0"
+        node = int(open(path + "/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        return cpus or None
+    except Exception:  # no device, no sysfs, an older torch: nothing to pin to
+        return None
+
+
+def pin_to_device_node(torch, device: int = 0) -> bool:
+    """Run this thread -- and the threads it starts, and the pinned memory it allocates from now on -- on the GPU's NUMA
+    node: the reader threads' copies then stay inside one socket's memory (a two-socket host moves them over the
+    inter-socket links otherwise).  True if the affinity was changed."""
+    cpus = device_numa_cpus(torch, device)
+    if not cpus or cpus == os.sched_getaffinity(0):
+        return False
+    os.sched_setaffinity(0, cpus)
+    return True
+
+
 def _hip_runtime(torch):
     """libamdhip64 of the running torch, for hipHostRegister / hipHostUnregister / hipMemcpyAsync on raw addresses (torch
     has no tensor over read-only memory); None if it cannot be loaded."""
@@ -304,11 +336,15 @@ class GpuChain:
     (``if (!filter->process(x, y)) continue;`` blah2.cpp:270-273): its result is ``{"skipped": True}``."""
 
     def __init__(self, cfg: dict, device: int = 0, batch: int = 1, want_map: bool = False, depth: int = 3,
-                 reader_threads: int = 8, hit_copy: int = 4096, read_mode: str = "memmove"):
+                 reader_threads: int = 8, hit_copy: int = 4096, read_mode: str = "memmove", numa: bool = True):
         import torch
 
         import blah2_amd
         self.torch, self.b2 = torch, blah2_amd
+        # before any pinned allocation and before the reader threads exist: everything host-side on the GPU's NUMA node
+        # (EPYC 9575F x 2, tools/gpu_hostreg.py: a reader thread copies 17-19 GB/s inside the node, 12.5 when the scheduler
+        # puts it on the other socket; four threads 51-54 GB/s against 41)
+        self.numa_pinned = pin_to_device_node(torch, device) if numa else False
         amb_c, det_c, clu_c = cfg["ambiguity"], cfg.get("detection", {}), cfg.get("clutter", {})
         self.fs, self.n = int(cfg["fs"]), int(cfg["n_samples"])
         n, B = self.n, int(batch)
@@ -484,18 +520,23 @@ class GpuChain:
 
     def run_batches(self, capture: RspduoFile, batches) -> Iterator[List[dict]]:
         """The pipeline over this rank's batches: yields each batch's results in order.  Up to ``depth`` batches are in
-        flight; batch i's slot is reused by batch i + depth only after batch i has been collected."""
+        flight; batch i's slot is reused by batch i + depth only after batch i has been collected.  (Starting the read of batch
+        i + depth on a background thread BEFORE batch i is collected -- a slot's input half is free once its upload is done --
+        was measured and changed nothing: the reader threads are not the ones waiting.)"""
         batches = list(batches)
         D = self.depth
-        for i in range(min(D - 1, len(batches))):  # fill
-            self._read(capture, self.slots[i % D], *batches[i])
-            self._submit(self.slots[i % D], batches[i][1])
-        for i, (k0, cnt) in enumerate(batches):
-            j = i + D - 1
-            if j < len(batches):  # its slot was collected in iteration i - 1
-                self._read(capture, self.slots[j % D], *batches[j])
-                self._submit(self.slots[j % D], batches[j][1])
-            yield self._collect(self.slots[i % D], k0, cnt)
+        try:
+            for i in range(min(D - 1, len(batches))):  # fill
+                self._read(capture, self.slots[i % D], *batches[i])
+                self._submit(self.slots[i % D], batches[i][1])
+            for i, (k0, cnt) in enumerate(batches):
+                j = i + D - 1
+                if j < len(batches):  # its slot was collected in iteration i - 1
+                    self._read(capture, self.slots[j % D], *batches[j])
+                    self._submit(self.slots[j % D], batches[j][1])
+                yield self._collect(self.slots[i % D], k0, cnt)
+        finally:
+            self.release_all()  # a consumer that stopped early leaves registered pages behind
 
     def __call__(self, iq: np.ndarray) -> List[dict]:
         """One batch, synchronously, from a host array [B, nSamples, 4] (tests; a caller that has the samples in memory)."""

@@ -23,6 +23,11 @@ H2D = 1
 
 
 def main():
+    if "--numa" in sys.argv:
+        sys.argv.remove("--numa")
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from blah2_amd import replay as R
+        print("pinned to the GPU's NUMA node:", R.pin_to_device_node(torch, 0), "cpus", len(os.sched_getaffinity(0)), flush=True)
     win = (int(sys.argv[1]) if len(sys.argv) > 1 else 256) << 20
     nwin = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     path = "/dev/shm/blah2_hostreg.bin"

@@ -62,6 +62,7 @@ def main():
     a = ap.parse_args()
     (dmin, dmax, fmin, fmax, fs, n), desc = bench.CONFIGS[a.config]
     dev = torch.device("cuda", 0)
+    numa = R.pin_to_device_node(torch, 0)  # before the capture is written: its page-cache pages on the GPU's node too
     path = f"/dev/shm/blah2_replay_{a.config}.rspduo"
     t0 = time.perf_counter()
     make_capture(path, n, a.cpis, fs)
@@ -71,7 +72,7 @@ def main():
     bound = rate / bytes_per_cpi
     res = {"config": a.config, "workload": desc, "cpis": a.cpis, "batch": a.batch, "bytes_per_cpi": bytes_per_cpi,
            "pinned_h2d_GBps": rate / 1e9, "pcie_bound_cpis_per_s": bound, "capture": path, "capture_written_s": t_gen,
-           "host_cores": os.cpu_count(), "runs": []}
+           "host_cores": os.cpu_count(), "pinned_to_gpu_numa_node": numa, "cpus_allowed": len(os.sched_getaffinity(0)), "runs": []}
     base = {"fs": fs, "n_samples": n,
             "ambiguity": {"delayMin": dmin, "delayMax": dmax, "dopplerMin": fmin, "dopplerMax": fmax},
             "detection": {"enable": True, "pfa": 1e-5, "nGuard": 2, "nTrain": 6, "minDelay": 5, "minDoppler": 15.0}}
