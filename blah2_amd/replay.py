@@ -369,6 +369,7 @@ class GpuChain:
         self.compute = torch.cuda.Stream(device=dev)
         self.copy = torch.cuda.Stream(device=dev)
         self.pool = ThreadPoolExecutor(max_workers=max(1, reader_threads))
+        self._bg = ThreadPoolExecutor(max_workers=1)  # starts and awaits a batch's read while the main thread works on another
         self.reader_threads = max(1, reader_threads)
         # How a batch gets from the page cache to the copy engine (tools/gpu_hostreg.py, tools/replay_bench.py; MI355X host):
         #   "memmove"  reader threads copy out of the file's shared mapping into a pinned ring (page tables filled by madvise
@@ -490,7 +491,6 @@ class GpuChain:
     def _collect(self, slot: dict, k0: int, cnt: int) -> List[dict]:
         b2, amb = self.b2, self.amb
         slot["downloaded"].synchronize()
-        self._release(slot)
         met_h = slot["h_met"].numpy()
         ok_h = slot["h_ok"].numpy() if self.wh is not None else np.ones(cnt, dtype=np.int32)
         res = []
@@ -520,23 +520,41 @@ class GpuChain:
 
     def run_batches(self, capture: RspduoFile, batches) -> Iterator[List[dict]]:
         """The pipeline over this rank's batches: yields each batch's results in order.  Up to ``depth`` batches are in
-        flight; batch i's slot is reused by batch i + depth only after batch i has been collected.  (Starting the read of batch
-        i + depth on a background thread BEFORE batch i is collected -- a slot's input half is free once its upload is done --
-        was measured and changed nothing: the reader threads are not the ones waiting.)"""
+        flight; batch i's slot is reused by batch i + depth.  A slot has two halves with different lifetimes: its INPUT
+        (the pinned batch, or the registered pages) is free as soon as the upload has completed, its RESULT buffers when the
+        batch has been collected -- so the read of the next batch is started (on a background thread that drives the reader
+        threads) the moment the previous read has ended, before this thread enqueues, synchronises, converts and yields:
+        the reader threads never wait for Python."""
         batches = list(batches)
-        D = self.depth
+        D, n = self.depth, len(batches)
+        reads = {}
+
+        def start(j):
+            slot = self.slots[j % D]
+            slot["uploaded"].synchronize()  # the slot's previous upload (batch j - depth) is done with the input half
+            self._release(slot)
+            reads[j] = self._bg.submit(self._read, capture, slot, *batches[j])
+
         try:
-            for i in range(min(D - 1, len(batches))):  # fill
-                self._read(capture, self.slots[i % D], *batches[i])
+            if n:
+                start(0)
+            for i in range(min(D - 1, n)):  # fill
+                reads.pop(i).result()
+                if i + 1 < n:
+                    start(i + 1)
                 self._submit(self.slots[i % D], batches[i][1])
             for i, (k0, cnt) in enumerate(batches):
                 j = i + D - 1
-                if j < len(batches):  # its slot was collected in iteration i - 1
-                    self._read(capture, self.slots[j % D], *batches[j])
+                if j < n:
+                    reads.pop(j).result()
+                    if j + 1 < n:
+                        start(j + 1)  # into the input half of the slot whose results are collected below
                     self._submit(self.slots[j % D], batches[j][1])
                 yield self._collect(self.slots[i % D], k0, cnt)
         finally:
-            self.release_all()  # a consumer that stopped early leaves registered pages behind
+            for f in reads.values():  # a consumer that stopped early: let the read finish before its pages are released
+                f.result()
+            self.release_all()
 
     def __call__(self, iq: np.ndarray) -> List[dict]:
         """One batch, synchronously, from a host array [B, nSamples, 4] (tests; a caller that has the samples in memory)."""
@@ -559,6 +577,7 @@ class GpuChain:
             self._release(slot)
 
     def close(self):
+        self._bg.shutdown(wait=True)
         self.pool.shutdown(wait=True)
         self.release_all()
 
