@@ -336,7 +336,7 @@ class GpuChain:
     (``if (!filter->process(x, y)) continue;`` blah2.cpp:270-273): its result is ``{"skipped": True}``."""
 
     def __init__(self, cfg: dict, device: int = 0, batch: int = 1, want_map: bool = False, depth: int = 3,
-                 reader_threads: int = 8, hit_copy: int = 4096, read_mode: str = "memmove", numa: bool = True):
+                 reader_threads: int = 4, hit_copy: int = 4096, read_mode: str = "memmove", numa: bool = True):
         import torch
 
         import blah2_amd
@@ -373,14 +373,15 @@ class GpuChain:
         self.reader_threads = max(1, reader_threads)
         # How a batch gets from the page cache to the copy engine (tools/gpu_hostreg.py, tools/replay_bench.py; MI355X host):
         #   "memmove"  reader threads copy out of the file's shared mapping into a pinned ring (page tables filled by madvise
-        #              first): 12.5 GB/s per thread, 8 threads saturate the link (57 GB/s); three passes over DRAM
-        #   "pread"    the same through the kernel's copy_to_user: 9.5 GB/s per thread
+        #              first): 17-19 GB/s per thread on the GPU's NUMA node (12.5 across sockets), FOUR threads keep the link
+        #              at 0.905 of its pinned rate (57 GB/s); three passes over DRAM
+        #   "pread"    the same through the kernel's copy_to_user: 12.6 GB/s per thread on the node (9.5): 0.76 with four threads
         #   "mapped"   no CPU copy and ONE pass over DRAM: the threads only REGISTER whole-page pieces of the mapping with the
-        #              device (hipHostRegister) and the copy engine reads the page cache's own pages.  A third of the host CPU
-        #              time -- but the driver registers 4 KB pages at 17-25 GB/s whatever the thread count (12-15 GB/s with the
-        #              page-table fill of a first pass), so a replay that touches every page once runs at a quarter of the link.
-        #              For captures replayed repeatedly out of a mapping that stays (warm page tables) it reaches 0.90 of it
-        #              with one thread.
+        #              device (hipHostRegister) and the copy engine reads the page cache's own pages.  A third to a half of the
+        #              host CPU time -- but the driver registers 4 KB pages at 17-25 GB/s whatever the thread count (12-15 GB/s
+        #              with the page-table fill of a first pass), so a replay that touches every page once gets 0.60 of the
+        #              link from one thread and less from more.  For captures replayed repeatedly out of a mapping that stays
+        #              (warm page tables) it reaches 0.94 of it with one thread.
         if read_mode not in ("memmove", "pread", "mapped"):
             raise ValueError("read_mode: 'memmove', 'pread' or 'mapped'")
         self.read_mode = read_mode
