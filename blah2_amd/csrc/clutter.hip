@@ -399,13 +399,14 @@ struct SolveArgs {
   uint32_t *epoch;   // launch epoch of the look-ahead solve's mailboxes (solve_la.hpp), bumped here
 };
 
-// grid (ceil(nBins/16), 2, nCpi) x 256: fixed-order fp64 sum over the jobs.  A block takes 16 bins (128-byte rows) and cuts the
-// jobs into sixteen interleaved slices (thread = bin + 16 slice): a lone CPI has up to 512 partials per bin, which one thread per bin
+// grid (ceil(nBins/16), 2, nCpi) x 1024: fixed-order fp64 sum over the jobs.  A block takes 16 bins (128-byte rows) and cuts the
+// jobs into 64 interleaved slices (thread = bin + 16 slice): a lone CPI has up to 512 partials per bin, which one thread per bin
 // summed as 64 dependent rounds of L2 latency (27.8 us of the 171 us a lone CPI's full chain took at configs[1], round 4);
 // the slices' sums meet in LDS and are added in slice order -- the same order every run.
-__global__ __launch_bounds__(256) void clutter_reduce_kernel(SolveArgs a)
+constexpr int RED_SLICES = 64; // 1024 threads: a lone CPI's 512 partials per bin are 4 dependent rounds of 2 loads per thread (16 slices: 16 rounds, 9.8 us)
+__global__ __launch_bounds__(16 * RED_SLICES) void clutter_reduce_kernel(SolveArgs a)
 {
-  __shared__ double sx[16][16], sy[16][16];
+  __shared__ double sx[RED_SLICES][16], sy[RED_SLICES][16];
   const int bin = threadIdx.x & 15, slice = threadIdx.x >> 4;
   const int k = blockIdx.x * 16 + bin, mode = blockIdx.y, cpi = blockIdx.z;
   if (a.epoch && blockIdx.x == 0 && threadIdx.x == 0 && mode == 0 && cpi == 0) { // one thread per launch; the solve kernel behind the boundary reads it
@@ -418,8 +419,8 @@ __global__ __launch_bounds__(256) void clutter_reduce_kernel(SolveArgs a)
     // two interleaved accumulators: the loads of a pair of rounds are independent
     double bx = 0.0, by = 0.0;
     int j = slice;
-    for (; j + 16 < a.nJobs; j += 32) {
-      const cf u = p[(size_t)j * a.nBins], v = p[(size_t)(j + 16) * a.nBins];
+    for (; j + RED_SLICES < a.nJobs; j += 2 * RED_SLICES) {
+      const cf u = p[(size_t)j * a.nBins], v = p[(size_t)(j + RED_SLICES) * a.nBins];
       ax += (double)u.x; ay += (double)u.y;
       bx += (double)v.x; by += (double)v.y;
     }
@@ -431,8 +432,8 @@ __global__ __launch_bounds__(256) void clutter_reduce_kernel(SolveArgs a)
   __syncthreads();
   if (slice == 0 && k < a.nBins) {
     double tx = sx[0][bin], ty = sy[0][bin];
-#pragma unroll
-    for (int q = 1; q < 16; q++) { tx += sx[q][bin]; ty += sy[q][bin]; }
+#pragma unroll 8
+    for (int q = 1; q < RED_SLICES; q++) { tx += sx[q][bin]; ty += sy[q][bin]; } // in slice order: the same sum every run
     a.rb[((size_t)cpi * 2 + mode) * a.nBins + k] = {tx, ty};
   }
 }
@@ -958,7 +959,7 @@ template <int R3, class In> int launch_clutter(blah2hip_clutter_s *h, const void
   sa.partial = h->d_partial; sa.rb = h->d_rb; sa.w = h->d_w; sa.ok = ok; sa.nBins = h->nBins; sa.nJobs = nJobs;
   sa.epoch = h->d_epoch;
   CHIP(h->timer.tic(BLAH2HIP_CK_REDUCE, st));
-  hipLaunchKernelGGL(clutter_reduce_kernel, dim3((h->nBins + 15) / 16, 2, nCpi), dim3(256), 0, st, sa);
+  hipLaunchKernelGGL(clutter_reduce_kernel, dim3((h->nBins + 15) / 16, 2, nCpi), dim3(16 * RED_SLICES), 0, st, sa);
   CHIP(h->timer.toc(BLAH2HIP_CK_REDUCE, st));
   { const int rc_ = launch_solve(h, sa, nCpi, st); if (rc_) return rc_; }
 
