@@ -259,3 +259,15 @@ def test_results_are_serialised_on_the_rank_that_owns_them(tmp_path):
         assert got[k, 1] == (k // batch) % 2          # batch b is rank b % world's
         assert got[k, 2] == 1000 + 37 * k + len(f"{stub(f.batch([k]))[0]['noisePower']:.6f}")
         assert abs(got[k, 3] - stub(f.batch([k]))[0]["noisePower"]) < 1e-5
+
+
+def test_numa_pinning_is_a_no_op_without_a_device():
+    """pin_to_device_node / device_numa_cpus (replay.py): without a GPU (this suite) or without sysfs topology there is nothing
+    to pin to, and the process's affinity must be left alone."""
+    import torch
+    before = os.sched_getaffinity(0)
+    assert R.device_numa_cpus(torch, 0) is None or isinstance(R.device_numa_cpus(torch, 0), set)
+    if not torch.cuda.is_available():
+        assert R.device_numa_cpus(torch, 0) is None
+        assert R.pin_to_device_node(torch, 0) is False
+        assert os.sched_getaffinity(0) == before
