@@ -47,11 +47,11 @@ CONFIGS = {
 
 # parity gates of the in-bench check (the same numbers as tests/test_ambiguity_gpu.py and
 # tests/test_full_chain_gpu.py, where they are derived)
-GATE_PEAK_REL, GATE_DB_MAP, GATE_METRICS_DB, GATE_CHAIN_DIRECT = 1e-5, 0.005, 1e-3, 2e-4
-# The dB-map figure is the worst of ~2e5 cells, some of them 50 dB below the mean level, on random input:
-# it is reported against SURVEY.md's 0.005 dB gate, and fatal only at 4x that (a weak-cell outlier on one
-# seed should not void a run whose map is within 1e-7 of the peak).
-FATAL_DB_MAP = 0.02
+GATE_PEAK_REL, GATE_DB_MAP, GATE_METRICS_DB, GATE_CHAIN_DIRECT = 1e-5, 0.005, 1e-3, 1e-4
+# The JSON-map gate, as tests/gates.py states it: 0.005 dB on every cell down to DB_FLOOR dB below the map's mean
+# level (the one consumer of the document, html/js/plot_map.js:170, clamps at the mean level itself); deeper cells --
+# the few deep nulls of a Rayleigh floor -- are held to the absolute error 0.005 dB means AT that line.  ONE threshold.
+DB_FLOOR = 20.0
 
 
 # ----------------------------------------------------------------------------- launcher
@@ -245,9 +245,15 @@ def parity_check(np, O, cfg, fmt, chain, cfar, n_doppler, x_h, y_h, got_map, got
         db_got = 10.0 * np.log10(np.abs(got_map.astype(np.complex128))) - got_met[0]
         db_ref = 10.0 * np.log10(np.abs(ref)) - noise
     if chain != "full":  # after cancellation the weakest cells are rounding noise in both
-        res["db_max"] = float(np.max(np.abs(db_got - db_ref)))
-        res["db_max_within_gate"] = bool(res["db_max"] <= GATE_DB_MAP)
-        res["pass"] = bool(res["pass"] and res["db_max"] <= FATAL_DB_MAP)
+        d_db = np.abs(db_got - db_ref)
+        shown = db_ref >= -DB_FLOOR
+        floor_level = 10.0 ** ((noise - DB_FLOOR) / 10.0)
+        res["db_max"] = float(d_db[shown].max())               # the gated figure: cells within DB_FLOOR of the mean level
+        res["db_max_all_cells"] = float(d_db.max())            # reported: includes the deep nulls
+        res["cells_over_gate_below_floor"] = int((d_db[~shown] > GATE_DB_MAP).sum())
+        res["abs_err_below_floor_over_floor_level"] = float(err[~shown].max() / floor_level) if (~shown).any() else 0.0
+        res["pass"] = bool(res["pass"] and res["db_max"] <= GATE_DB_MAP
+                           and res["abs_err_below_floor_over_floor_level"] <= 10.0 ** (GATE_DB_MAP / 10.0) - 1.0)
     res["metrics_db"] = float(max(abs(got_met[0] - noise), abs(got_met[1] - mx)))
     res["pass"] = bool(res["pass"] and res["metrics_db"] <= GATE_METRICS_DB)
     return res
@@ -483,7 +489,7 @@ def main(argv=None):
                   "metrics": ("metrics_kernel",), "cfar": ("cfar2d_stream_kernel", "cfar2d_tile_kernel", "cfar2d_kernel", "cfar1d_kernel"),
                   "sat_rows": ("sat_rows_kernel",), "sat_cols": ("sat_cols_kernel",), "rotate": ("rotate_kernel",),
                   "clutter_corr": ("clutter_corr_half_kernel", "clutter_corr_kernel"), "clutter_fir": ("clutter_fir_kernel",),
-                  "clutter_solve": ("clutter_solve_kernel",), "clutter_reduce": ("clutter_reduce_kernel",)}
+                  "clutter_solve": ("clutter_solve_la_kernel", "clutter_solve_kernel"), "clutter_reduce": ("clutter_reduce_kernel",)}
     for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
             tj = json.load(open(pth))
@@ -543,7 +549,7 @@ def main(argv=None):
         parity = {"pass": all(c_["pass"] for c_ in checks), "cpis": checks,
                   "oracle": "oracle/blah2_oracle.py (fp64 NumPy restatement of Ambiguity.cpp:92-172, Map.cpp:187-206"
                             + (", WienerHopf.cpp:58-163)" if a.chain == "full" else ")"),
-                  "gates": {"peak_rel": GATE_PEAK_REL, "db_max": GATE_DB_MAP, "db_max_fatal": FATAL_DB_MAP,
+                  "gates": {"peak_rel": GATE_PEAK_REL, "db_max": GATE_DB_MAP, "db_floor_below_mean_level": DB_FLOOR,
                             "metrics_db": GATE_METRICS_DB, "chain_err_over_direct_path": GATE_CHAIN_DIRECT}}
         for key in ("peak_rel", "db_max", "metrics_db", "chain_err_over_direct_path"):
             vals = [c_[key] for c_ in checks if key in c_]

@@ -24,8 +24,9 @@ CLUTTER_KERNEL_NAMES = {CK_CORR: "clutter_corr", CK_REDUCE: "clutter_reduce", CK
 OPT_DOPPLER_KERNEL, OPT_RANGE_GRID, OPT_RANGE_KERNEL, OPT_DOPPLER_GRID, OPT_FFT_LEN, OPT_CFAR2D_KERNEL = 1, 2, 3, 4, 5, 6
 CFAR2D_AUTO, CFAR2D_TILE, CFAR2D_SAT, CFAR2D_STREAM = 0, 1, 2, 3
 CLUTTER_OPT_SOLVE_K, CLUTTER_OPT_FFT_LEN, CLUTTER_OPT_CORR, CLUTTER_OPT_SOLVE_FORM, CLUTTER_OPT_SOLVE_E, CLUTTER_OPT_FIR_CARRY = 1, 2, 3, 4, 5, 6
+CLUTTER_OPT_SOLVE_SPIN_LIMIT = 7
 CLUTTER_SOLVE_AUTO, CLUTTER_SOLVE_STEPWISE, CLUTTER_SOLVE_LOOKAHEAD = 0, 1, 2
-CLUTTER_INFO_SOLVE_FORM, CLUTTER_INFO_SOLVE_E, CLUTTER_INFO_SOLVE_G, CLUTTER_INFO_SOLVE_FAULT = 1, 2, 3, 4
+CLUTTER_INFO_SOLVE_FORM, CLUTTER_INFO_SOLVE_E, CLUTTER_INFO_SOLVE_G, CLUTTER_INFO_SOLVE_FAULT, CLUTTER_INFO_SOLVE_RETRIES = 1, 2, 3, 4, 5
 CLUTTER_CORR_AUTO, CLUTTER_CORR_HALF, CLUTTER_CORR_WINDOW = 0, 1, 2
 DOP_AUTO, DOP_TILE8, DOP_TILE16, DOP_TILEM, DOP_COLUMN, DOP_DIRECT, DOP_TILEW, DOP_TILEW2, DOP_TILE16WG, DOP_SUB4 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 DOPPLER_KERNEL_NAMES = {DOP_AUTO: "auto", DOP_TILE8: "tile8", DOP_TILE16: "tile16", DOP_TILEM: "tilem",

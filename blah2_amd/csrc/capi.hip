@@ -1345,6 +1345,11 @@ int blah2hip_cfar2d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
     return fail(BLAH2HIP_ERR_UNSUPPORTED, "2-D window beyond the tile kernel's halo (nGf + nTf <= 24, nGd + nTd <= 40)");
   if (h->cfar2dForce == BLAH2HIP_CFAR2D_STREAM && !cfar2d_stream_shape(ngd, ntd, ngf, ntf))
     return fail(BLAH2HIP_ERR_UNSUPPORTED, "the stream kernel is not instantiated for this 2-D window (C2S_SHAPES in cfar_kernels.hpp)");
+  {
+    int lo, hi; // the handle's Doppler axis is monotonic (Ambiguity.cpp:60-66), so this cannot fail today; a forced kernel never runs another one
+    if (h->cfar2dForce == BLAH2HIP_CFAR2D_STREAM && !cfar2d_dead_rows(h, min_doppler, &lo, &hi))
+      return fail(BLAH2HIP_ERR_UNSUPPORTED, "the stream kernel needs the rows below minDoppler to be one interval of the Doppler axis");
+  }
   if (!cfar2d_use_stream(h, ngd, ntd, ngf, ntf, min_doppler) && !cfar2d_use_tile(h, ngd, ntd, ngf, ntf) && (rc = ensure_sat(h))) return rc; // no-op once allocated
   const double *d_alpha = nullptr;
   if ((rc = alpha_table(h, pfa, (size_t)(2 * (ngd + ntd) + 1) * (2 * (ngf + ntf) + 1), &d_alpha, st))) return rc;

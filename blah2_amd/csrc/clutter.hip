@@ -397,6 +397,11 @@ struct SolveArgs {
   int32_t *ok;       // [nCpi]
   int32_t nBins, nJobs;
   uint32_t *epoch;   // launch epoch of the look-ahead solve's mailboxes (solve_la.hpp), bumped here
+  // clutter_solve_kernel as the launch BEHIND the look-ahead solve: a workgroup runs only if its CPI's fault word carries
+  // this launch's epoch (a bounded wait of the look-ahead form ran out), and counts itself in *retries
+  const unsigned long long *gate = nullptr; // the CPI's fault word: gate[cpi * gateStride]
+  int64_t gateStride = 0;
+  uint32_t *retries = nullptr;
 };
 
 // grid (ceil(nBins/16), 2, nCpi) x 1024: fixed-order fp64 sum over the jobs.  A block takes 16 bins (128-byte rows) and cuts the
@@ -504,6 +509,11 @@ __global__ __launch_bounds__(1024) void clutter_solve_kernel(SolveArgs a)
   SolveScal *scal = reinterpret_cast<SolveScal *>(nxt + (n + 1)); // [parity]
   const int cpi = blockIdx.x;
   const int t = threadIdx.x, NT = blockDim.x;
+  if (a.gate) { // behind the look-ahead solve: only the CPIs it gave up on
+    const unsigned long long g = __hip_atomic_load(a.gate + (size_t)cpi * a.gateStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)g != *a.epoch) return;
+    if (t == 0) atomicAdd(a.retries, 1u);
+  }
   const dcx *rg = a.rb + (size_t)cpi * 2 * n;
   const double r0 = rg[0].x;
   bool ok = (r0 > 0.0) && isfinite(r0);
@@ -771,7 +781,9 @@ struct blah2hip_clutter_s {
   int solveE = 0;            // BLAH2HIP_CLUTTER_OPT_SOLVE_E (0 = by launch size)
   sla::u64 *d_mail = nullptr; // mailboxes of the look-ahead solve (solve_la.hpp), sized for max_batch
   int64_t mailWords = 0;
-  uint32_t *d_epoch = nullptr; // [0] launch epoch, [1] fault word (a bounded spin ran out)
+  uint32_t *d_epoch = nullptr; // [0] launch epoch, [1] sticky fault word (a bounded spin ran out), [2] CPIs solved again by the gated launch
+  uint32_t spinLimit = sla::SPIN_LIMIT; // BLAH2HIP_CLUTTER_OPT_SOLVE_SPIN_LIMIT
+  int laCap[4][2] = {};        // workgroups of clutter_solve_la_kernel<kE[i], 4 | 8> the chip holds at once
   int lastForm = 0, lastE = 0, lastG = 0; // what the last launch ran
   bool corrHalf = false;     // half-window correlation (2 transforms per F/2 samples) instead of the windowed one
   int fftLenForce = 0;       // BLAH2HIP_CLUTTER_OPT_FFT_LEN (0 = planner)
@@ -781,6 +793,8 @@ struct blah2hip_clutter_s {
 };
 
 namespace {
+
+hipError_t solve_la_capacity(blah2hip_clutter_s *h);
 
 // Mailboxes of the look-ahead Toeplitz solve (solve_la.hpp): sized for the largest launch each plan can be chosen for
 // (create, and again when BLAH2HIP_CLUTTER_OPT_SOLVE_E changes).  Zeroed once: tags are launch epochs >= 1.
@@ -803,10 +817,38 @@ int solve_la_alloc(blah2hip_clutter_s *h)
     h->mailWords = need;
   }
   if (!h->d_epoch) {
-    CHIP(hipMalloc(&h->d_epoch, 2 * sizeof(uint32_t)));
-    CHIP(hipMemset(h->d_epoch, 0, 2 * sizeof(uint32_t)));
+    CHIP(hipMalloc(&h->d_epoch, 4 * sizeof(uint32_t)));
+    CHIP(hipMemset(h->d_epoch, 0, 4 * sizeof(uint32_t)));
   }
+  if (!h->laCap[0][0]) CHIP(solve_la_capacity(h));
   return BLAH2HIP_OK;
+}
+
+// Resident workgroups per instantiation (occupancy x CUs): what sla::choose_plan may count on for plans whose workgroups
+// wait for each other.
+template <int E> hipError_t solve_la_capacity_e(blah2hip_clutter_s *h, int i)
+{
+  int b4 = 0, b8 = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, sla::clutter_solve_la_kernel<E, 4>, 256, 0);
+  if (e != hipSuccess) return e;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b8, sla::clutter_solve_la_kernel<E, 8>, 512, 0);
+  if (e != hipSuccess) return e;
+  h->laCap[i][0] = std::max(1, b4) * h->numCU;
+  h->laCap[i][1] = std::max(1, b8) * h->numCU;
+  return hipSuccess;
+}
+hipError_t solve_la_capacity(blah2hip_clutter_s *h)
+{
+  hipError_t e = solve_la_capacity_e<2>(h, 0);
+  if (e == hipSuccess) e = solve_la_capacity_e<3>(h, 1);
+  if (e == hipSuccess) e = solve_la_capacity_e<6>(h, 2);
+  if (e == hipSuccess) e = solve_la_capacity_e<12>(h, 3);
+  return e;
+}
+int solve_la_cap(const blah2hip_clutter_s *h, int E, int NW)
+{
+  const int i = E == 2 ? 0 : (E == 3 ? 1 : (E == 6 ? 2 : 3));
+  return h->laCap[i][NW == 8 ? 1 : 0];
 }
 
 template <int E> void launch_solve_la(const sla::Args &a, int grid, int nw, hipStream_t st)
@@ -866,6 +908,18 @@ int clutter_plan(blah2hip_clutter_s *h)
   return BLAH2HIP_OK;
 }
 
+// clutter_solve_kernel: one index per thread up to 1024 taps (measured: more, smaller threads win while the recursion is
+// latency-bound), 2 up to 2048, 4 above
+void launch_solve_stepwise(blah2hip_clutter_s *h, const SolveArgs &sa, uint32_t nCpi, hipStream_t st)
+{
+  const size_t sl = ((size_t)2 * (h->nBins + 1)) * sizeof(dcx) + 2 * sizeof(SolveScal);
+  const int kper = h->solveK ? h->solveK : (h->nBins > 2048 ? 4 : (h->nBins > 1024 ? 2 : 1));
+  const int nt = std::min(1024, 64 * ((h->nBins + 64 * kper - 1) / (64 * kper)));
+  if (kper == 1) hipLaunchKernelGGL(clutter_solve_kernel<1>, dim3(nCpi), dim3(nt), sl, st, sa);
+  else if (kper == 2) hipLaunchKernelGGL(clutter_solve_kernel<2>, dim3(nCpi), dim3(nt), sl, st, sa);
+  else hipLaunchKernelGGL(clutter_solve_kernel<4>, dim3(nCpi), dim3(nt), sl, st, sa);
+}
+
 // The Toeplitz solve of nCpi systems whose r, b sit in h->d_rb (the epoch of the look-ahead form's mailboxes has been
 // bumped by the launch in front: clutter_reduce_kernel, or solve_epoch_kernel)
 int launch_solve(blah2hip_clutter_s *h, const SolveArgs &sa, uint32_t nCpi, hipStream_t st)
@@ -877,9 +931,10 @@ int launch_solve(blah2hip_clutter_s *h, const SolveArgs &sa, uint32_t nCpi, hipS
   CHIP(h->timer.tic(BLAH2HIP_CK_SOLVE, st));
   if (h->solveForm != BLAH2HIP_CLUTTER_SOLVE_STEPWISE && h->d_mail) {
     // blocks of 32 orders on several workgroups per CPI (solve_la.hpp): as many CUs per CPI as the launch leaves free
-    const sla::Plan p = sla::choose_plan(h->nBins, (int)nCpi, h->numCU, h->solveE);
+    const sla::Plan p = sla::choose_plan(h->nBins, (int)nCpi, h->numCU, h->solveE, [h](int E, int NW) { return solve_la_cap(h, E, NW); });
     sla::Args la;
     la.rb = sa.rb; la.w = sa.w; la.ok = ok; la.mail = h->d_mail; la.epoch = h->d_epoch; la.fault = h->d_epoch + 1;
+    la.spinLimit = h->spinLimit;
     la.n = h->nBins; la.NB = p.NB; la.nbulk = p.nbulk; la.G = p.G; la.nCpi = (int)nCpi; la.mailStride = p.stride;
     la.offHalo = p.offHalo; la.offFeed = p.offFeed; la.offHaloFlag = p.offHaloFlag; la.offFeedFlag = p.offFeedFlag;
     la.offStatus = p.offStatus;
@@ -892,15 +947,15 @@ int launch_solve(blah2hip_clutter_s *h, const SolveArgs &sa, uint32_t nCpi, hipS
     default: launch_solve_la<12>(la, grid, p.NW, st); break;
     }
     h->lastForm = BLAH2HIP_CLUTTER_SOLVE_LOOKAHEAD; h->lastE = p.E; h->lastG = p.G;
+    CHIP(hipGetLastError());
+    // ... and behind it the one-workgroup kernel, gated per CPI on the fault word of this launch: workgroups that a busy
+    // chip (another handle's kernels, a chip-filling launch on a second stream) dispatched so late that a bounded wait ran
+    // out leave their CPI to it.  No CPI faulted: every workgroup reads one word and leaves (2 us for the launch).
+    SolveArgs ga = sa;
+    ga.gate = h->d_mail + p.offStatus + 1; ga.gateStride = p.stride; ga.retries = h->d_epoch + 2; ga.epoch = h->d_epoch;
+    launch_solve_stepwise(h, ga, nCpi, st);
   } else {
-    // one index per thread up to 1024 taps (measured: more, smaller threads win while the recursion is
-    // latency-bound), 2 up to 2048, 4 above
-    const size_t sl = ((size_t)2 * (h->nBins + 1)) * sizeof(dcx) + 2 * sizeof(SolveScal);
-    const int kper = h->solveK ? h->solveK : (h->nBins > 2048 ? 4 : (h->nBins > 1024 ? 2 : 1));
-    const int nt = std::min(1024, 64 * ((h->nBins + 64 * kper - 1) / (64 * kper)));
-    if (kper == 1) hipLaunchKernelGGL(clutter_solve_kernel<1>, dim3(nCpi), dim3(nt), sl, st, sa);
-    else if (kper == 2) hipLaunchKernelGGL(clutter_solve_kernel<2>, dim3(nCpi), dim3(nt), sl, st, sa);
-    else hipLaunchKernelGGL(clutter_solve_kernel<4>, dim3(nCpi), dim3(nt), sl, st, sa);
+    launch_solve_stepwise(h, sa, nCpi, st);
     h->lastForm = BLAH2HIP_CLUTTER_SOLVE_STEPWISE; h->lastE = 0; h->lastG = 1;
   }
   CHIP(hipGetLastError());
@@ -1064,6 +1119,14 @@ int blah2hip_clutter_get_info(blah2hip_clutter_t h, int what, int64_t *value)
     *value = v;
     return BLAH2HIP_OK;
   }
+  case BLAH2HIP_CLUTTER_INFO_SOLVE_RETRIES: {
+    uint32_t v = 0;
+    CHIP(hipSetDevice(h->device));
+    CHIP(hipDeviceSynchronize());
+    if (h->d_epoch) CHIP(hipMemcpy(&v, h->d_epoch + 2, sizeof(v), hipMemcpyDeviceToHost));
+    *value = v;
+    return BLAH2HIP_OK;
+  }
   default: CFAIL(BLAH2HIP_ERR_INVALID, "unknown info");
   }
 }
@@ -1110,6 +1173,10 @@ int blah2hip_clutter_set_option(blah2hip_clutter_t h, int option, int64_t value)
     if (rc) h->solveE = prev;
     return rc;
   }
+  case BLAH2HIP_CLUTTER_OPT_SOLVE_SPIN_LIMIT:
+    if (value < 0 || value > (int64_t)0x7fffffff) CFAIL(BLAH2HIP_ERR_INVALID, "polls per bounded wait: 0 (default) ... 2^31 - 1");
+    h->spinLimit = value ? (uint32_t)value : sla::SPIN_LIMIT;
+    return BLAH2HIP_OK;
   case BLAH2HIP_CLUTTER_OPT_FIR_CARRY: {
     if (value != 0 && value != 1) CFAIL(BLAH2HIP_ERR_INVALID, "FIR carry: 0 or 1");
     const bool prev = h->firNoCarry;

@@ -701,16 +701,24 @@ struct DopplerArgs {
 // 10*log10|z| = 5*log10(re^2+im^2) = 5*log10(2) * log2(re^2+im^2)
 __device__ __forceinline__ float db_of(cf z) { return 1.50514997831990597607f * log2f(z.x * z.x + z.y * z.y); }
 
-// sum / max over the 256 threads of a workgroup -> one partial per workgroup
-__device__ __forceinline__ void block_metrics_partial(double lsum, float lmax, double *dst_sum, float *dst_max)
+// Map::set_metrics partial of one wave: the lanes' (sum of dB values, largest dB value) folded by a butterfly over the
+// lane index, every lane ending with the wave's result.  One definition for every kernel that fuses the metrics, so
+// the order of the additions -- and with it the bits of noisePower -- is the same whichever Doppler kernel ran.
+__device__ __forceinline__ void wave_sum_max(double &lsum, float &lmax)
 {
-  __shared__ double wsum[4];
-  __shared__ float wmax[4];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     lsum += __shfl_xor(lsum, off);
     lmax = fmaxf(lmax, __shfl_xor(lmax, off));
   }
+}
+
+// sum / max over the 256 threads of a workgroup -> one partial per workgroup
+__device__ __forceinline__ void block_metrics_partial(double lsum, float lmax, double *dst_sum, float *dst_max)
+{
+  __shared__ double wsum[4];
+  __shared__ float wmax[4];
+  wave_sum_max(lsum, lmax);
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { wsum[wave] = lsum; wmax[wave] = lmax; }
   __syncthreads();
@@ -965,11 +973,7 @@ __global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a, 
         lmax = ok ? fmaxf(lmax, db) : lmax;
       }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      lsum += __shfl_xor(lsum, off);
-      lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-    }
+    wave_sum_max(lsum, lmax);
     if (t == 0) { const int wl = relaunder(tid) >> 6; wsum[wl] = lsum; wmax[wl] = lmax; }
     __syncthreads(); // also: every thread has taken its rows out of the regions
     if (tid == 0) {
@@ -1103,11 +1107,7 @@ __global__ __launch_bounds__(1024) void doppler_tile1k_kernel(DopplerArgs a, int
         lmax = ok ? fmaxf(lmax, db) : lmax;
       }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      lsum += __shfl_xor(lsum, off);
-      lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-    }
+    wave_sum_max(lsum, lmax);
     if (t == 0) { const int wl = relaunder(tid) >> 6; wsum[wl] = lsum; wmax[wl] = lmax; }
     __syncthreads(); // also: every thread has taken its rows out of the regions
     if (tid == 0) {
@@ -1261,11 +1261,7 @@ __global__ __launch_bounds__(64 * DOPS_NCOL) void doppler_sub1k_kernel(DopplerAr
       lmax = ok ? fmaxf(lmax, db) : lmax;
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    lsum += __shfl_xor(lsum, off);
-    lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-  }
+  wave_sum_max(lsum, lmax);
   if (t == 0) { ssum[w] = lsum; smax[w] = lmax; }
   __syncthreads();
   if (tid == 0) {
@@ -1469,11 +1465,7 @@ __global__ __launch_bounds__(64 * DOPW_NCOL, 2) void doppler_tilew_kernel(Dopple
         lmax = ok1 ? fmaxf(lmax, db1) : lmax;
       }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      lsum += __shfl_xor(lsum, off);
-      lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-    }
+    wave_sum_max(lsum, lmax);
     if (t == 0) { const int wl = relaunder(tid) >> 6; wsum[wl] = lsum; wmax[wl] = lmax; }
     DW_T(6)
     __syncthreads(); // also: every thread has taken its rows out of the regions
@@ -1659,11 +1651,7 @@ __global__ __launch_bounds__(128 * DOPW2_NCOL, 2) void doppler_tilew2_kernel(Dop
         lmax = ok1 ? fmaxf(lmax, db1) : lmax;
       }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      lsum += __shfl_xor(lsum, off);
-      lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-    }
+    wave_sum_max(lsum, lmax);
     if (lane == 0) { const int wl = relaunder(tid) >> 6; wsum[wl] = lsum; wmax[wl] = lmax; }
     __syncthreads(); // also: every thread has taken its rows out of the regions
     if (tid == 0 && live) {
@@ -1828,11 +1816,7 @@ __global__ __launch_bounds__(1024) void doppler_tilem_kernel(DopplerArgs a)
   const size_t part = (size_t)cpi * gridDim.x + blockIdx.x;
   __shared__ double wsum[16];
   __shared__ float wmax[16];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    lsum += __shfl_xor(lsum, off);
-    lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-  }
+  wave_sum_max(lsum, lmax);
   if ((tid & 63) == 0) { wsum[tid >> 6] = lsum; wmax[tid >> 6] = lmax; }
   __syncthreads();
   if (tid == 0) {

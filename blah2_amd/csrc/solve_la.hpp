@@ -45,7 +45,7 @@
 namespace sla {
 
 constexpr int KB = 32;                 // orders per block = halo width = sub-window width
-constexpr unsigned SPIN_LIMIT = 1u << 20;
+constexpr unsigned SPIN_LIMIT = 1u << 20; // polls of a bounded wait (about a second); Args::spinLimit, a test can lower it
 
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
@@ -57,7 +57,8 @@ struct Args {
   int32_t *ok;       // [nCpi]
   u64 *mail;         // [nCpi][mailStride]
   const uint32_t *epoch;
-  uint32_t *fault;   // set when a bounded spin ran out
+  uint32_t *fault;   // set when a bounded spin ran out (sticky, per handle: a diagnostic)
+  uint32_t spinLimit; // polls before a wait gives up
   int32_t n, NB, nbulk, G, nCpi;
   int64_t mailStride;                                   // u64 words per CPI
   int64_t offHalo, offFeed, offHaloFlag, offFeedFlag, offStatus; // coefficient granules at 0
@@ -70,18 +71,35 @@ __device__ __forceinline__ void st_d(u64 *p, double v) { st64(p, (u64)__double_a
 __device__ __forceinline__ double ld_d(const u64 *p) { return __longlong_as_double((long long)ld64(p)); }
 __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-__device__ __forceinline__ bool spin_fail(unsigned &spins, uint32_t *fault)
+// What a wave does when a bounded wait runs out: the handle's sticky fault word (a diagnostic) and the CPI's own fault word
+// in its mailbox (offStatus + 1 = this launch's tag).  The launch that follows on the stream (clutter_solve_kernel, gated
+// on that word) then solves the CPI again in ONE workgroup, which waits for nobody: a wait that ran out -- workgroups of
+// this launch that a busy chip dispatched late -- costs time, never a result, and is never mistaken for "not positive
+// definite" (WienerHopf.cpp:111-115).
+struct FaultRef {
+  uint32_t *sticky;
+  u64 *cpiWord;
+  uint32_t tag;
+  unsigned limit;
+};
+__device__ __forceinline__ FaultRef fault_ref(const Args &a, int cpi, uint32_t tag)
+{
+  return FaultRef{a.fault, a.mail + (size_t)cpi * a.mailStride + a.offStatus + 1, tag, a.spinLimit};
+}
+
+__device__ __forceinline__ bool spin_fail(unsigned &spins, const FaultRef &f)
 {
   __builtin_amdgcn_s_sleep(1);
-  if (++spins > SPIN_LIMIT) {
-    __hip_atomic_store((gu32 *)fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (++spins > f.limit) {
+    __hip_atomic_store((gu32 *)f.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st64(f.cpiWord, (u64)f.tag);
     return true;
   }
   return false;
 }
 
 // one relaxed poll of ONE word until it carries this launch's tag
-__device__ __forceinline__ bool wait_flag(const u64 *flag, uint32_t tag, uint32_t *fault)
+__device__ __forceinline__ bool wait_flag(const u64 *flag, uint32_t tag, const FaultRef &fault)
 {
   for (unsigned spins = 0;;) {
     const u64 v = ld64(flag);
@@ -93,7 +111,7 @@ __device__ __forceinline__ bool wait_flag(const u64 *flag, uint32_t tag, uint32_
 }
 
 // a chunk of 8 orders = 64 granules, lane L <-> field (L & 7) of order (L >> 3)
-__device__ __forceinline__ bool sweep_chunk(const u64 *g, int lane, uint32_t tag, uint32_t *fault, uint32_t &val)
+__device__ __forceinline__ bool sweep_chunk(const u64 *g, int lane, uint32_t tag, const FaultRef &fault, uint32_t &val)
 {
   for (unsigned spins = 0;;) {
     const u64 x = ld64(g + lane);
@@ -223,7 +241,7 @@ struct PairLds {
   unsigned bad;          // one of the two has given up (not positive definite, or a bounded wait ran out)
 };
 
-__device__ __forceinline__ bool lds_wait_count(const unsigned *p, unsigned want, const unsigned *bad, uint32_t *fault)
+__device__ __forceinline__ bool lds_wait_count(const unsigned *p, unsigned want, const unsigned *bad, const FaultRef &fault)
 {
   for (unsigned spins = 0;;) {
     const unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -238,12 +256,13 @@ __device__ __forceinline__ bool lds_wait_count(const unsigned *p, unsigned want,
 
 __device__ __forceinline__ void front_chain(const Args &a, int cpi, uint32_t tag, int lane, PairLds *pl)
 {
+  const FaultRef fr = fault_ref(a, cpi, tag);
   const int n = a.n, NB = a.NB;
   const dcx *r = a.rb + (size_t)cpi * 2 * n, *b = r + n;
   u64 *mail = a.mail + (size_t)cpi * a.mailStride;
   u64 *coef = mail;
   __builtin_amdgcn_s_setprio(3);
-  if (lane == 0) a.ok[cpi] = 0; // stays 0 if a bounded wait runs out
+  if (lane == 0) a.ok[cpi] = 0; // stays 0 if a bounded wait runs out (the gated launch behind this one then decides)
   const double r0 = r[0].x;
   bool bad = !(r0 > 0.0) || !isfinite(r0);
   double inv_s = bad ? 0.0 : 1.0 / r0;
@@ -387,7 +406,7 @@ __device__ __forceinline__ void front_chain(const Args &a, int cpi, uint32_t tag
     SLA_LAP(tr1);
     if (blk + 1 >= NB) break;
     // the next triangle: W_(blk+1), valid through this block, from the companion
-    if (!lds_wait_count(&pl->handseq[0], (unsigned)blk + 1u, &pl->bad, a.fault)) return;
+    if (!lds_wait_count(&pl->handseq[0], (unsigned)blk + 1u, &pl->bad, fr)) return;
     {
       const int l = lane & 31;
       const double u0 = pl->hand[0][l], u1 = pl->hand[1][l], v0 = pl->hand[2][l], v1 = pl->hand[3][l], z0 = pl->hand[4][l], z1 = pl->hand[5][l];
@@ -416,6 +435,7 @@ __device__ __forceinline__ void front_chain(const Args &a, int cpi, uint32_t tag
 
 __device__ __forceinline__ void front_companion(const Args &a, int cpi, uint32_t tag, int lane, PairLds *pl)
 {
+  const FaultRef fr = fault_ref(a, cpi, tag);
   const int n = a.n, NB = a.NB;
   const dcx *r = a.rb + (size_t)cpi * 2 * n, *b = r + n;
   u64 *mail = a.mail + (size_t)cpi * a.mailStride;
@@ -439,7 +459,7 @@ __device__ __forceinline__ void front_companion(const Args &a, int cpi, uint32_t
         D.Ur[0] = rot32(D.Ur[0], lane); D.Ui[0] = rot32(D.Ui[0], lane); D.Vr[0] = rot32(D.Vr[0], lane);
         D.Vi[0] = rot32(D.Vi[0], lane); D.Zr[0] = rot32(D.Zr[0], lane); D.Zi[0] = rot32(D.Zi[0], lane);
         const int wb = blk + 1;
-        if (!wait_flag(mail + a.offFeedFlag + wb, tag, a.fault)) { __hip_atomic_store(&pl->bad, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
+        if (!wait_flag(mail + a.offFeedFlag + wb, tag, fr)) { __hip_atomic_store(&pl->bad, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
         if (!lo) {
           const u64 *p = mail + a.offFeed + ((size_t)wb * KB + (lane - 32)) * 6;
           D.Ur[0] = ld_d(p + 0); D.Ui[0] = ld_d(p + 1); D.Vr[0] = ld_d(p + 2);
@@ -447,7 +467,7 @@ __device__ __forceinline__ void front_companion(const Args &a, int cpi, uint32_t
         }
       }
       SLA_LAP(trf);
-      if (!lds_wait_count(&pl->seq[0], 4u * (unsigned)blk, &pl->bad, a.fault)) return;
+      if (!lds_wait_count(&pl->seq[0], 4u * (unsigned)blk, &pl->bad, fr)) return;
       const Coef *cp = pl->rec[(blk - 1) & 1];
 #pragma unroll 1
       for (int c = 0; c < 4; c++) apply_chunk<1, false>(D, cp + 8 * c, lane, 0);
@@ -465,7 +485,7 @@ __device__ __forceinline__ void front_companion(const Args &a, int cpi, uint32_t
     const Coef *cq = pl->rec[blk & 1];
 #pragma unroll 1
     for (int c = 0; c < 4; c++) {
-      if (!lds_wait_count(&pl->seq[0], 4u * (unsigned)blk + (unsigned)c + 1u, &pl->bad, a.fault)) return;
+      if (!lds_wait_count(&pl->seq[0], 4u * (unsigned)blk + (unsigned)c + 1u, &pl->bad, fr)) return;
       apply_chunk<1, false>(C, cq + 8 * c, lane, 0);
     }
     // hand C.hi = W_(blk+1), valid through this block, over
@@ -487,6 +507,7 @@ __device__ __forceinline__ void front_companion(const Args &a, int cpi, uint32_t
 // ---- a bulk wave ----------------------------------------------------------------------------------------------------
 template <int E> __device__ __forceinline__ void bulk(const Args &a, int cpi, uint32_t tag, int lane, int q, Coef *cl)
 {
+  const FaultRef fr = fault_ref(a, cpi, tag);
   constexpr int S = 64 * E - KB, P = 64 * E;
   const int n = a.n, NB = a.NB;
   const dcx *r = a.rb + (size_t)cpi * 2 * n, *b = r + n;
@@ -515,7 +536,7 @@ template <int E> __device__ __forceinline__ void bulk(const Args &a, int cpi, ui
       // this chunk's granules were requested before the previous chunk's orders; re-read until every tag is this launch's
       u64 x = pre;
       for (unsigned spins = 0; !__all((uint32_t)(x >> 32) == tag);) {
-        if (spin_fail(spins, a.fault)) return;
+        if (spin_fail(spins, fr)) return;
         x = ld64(coef + ((size_t)(KB * blk + 8 * c)) * 8 + lane);
       }
       if (4 * blk + c + 1 < 4 * NB) pre = ld64(coef + ((size_t)(KB * blk + 8 * c + 8)) * 8 + lane);
@@ -562,7 +583,7 @@ template <int E> __device__ __forceinline__ void bulk(const Args &a, int cpi, ui
     SLA_LAP(trp);
     // own halo from the wave below (wave 0: the positions below index 0 are exact zeros, nothing creeps in)
     if (q > 0) {
-      if (!wait_flag(mail + a.offHaloFlag + (size_t)(q - 1) * NB + blk, tag, a.fault)) return;
+      if (!wait_flag(mail + a.offHaloFlag + (size_t)(q - 1) * NB + blk, tag, fr)) return;
       const u64 *h = mail + a.offHalo + ((size_t)(q - 1) * NB + blk) * (KB * 6);
 #pragma unroll
       for (int e = 0; e < E; e++) {
@@ -646,18 +667,23 @@ inline Plan make_plan(int n, int E, int NW)
 }
 constexpr int kE[4] = {2, 3, 6, 12};
 // narrowest slices (lowest latency per block) whose workgroups all get a CU of their own, four waves per workgroup before
-// eight; the widest slices otherwise
-inline Plan choose_plan(int n, int nCpi, int numCU, int forceE)
+// eight; the widest slices otherwise.  `capacity(E, NW)` = workgroups of that instantiation the chip holds at once
+// (occupancy x CUs): a plan whose G > 1 workgroups per CPI wait for each other is only used when the whole grid fits --
+// also when a slice width is forced -- else the one-workgroup-per-CPI plan (E = 12, eight waves: G = 1 up to 4417 taps,
+// nothing to wait for outside the workgroup).
+template <class Cap> inline Plan choose_plan(int n, int nCpi, int numCU, int forceE, Cap capacity)
 {
   const int64_t groups = (nCpi + 7) / 8 * 8;
   for (int E : kE) {
     if (forceE && E != forceE) continue;
     for (int NW : {4, 8}) {
       const Plan p = make_plan(n, E, NW);
-      if ((int64_t)p.G * groups <= numCU) return p;
+      if ((int64_t)p.G * groups <= std::min<int64_t>(numCU, capacity(E, NW))) return p;
     }
   }
-  return make_plan(n, forceE ? forceE : 12, 8);
+  const Plan p = make_plan(n, forceE ? forceE : 12, 8);
+  if (p.G > 1 && (int64_t)p.G * groups > capacity(p.E, p.NW)) return make_plan(n, 12, 8);
+  return p;
 }
 
 } // namespace sla

@@ -464,6 +464,11 @@ class WienerHopf:
         check(self._L.blah2hip_clutter_set_option(self._h, _lib.CLUTTER_OPT_SOLVE_FORM, int(which)))
         check(self._L.blah2hip_clutter_set_option(self._h, _lib.CLUTTER_OPT_SOLVE_E, int(indices_per_lane)))
 
+    def set_solve_spin_limit(self, polls):
+        """Polls after which a wait of the look-ahead solve gives up (0 = default, about a second).  Tests: a CPI whose
+        solve gave up is solved again by the one-workgroup kernel behind it, so the result does not change."""
+        check(self._L.blah2hip_clutter_set_option(self._h, _lib.CLUTTER_OPT_SOLVE_SPIN_LIMIT, int(polls)))
+
     def solve(self, r, b):
         """The filter's Toeplitz solve alone: toeplitz(r) w = b for [n_cpi][nBins] (or [nBins]) complex r, b.
         Returns (ok[n_cpi] bool, w[n_cpi][nBins] complex64)."""
@@ -482,10 +487,12 @@ class WienerHopf:
         check(self._L.blah2hip_clutter_solve_dev(self._h, d_rb, n_cpi, d_w, d_ok, stream))
 
     def solve_info(self):
-        """What the last call's Toeplitz solve ran: {'form', 'E' (indices per lane), 'G' (workgroups per CPI), 'fault'}."""
+        """What the last call's Toeplitz solve ran: {'form', 'E' (indices per lane), 'G' (workgroups per CPI), 'fault' (sticky:
+        a bounded wait of the look-ahead form ran out at some point), 'retries' (CPIs the gated one-workgroup kernel has solved)}."""
         out = {}
         for name, what in (("form", _lib.CLUTTER_INFO_SOLVE_FORM), ("E", _lib.CLUTTER_INFO_SOLVE_E),
-                           ("G", _lib.CLUTTER_INFO_SOLVE_G), ("fault", _lib.CLUTTER_INFO_SOLVE_FAULT)):
+                           ("G", _lib.CLUTTER_INFO_SOLVE_G), ("fault", _lib.CLUTTER_INFO_SOLVE_FAULT),
+                           ("retries", _lib.CLUTTER_INFO_SOLVE_RETRIES)):
             v = C.c_int64(0)
             check(self._L.blah2hip_clutter_get_info(self._h, what, C.byref(v)))
             out[name] = int(v.value)

@@ -341,10 +341,46 @@ class GpuChain:
 
         import blah2_amd
         self.torch, self.b2 = torch, blah2_amd
-        # before any pinned allocation and before the reader threads exist: everything host-side on the GPU's NUMA node
-        # (EPYC 9575F x 2, tools/gpu_hostreg.py: a reader thread copies 17-19 GB/s inside the node, 12.5 when the scheduler
-        # puts it on the other socket; four threads 51-54 GB/s against 41)
-        self.numa_pinned = pin_to_device_node(torch, device) if numa else False
+        # The host side of the ring on the GPU's NUMA node (EPYC 9575F x 2, tools/gpu_hostreg.py: a reader thread copies
+        # 17-19 GB/s inside the node, 12.5 when the scheduler puts it on the other socket; four threads 51-54 GB/s against
+        # 41): the chain's OWN threads pin themselves when they start, and the pinned buffers are allocated (first touch)
+        # with the calling thread on the node for the length of that allocation only -- the caller's affinity is what it
+        # was when the constructor returns (a host program that builds chains for several devices, or has threads of its
+        # own, is not narrowed to the last GPU's node).
+        self._node_cpus = device_numa_cpus(torch, device) if numa else None
+        self.numa_pinned = bool(self._node_cpus)
+        with self._on_node():
+            self._build(cfg, device, batch, want_map, depth, reader_threads, hit_copy, read_mode)
+
+    def _pin_worker(self):
+        if self._node_cpus:
+            try:
+                os.sched_setaffinity(0, self._node_cpus)  # the calling thread only
+            except OSError:
+                pass
+
+    def _on_node(self):
+        """The calling thread on the GPU's node for the length of a ``with`` block (pinned allocations), then back."""
+        chain = self
+
+        class _Ctx:
+            def __enter__(self):
+                self.prev = None
+                if chain._node_cpus:
+                    try:
+                        self.prev = os.sched_getaffinity(0)
+                        os.sched_setaffinity(0, chain._node_cpus)
+                    except OSError:
+                        self.prev = None
+
+            def __exit__(self, *exc):
+                if self.prev is not None:
+                    os.sched_setaffinity(0, self.prev)
+                return False
+        return _Ctx()
+
+    def _build(self, cfg, device, batch, want_map, depth, reader_threads, hit_copy, read_mode):
+        torch, blah2_amd = self.torch, self.b2
         amb_c, det_c, clu_c = cfg["ambiguity"], cfg.get("detection", {}), cfg.get("clutter", {})
         self.fs, self.n = int(cfg["fs"]), int(cfg["n_samples"])
         n, B = self.n, int(batch)
@@ -368,8 +404,8 @@ class GpuChain:
         self.hit_copy = min(self.cap, int(hit_copy))
         self.compute = torch.cuda.Stream(device=dev)
         self.copy = torch.cuda.Stream(device=dev)
-        self.pool = ThreadPoolExecutor(max_workers=max(1, reader_threads))
-        self._bg = ThreadPoolExecutor(max_workers=1)  # starts and awaits a batch's read while the main thread works on another
+        self.pool = ThreadPoolExecutor(max_workers=max(1, reader_threads), initializer=self._pin_worker)
+        self._bg = ThreadPoolExecutor(max_workers=1, initializer=self._pin_worker)  # starts and awaits a batch's read while the main thread works on another
         self.reader_threads = max(1, reader_threads)
         # How a batch gets from the page cache to the copy engine (tools/gpu_hostreg.py, tools/replay_bench.py; MI355X host):
         #   "memmove"  reader threads copy out of the file's shared mapping into a pinned ring (page tables filled by madvise
@@ -439,7 +475,8 @@ class GpuChain:
             print(f"[blah2_amd.replay] hipHostRegister of the mapped capture failed ({hip.hipGetErrorString(max(rcs)).decode()}): "
                   "copying into a pinned buffer instead", file=sys.stderr)
         if slot["h_iq"] is None:
-            slot["h_iq"] = self.torch.empty((self.batch, self.n, 4), dtype=self.torch.int16).pin_memory()
+            with self._on_node():
+                slot["h_iq"] = self.torch.empty((self.batch, self.n, 4), dtype=self.torch.int16).pin_memory()
         capture.read_into(k0, cnt, slot["h_iq"].numpy(), self.pool, self.reader_threads, how=self.read_mode)
 
     def _release(self, slot: dict):
@@ -562,7 +599,8 @@ class GpuChain:
         cnt = iq.shape[0]
         slot = self.slots[0]
         if slot["h_iq"] is None:
-            slot["h_iq"] = self.torch.empty((self.batch, self.n, 4), dtype=self.torch.int16).pin_memory()
+            with self._on_node():
+                slot["h_iq"] = self.torch.empty((self.batch, self.n, 4), dtype=self.torch.int16).pin_memory()
         slot["h_iq"][:cnt].copy_(self.torch.from_numpy(np.ascontiguousarray(iq)))
         slot["mapped"] = None
         self._submit(slot, cnt)

@@ -314,16 +314,25 @@ int blah2hip_clutter_process_dev_fmt(blah2hip_clutter_t h, int fmt, const void *
  * F = 4096) runs on blocks of exactly F/2 samples and the FIR kernel carries the window overlap in registers; 0 = blocks of
  * F - nBins + 1 samples, every window read whole (tests, A/B timing). */
 #define BLAH2HIP_CLUTTER_OPT_FIR_CARRY 6
+/* SOLVE_SPIN_LIMIT (tests): polls after which a wait of the look-ahead solve gives up (0 = default, 2^20, about a second).
+ * A CPI whose solve gave up is solved again by the one-workgroup kernel enqueued behind it, so a low limit changes the
+ * time, not the result. */
+#define BLAH2HIP_CLUTTER_OPT_SOLVE_SPIN_LIMIT 7
 #define BLAH2HIP_CLUTTER_SOLVE_AUTO 0
 #define BLAH2HIP_CLUTTER_SOLVE_STEPWISE 1
 #define BLAH2HIP_CLUTTER_SOLVE_LOOKAHEAD 2
 int blah2hip_clutter_set_option(blah2hip_clutter_t h, int option, int64_t value);
-/* What the last process call launched: the solve's form, indices per lane and workgroups per CPI; SOLVE_FAULT reads
- * (synchronising) the word a look-ahead solve sets when one of its bounded waits ran out -- ok is 0 for that CPI. */
+/* What the last process call launched: the solve's form, indices per lane and workgroups per CPI.  The look-ahead
+ * form's workgroups wait for each other with BOUNDED waits; a CPI whose wait ran out (workgroups dispatched late on a chip
+ * busy with other work) is solved again by the one-workgroup kernel that every look-ahead launch has behind it, gated per
+ * CPI, so ok = 0 always and only means "not positive definite" (WienerHopf.cpp:111-115).  SOLVE_FAULT reads
+ * (synchronising) the sticky word set when any wait ran out since the handle was created, SOLVE_RETRIES how many CPIs the
+ * gated kernel has solved. */
 #define BLAH2HIP_CLUTTER_INFO_SOLVE_FORM 1
 #define BLAH2HIP_CLUTTER_INFO_SOLVE_E 2
 #define BLAH2HIP_CLUTTER_INFO_SOLVE_G 3
 #define BLAH2HIP_CLUTTER_INFO_SOLVE_FAULT 4
+#define BLAH2HIP_CLUTTER_INFO_SOLVE_RETRIES 5
 int blah2hip_clutter_get_info(blah2hip_clutter_t h, int what, int64_t *value);
 /* The filter's Toeplitz solve on its own: n_cpi systems toeplitz(r) w = b given as rb = [n_cpi][2][nBins] complex fp64 (r then b,
  * interleaved re, im; the layout blah2hip_clutter_read_last returns), taps to w ([n_cpi][nBins] complex fp32), ok[c] = 0

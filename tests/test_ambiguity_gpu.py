@@ -184,20 +184,21 @@ def test_batched_device_chain_matches_single(b2):
     assert abs(mt[1, 1] - g["metrics"][1]) <= DB_TOL  # dynamic range is scale-free
 
 
-# Map::to_json writes data[i][j] = 10*log10|M| - noisePower with two decimals
-# (Map.cpp:115-185).  SURVEY.md 8d gate: |delta dB| <= 0.005 on every cell of the map
-# (measured 0.0024 / 0.0009 on the two configurations below).
+# Map::to_json writes data[i][j] = 10*log10|M| - noisePower with two decimals (Map.cpp:115-185).  SURVEY.md 8d gate:
+# |delta dB| <= 0.005 on the JSON map -- stated once in tests/gates.py (every cell down to 20 dB below the mean level,
+# which is 20 dB below what html/js/plot_map.js:170 can show; below that the absolute error 0.005 dB means at that
+# line).  At these two sizes (3e5 / 2e5 cells) no cell at all exceeds 0.005 dB (measured 0.0024 / 0.0009).
 @pytest.mark.parametrize("args", [(-10, 300, -300, 300, 2_000_000, 1_000_000, True),
                                   (-10, 400, -256, 256, 2_000_000, 2_000_000, True)])
 def test_json_db_map_within_half_a_hundredth(b2, args):
+    from gates import db_map_gate
     fs, n = args[4], args[5]
     x, y = O.synth_iq(n, fs=fs, seed=7)
     m = b2.Ambiguity(*args).process(x, y)
     ref = O.ambiguity_process(O.ambiguity_dims(*args), x, y)
-    noise, _ = O.map_metrics(ref)
-    got_db = 10.0 * np.log10(np.abs(m.data.astype(np.complex128))) - m.noisePower
-    ref_db = 10.0 * np.log10(np.abs(ref)) - noise
-    assert np.max(np.abs(got_db - ref_db)) <= 0.005
+    g = db_map_gate(m.data, m.noisePower, ref)
+    assert g["ok"], g
+    assert g["db_max_all"] <= 0.005, g   # stronger than the gate, and true at these sizes
 
 
 def test_device_db_map_matches_to_json_values(b2):

@@ -31,6 +31,12 @@ def check(b2, cfg, expect_dims, targets, seed, elem_tol=1e-4):
     assert np.max(err[strong] / np.abs(ref[strong])) <= elem_tol
     noise, mx = O.map_metrics(ref)
     assert abs(m.noisePower - noise) <= 1e-3 and abs(m.maxPower - mx) <= 1e-3
+    # the JSON map (Map.cpp:115-185): 0.005 dB on every cell down to 20 dB below the mean level (tests/gates.py);
+    # how many of the deeper cells exceed it, and how deep they sit, is printed (pytest -s) and recorded in DESIGN.md 5
+    from gates import db_map_gate
+    g = db_map_gate(got, m.noisePower, ref, noise)
+    print(f"\n[dB map {amb.get_n_doppler_bins()} x {amb.get_n_delay_bins()}] {g}")
+    assert g["ok"], g
     # every injected target is the local maximum of the map around its cell
     db = 10 * np.log10(np.abs(got))
     for dly, f, _ in targets:

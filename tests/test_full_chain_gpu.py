@@ -169,7 +169,7 @@ def test_full_chain_cfg3(b2, cfg3_data, cfg3_oracle_filter):
           f"cell-rel (within 20 dB of peak, {strong.sum()} cells) {np.max(err[strong] / np.abs(m_ref[strong])):.2e}  "
           f"noise {m.noisePower:.4f} vs {noise_ref:.4f}  max {m.maxPower:.4f} vs {max_ref:.4f}")
     assert err.max() / direct_level <= 1e-4
-    assert np.max(err[strong] / np.abs(m_ref[strong])) <= 1e-3
+    assert np.max(err[strong] / np.abs(m_ref[strong])) <= 1e-4  # north_star: 1e-4 (measured 2e-7 ... 3e-7)
     assert abs(m.noisePower - noise_ref) <= 1e-3 and abs(m.maxPower - max_ref) <= 1e-3
     hn = hits.cpu().numpy().view(b2.HIT_DTYPE).reshape(1, cap)
     det = b2.hits_to_detection(amb, hn[0], int(cnt.item()), cap)
@@ -305,7 +305,7 @@ def test_full_chain_matches_compiled_reference(b2):
     print(f"\n[medium chain] err/peak {err.max() / peak:.2e} err/direct {err.max() / direct_level:.2e} "
           f"cell-rel {np.max(err[strong] / np.abs(ref[strong])):.2e} noise {m.noisePower - g['chain_metrics'][0]:.2e}")
     assert err.max() / direct_level <= 1e-4
-    assert np.max(err[strong] / np.abs(ref[strong])) <= 1e-3
+    assert np.max(err[strong] / np.abs(ref[strong])) <= 1e-4  # north_star: 1e-4 (measured 2e-7 ... 3e-7)
     assert abs(m.noisePower - g["chain_metrics"][0]) <= 1e-3
     det = b2.CfarDetector1D(pfa, int(ng), int(nt), int(md), mdop).process(m)
     ref_set = set(zip(g["chain_cfar"][0], g["chain_cfar"][1]))

@@ -120,3 +120,79 @@ def test_the_planner_spreads_a_small_batch_and_packs_a_large_one(b2):
         assert ok.all()
         for c in (0, B - 1):
             assert np.linalg.norm(w[c] - ref) / np.linalg.norm(ref) <= 1e-6
+
+
+# ---- the look-ahead form beside other work: bounded waits that run out cost time, never a result -------------------------
+
+@pytest.mark.parametrize("E", [0, 2, 6])
+@pytest.mark.parametrize("n", [410, 2047])
+def test_a_wait_that_runs_out_is_solved_again_not_reported_as_not_positive_definite(b2, n, E):
+    """A spin limit of ONE poll makes the look-ahead form's waits run out at once (what a chip busy with other kernels does
+    to workgroups it dispatches late): the one-workgroup kernel gated behind the launch solves those CPIs again -- same
+    taps, ok = 1 -- and a matrix that really is not positive definite still comes back ok = 0 (WienerHopf.cpp:111-115)."""
+    B = 5
+    rs, bs = map(list, zip(*(normal_equations(n, 0.1 * c, 50 * n + c) for c in range(B))))
+    rs[3] = rs[3].copy()
+    rs[3][n // 2] = 1.5 * abs(rs[3][0])
+    wh = handle(b2, n, max_batch=B)
+    wh.set_solve_form("lookahead", E)
+    wh.set_solve_spin_limit(1)
+    ok, w = wh.solve(np.stack(rs), np.stack(bs))
+    info = wh.solve_info()
+    assert info["form"] == 2 and info["G"] > 1      # several workgroups per CPI: the form that waits
+    assert info["fault"] == 1 and info["retries"] >= 1, info
+    assert ok.tolist() == [True, True, True, False, True]
+    assert not w[3].any()
+    for c in (0, 1, 2, 4):
+        ref = np.linalg.solve(toeplitz(rs[c]), bs[c])
+        assert np.linalg.norm(w[c] - ref) / np.linalg.norm(ref) <= 1e-6, c
+    # back at the default limit the same handle solves without a retry
+    wh.set_solve_spin_limit(0)
+    before = wh.solve_info()["retries"]
+    ok, w2 = wh.solve(np.stack(rs), np.stack(bs))
+    assert wh.solve_info()["retries"] == before
+    assert ok.tolist() == [True, True, True, False, True]
+    for c in (0, 1, 2, 4):
+        ref = np.linalg.solve(toeplitz(rs[c]), bs[c])
+        assert np.linalg.norm(w2[c] - ref) / np.linalg.norm(ref) <= 1e-6, c
+
+
+def test_two_handles_on_two_streams_and_a_chip_filling_kernel_beside_them(b2):
+    """Two filter handles enqueue their look-ahead solves (G > 1: workgroups that wait for each other) on two streams at
+    the same time, round after round, while a third stream keeps the chip full with the batched range kernel of
+    BASELINE configs[1] (persistent workgroups on every CU).  Every solve agrees with LAPACK, no wait ran out for good
+    (retries are allowed -- they are the mechanism -- and counted)."""
+    import torch
+    n, B = 410, 2
+    whs = [handle(b2, n, max_batch=B) for _ in range(2)]
+    for wh in whs:
+        wh.set_solve_form("lookahead", 0)
+    sys_ = [[normal_equations(n, 0.2 * (c + 1), 9000 + 10 * h + c) for c in range(B)] for h in range(2)]
+    d_rb = [torch.from_numpy(np.stack([np.stack([r, b]) for r, b in s])).cuda() for s in sys_]
+    d_w = [torch.zeros((B, n), dtype=torch.complex64, device="cuda") for _ in range(2)]
+    d_ok = [torch.full((B,), -7, dtype=torch.int32, device="cuda") for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    # the chip-filling neighbour: 16 CPIs of configs[1] per launch on the one-wave range kernel + the tile Doppler kernel
+    geom = (-10, 400, -256, 256, 2_000_000, 2_000_000)
+    nb = 16
+    amb = b2.Ambiguity(*geom, True, max_batch=nb)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    x = torch.view_as_complex(300 * torch.randn((nb, geom[5], 2), generator=g, device="cuda"))
+    y = torch.view_as_complex(300 * torch.randn((nb, geom[5], 2), generator=g, device="cuda"))
+    torch.cuda.synchronize()
+    for rnd in range(20):
+        for _ in range(2):
+            amb.process_dev(b2.FMT_C32, x.data_ptr(), y.data_ptr(), nb, geom[5], None, None, streams[2].cuda_stream)
+        for h in range(2):
+            whs[h].solve_dev(d_rb[h].data_ptr(), B, d_w[h].data_ptr(), d_ok[h].data_ptr(), streams[h].cuda_stream)
+    torch.cuda.synchronize()
+    infos = [wh.solve_info() for wh in whs]
+    print(f"\n[solve beside other work] {infos}")
+    for h in range(2):
+        assert infos[h]["form"] == 2 and infos[h]["G"] > 1
+        assert d_ok[h].cpu().tolist() == [1] * B
+        w = d_w[h].cpu().numpy()
+        for c, (r, b) in enumerate(sys_[h]):
+            ref = np.linalg.solve(toeplitz(r), b)
+            assert np.linalg.norm(w[c] - ref) / np.linalg.norm(ref) <= 1e-6, (h, c)

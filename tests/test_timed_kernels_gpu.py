@@ -39,7 +39,7 @@ def assert_cpi(got, met, ref, tag, cell_tol=CELL_TOL):
 
 
 def run_batch(b2, geom, B, kernel, seeds, fmt="c32", expect=None, cell_tol=CELL_TOL, targets=((37, -63.0, 0.05),),
-              range_kernel=0, doppler_grid=0, range_grid=0, fft_len=0):
+              range_kernel=0, doppler_grid=0, range_grid=0, fft_len=0, db_gate=False, synth=None):
     """B distinct CPIs through blah2hip_amb_process_dev in ONE call; every CPI against the oracle."""
     import torch
     dmin, dmax, fmin, fmax, fs, n = geom
@@ -54,7 +54,8 @@ def run_batch(b2, geom, B, kernel, seeds, fmt="c32", expect=None, cell_tol=CELL_
         amb.set_doppler_grid(doppler_grid)
     if range_grid:
         amb.set_range_grid(range_grid)
-    xs, ys = zip(*(O.synth_iq(n, seed=s, fs=fs, targets=targets) for s in seeds))
+    synth = synth or O.synth_iq
+    xs, ys = zip(*(synth(n, seed=s, fs=fs, targets=targets, quantise=(fmt != "f16")) for s in seeds))
     nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
     out = torch.zeros((B, nD, nC), dtype=torch.complex64, device="cuda")
     met = torch.zeros((B, 2), dtype=torch.float64, device="cuda")
@@ -63,6 +64,15 @@ def run_batch(b2, geom, B, kernel, seeds, fmt="c32", expect=None, cell_tol=CELL_
         x = torch.from_numpy(np.stack(xs).astype(np.complex64)).cuda()
         y = torch.from_numpy(np.stack(ys).astype(np.complex64)).cuda()
         amb.process_dev(b2.FMT_C32, x.data_ptr(), y.data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
+    elif fmt == "f16":
+        # fp16 IQ storage (BASELINE configs[4]): the oracle is fed the ALREADY-QUANTISED values,
+        # so that storage error is not counted as kernel error
+        xh = np.stack([np.stack([x_.real, x_.imag], axis=-1) for x_ in xs]).astype(np.float16)
+        yh = np.stack([np.stack([y_.real, y_.imag], axis=-1) for y_ in ys]).astype(np.float16)
+        xs = [h[:, 0].astype(np.float64) + 1j * h[:, 1].astype(np.float64) for h in xh]
+        ys = [h[:, 0].astype(np.float64) + 1j * h[:, 1].astype(np.float64) for h in yh]
+        x, y = torch.from_numpy(xh).cuda(), torch.from_numpy(yh).cuda()
+        amb.process_dev(b2.FMT_F16, x.data_ptr(), y.data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
     else:
         iq = np.stack([np.stack([x_.real, x_.imag, y_.real, y_.imag], axis=-1) for x_, y_ in zip(xs, ys)]).astype(np.int16)
         d = torch.from_numpy(iq).cuda()
@@ -74,7 +84,13 @@ def run_batch(b2, geom, B, kernel, seeds, fmt="c32", expect=None, cell_tol=CELL_
     d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True)
     assert (d.n_doppler_bins, d.n_delay_bins) == (nD, nC)
     for c in range(B):
-        assert_cpi(o[c], m[c], O.ambiguity_process(d, xs[c], ys[c]), f"cpi {c} of {B} [{ran}]", cell_tol)
+        ref = O.ambiguity_process(d, xs[c], ys[c])
+        assert_cpi(o[c], m[c], ref, f"cpi {c} of {B} [{ran}]", cell_tol)
+        if db_gate:  # the JSON-map gate of tests/gates.py on this CPI too
+            from gates import db_map_gate
+            g = db_map_gate(o[c], m[c][0], ref)
+            print(f"\n[dB map, cpi {c} of {B}, {fmt}, {ran}] {g}")
+            assert g["ok"], g
     return amb
 
 
@@ -381,3 +397,63 @@ def test_a_lone_cpi_takes_the_small_launch_kernels(b2):
     from blah2_amd import _lib
     amb = run_batch(b2, CFG2, 1, "auto", seeds=(77,), expect="sub4")
     assert amb.dims.fft_len == 1024 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_PS
+
+
+# ---- fp16 IQ storage (BASELINE configs[4]): every range-kernel instantiation of InF16 the planner can reach ----------------
+
+CFG5 = (-10, 400, -512, 512, 20_000_000, 40_000_000)
+
+
+def synth_iq_device(n, seed, fs, targets, quantise=False, ref_amp=300.0, noise_amp=30.0, direct=0.8):
+    """oracle.synth_iq's signal model drawn on the device (40 M samples take 35 s per CPI with NumPy's generator):
+    test INPUT only -- the oracle then works on exactly the values the kernels read."""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    x = ref_amp * torch.view_as_complex(torch.randn((n, 2), generator=g, device="cuda", dtype=torch.float64))
+    y = direct * x
+    t = torch.arange(n, device="cuda", dtype=torch.float64) / fs
+    for d, f, a in targets:
+        xd = torch.roll(x, d)
+        xd[:d] = 0
+        y = y + a * xd * torch.exp(2j * torch.pi * f * t)
+    y = y + noise_amp * torch.view_as_complex(torch.randn((n, 2), generator=g, device="cuda", dtype=torch.float64))
+    if quantise:
+        x, y = (torch.view_as_complex(torch.clamp(torch.round(torch.view_as_real(v)), -32768, 32767)) for v in (x, y))
+    return x.cpu().numpy(), y.cpu().numpy()
+
+
+def test_cfg5_fp16_timed_combination(b2):
+    """BASELINE configs[4] as `bench.py --config cfg5 --fmt f16` times it: rangew_kernel<InF16,false,true> (F = 2048,
+    segments of 1627 samples: every load issued, seven outputs per lane) into doppler_tilew2_kernel (nD = 2049), two
+    CPIs of 40 M fp16 samples per launch, each against the fp64 oracle on the quantised values
+    (Ambiguity.cpp:106-169)."""
+    from blah2_amd import _lib
+    amb = run_batch(b2, CFG5, 2, "auto", seeds=(900, 901), fmt="f16", expect="tilew2",
+                    targets=((37, -63.0, 0.05), (300, 250.25, 0.05)), db_gate=True, synth=synth_iq_device)
+    assert (amb.get_n_doppler_bins(), amb.get_n_delay_bins(), amb.dims.fft_len) == (2049, 411, 2048)
+    assert amb.dims.seg_len > 24 * 64
+    assert amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_WAVE
+
+
+@pytest.mark.parametrize("geom,fft_len,kernel,B", [
+    (CFG2, 1024, "wave1k", 3),                                          # rangew1k_kernel<InF16,true,true,true>: carried y' registers
+    ((-7, 492, -50, 50, 155_540, 155_540), 1024, "wave1k", 3),          # <InF16,true,false>: 500 lags, no carry
+    ((-5, 94, -40, 40, 240_000, 240_000), 1024, "wave1k", 3),           # <InF16,false,true>: long segments
+    (CFG2, 2048, "wave", 3),                                            # rangew_kernel<InF16,true,true>: pruned windows
+    ((-7, 492, -50, 50, 155_540, 155_540), 2048, "wave", 2),            # rangew_kernel<InF16,false,false>
+    ((-10, 100, -100, 100, 1_000_000, 100_000), 1024, "e8", 2),         # range8_kernel<2,InF16>
+    (CFG2, 2048, "e16", 2),                                             # range_kernel<8,InF16>
+    ((-24, 2023, -64, 64, 1_260_000, 1_260_000), 4096, "e16", 2),       # range_kernel<16,InF16>: half-zero x segments
+    ((-10, 89, -20, 20, 123_000, 123_000), 4096, "e16", 2),             # range_kernel<16,InF16>: full segments
+    (CFG2, 1024, "ps", 1),                                              # rangeps_kernel<InF16,true,true>: a lone CPI
+    ((1, 299, -100, 100, 1_000_000, 777_001), 1024, "ps", 2)])          # rangeps_kernel<InF16,...>: ragged pulse
+def test_fp16_every_range_kernel_forced(b2, geom, fft_len, kernel, B):
+    """Each InF16 range-kernel instantiation forced at a small geometry, every CPI against the oracle on the
+    quantised values; asserts which range kernel ran."""
+    from blah2_amd import _lib
+    k = {"wave1k": _lib.RANGE_WAVE1K, "wave": _lib.RANGE_WAVE, "e8": _lib.RANGE_E8, "e16": _lib.RANGE_E16,
+         "ps": _lib.RANGE_PS}[kernel]
+    amb = run_batch(b2, geom, B, "direct", seeds=range(910, 910 + B), fmt="f16", fft_len=fft_len, range_kernel=k,
+                    targets=((37, -13.0, 0.05),), cell_tol=1e-4)
+    assert amb.dims.fft_len == fft_len and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == k
