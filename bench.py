@@ -259,64 +259,14 @@ def parity_check(np, O, cfg, fmt, chain, cfar, n_doppler, x_h, y_h, got_map, got
     return res
 
 
-# ----------------------------------------------------------------------------- main
-def main(argv=None):
-    argv = sys.argv[1:] if argv is None else argv
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=0,
-                    help="CPIs per step (per GPU); default 256 for the 2 MS/s configs (8 GB of fp32 IQ per step: a pulse is the scheduling unit of the range kernel, and 256 x 513 pulses are 42.75 rounds of its "
-                         "3072 resident waves -- measured on one box: 98.8 k / 107.7 k / 110.3 k CPIs/s at 32 / 128 / 256); "
-                         "32 for cfg3 (256 with --chain full, 41 GB of IQ: the Toeplitz solve takes 1.6 ms per launch whatever the batch -- "
-                         "4.69 k CPIs/s at 128, 4.92 k at 256), 8 for cfg5 -- "
-                         "measured: cfg3 93.9 / 88.8 / 84.7 us/CPI at 8 / 16 / 32, cfg5 142.8 / 138.4 / 138.8 at 4 / 8 / 16")
-    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--fmt", default="c32", choices=["c32", "i16", "f16"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison after the timed region")
-    ap.add_argument("--chain", default="amb", choices=["amb", "full"],
-                    help="amb: range+Doppler+metrics (BASELINE headline); full: clutter filter + amb + CFAR (configs[2])")
-    ap.add_argument("--cfar", default="2d", choices=["1d", "2d"])
-    ap.add_argument("--n-doppler", type=int, default=0,
-                    help="explicit number of Doppler bins (extension; 0 = the reference constructor's rule, which gives "
-                         "513 at the headline configuration; 512 gives the literal BASELINE wording)")
-    ap.add_argument("--doppler-kernel", default="auto", help="force a Doppler kernel (auto, tile8, tile16, sub4, tilew, tilew2, tilem, column, direct)")
-    ap.add_argument("--prewarm-s", type=float, default=0.6,
-                    help="seconds of untimed steps BEFORE the W warmup steps: the shader clock needs ~0.3 s of load to ramp up "
-                         "from idle (measured: steps 5..25 of a cold run are 4-5 %% slower than steady state)")
-    ap.add_argument("--range-kernel", default="auto", choices=["auto", "wave", "wave1k", "ps", "e16", "e8"],
-                    help="range kernel: by transform length (F = 2048: the one-wave kernel, F = 4096: the two-wave kernel), or forced")
-    ap.add_argument("--fft-len", type=int, default=0, choices=[0, 1024, 2048, 4096],
-                    help="force the range transform length (0 = the planner's choice); diagnostics")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="independent CPI streams per GPU (engine handles on their own HIP streams); successive "
-                         "steps alternate between them so one batch's Doppler stage overlaps the next batch's range stage")
-    a = ap.parse_args(argv)
-
-    import torch
-    action, detail = plan_launch(a.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0)
-    if action == "error":
-        raise SystemExit(f"bench.py: {detail} (the HIP path has no CPU fallback)")
-    if action == "spawn":
-        raise SystemExit(spawn_ranks(detail, argv))
-
-    import numpy as np
-    import blah2_amd
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if "RANK" in os.environ and "MASTER_ADDR" in os.environ:  # under torchrun, also at N = 1
-        import torch.distributed as dist_
-        dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
-        assert dist.get_world_size() == a.gpus
-
+# ----------------------------------------------------------------------------- one measurement
+def measure(a, env):
+    """One bench line's worth of measurement for the configuration in ``a``: data, handles, the timed region (barrier +
+    synchronize on both sides), a second region with every kernel bracketed by HIP events, the parity gate.  Returns
+    (result dict on rank 0 else None, parity dict or None).  Frees what it allocated: the default run calls it once for
+    the headline and once per secondary BASELINE configuration (``config_legs``)."""
+    torch, np, blah2_amd = env.torch, env.np, env.b2
+    rank, world, local, dev, dist = env.rank, env.world, env.local, env.dev, env.dist
     cfg, cfg_desc = CONFIGS[a.config]
     dmin, dmax, fmin, fmax, fs, n = cfg
     B = a.batch if a.batch > 0 else ({"cfg3": 256 if a.chain == "full" else 32, "cfg5": 8, "small": 1024}.get(a.config, 256))
@@ -411,6 +361,18 @@ def main(argv=None):
             step(n_pre + i)
         n_pre += 4
         torch.cuda.synchronize()
+    if a.target_s > 0:  # steps for a timed region of about target_s (every rank computes the same number: max over ranks)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - tp) / 3
+        if dist is not None:
+            tt = torch.tensor([per], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            per = float(tt.item())
+        a.steps = int(min(5000, max(8, round(a.target_s / max(per, 1e-7)))))
     for i in range(a.warmup):
         step(i)
     sync()
@@ -535,6 +497,8 @@ def main(argv=None):
         from oracle import blah2_oracle as O  # checker only; nothing above this line touched it
         checks = []
         for slot, c in enumerate((0, B - 1) if B > 1 else (0,)):  # the last CPI's tiles are later iterations of the persistent kernels
+            if a.parity_cpis == "last" and c != B - 1:
+                continue
             if a.fmt == "c32":
                 x_h = xs[r_last][c].cpu().numpy().astype(np.complex128)
                 y_h = ys[r_last][c].cpu().numpy().astype(np.complex128)
@@ -556,6 +520,7 @@ def main(argv=None):
             if vals:
                 parity[key] = max(vals)
 
+    res = None
     if rank == 0:
         total_cpis = world * B * a.steps
         res = {
@@ -595,16 +560,157 @@ def main(argv=None):
                          "kernel_us_per_step": {k: v[0] / max(v[1], 1) * 1e3 for k, v in kt.items() if v[1]},
                          "chain_us_per_step": chain_s * 1e6},
         }
+    for h_ in ambs + (whs if wh is not None else []):
+        h_.close()
+    return res, parity
+
+
+# ----------------------------------------------------------------------------- the other BASELINE configurations
+LEGS = [
+    # (key, argv beyond the headline's, what BASELINE.json calls it)
+    ("configs[2]", ["--config", "cfg3", "--chain", "full", "--cfar", "2d", "--batch", "32", "--streams", "2"],
+     "1xMI355X, 10 MS/s, 1 s CPI, 1024 Doppler x 2048 range, + clutter filter + 2D CA-CFAR"),
+    ("configs[2] ambiguity only", ["--config", "cfg3", "--batch", "32"],
+     "the same geometry, range + Doppler + metrics only (what B_amb prices)"),
+    ("configs[4]", ["--config", "cfg5", "--fmt", "f16", "--batch", "8"],
+     "1xMI355X, 20 MS/s, 2 s CPI, 2048 Doppler bins, fp16 IQ storage with fp32 accumulate"),
+    ("configs[1], one CPI per launch", ["--config", "cfg2", "--batch", "1"],
+     "real-time single stream (blah2.cpp:263-289): a lone CPI per launch, range + Doppler + metrics"),
+    ("configs[1], one CPI per launch, full chain", ["--config", "cfg2", "--batch", "1", "--chain", "full", "--cfar", "1d"],
+     "the same with the clutter filter (410 taps) in front and the 1-D detector behind"),
+]
+
+
+def config_legs(a, env):
+    """Short measurements of every other single-GPU configuration BASELINE.json names, in this process after the
+    headline: the same measure() (same timed region, same HIP-event pass, same oracle gate on the last CPI of the last
+    timed batch), about 0.3 s of timed work each.  A leg that fails is reported as such; it never voids the headline."""
+    out = []
+    for key, extra, what in LEGS:
+        t0 = time.perf_counter()
+        try:
+            env.torch.cuda.empty_cache()
+            la = _leg_args(a, extra)
+            r, par = measure(la, env)
+            rl = r["roofline"]
+            ks = [{"kernel": k["kernel"], "us_per_cpi": k["us_per_cpi"], "frac_hbm": k.get("frac_hbm")} for k in rl["kernels"]]
+            dom = max(ks, key=lambda k: k["us_per_cpi"]) if ks else None
+            out.append({"baseline_config": key, "baseline_wording": what, "workload": r["config"]["workload"],
+                        "chain": la.chain, "fmt": la.fmt, "batch_cpis_per_step": r["config"]["batch_cpis_per_step"],
+                        "streams_per_gpu": r["config"]["streams_per_gpu"], "steps": r["steps"],
+                        "cpis_per_s": r["value"], "us_per_cpi": r["us_per_cpi"], "cells_per_s": r["cells_per_s"],
+                        "n_doppler_bins": r["config"]["n_doppler_bins"], "n_delay_bins": r["config"]["n_delay_bins"],
+                        "range_kernel": r["config"]["range_kernel"], "doppler_kernel": r["config"]["doppler_kernel"],
+                        "chain_frac": rl["chain_frac"],  # B_amb over the time of the whole chain, against 8 TB/s (SURVEY.md 8d)
+                        "dominant_kernel": dom, "kernels": ks,
+                        "parity": None if par is None else {k: par[k] for k in ("pass", "peak_rel", "db_max", "metrics_db",
+                                                                                 "chain_err_over_direct_path") if k in par},
+                        "leg_wall_s": time.perf_counter() - t0})
+        except BaseException as e:  # SystemExit of a violated gate included: recorded, the headline stands on its own
+            out.append({"baseline_config": key, "error": f"{type(e).__name__}: {e}"[:600], "leg_wall_s": time.perf_counter() - t0})
+        env.torch.cuda.empty_cache()
+    return out
+
+
+def _leg_args(a, extra):
+    import copy
+    la = copy.copy(a)
+    la.config, la.chain, la.fmt, la.cfar, la.batch, la.streams = "cfg2", "amb", "c32", "2d", 0, 1
+    la.n_doppler, la.doppler_kernel, la.range_kernel, la.fft_len = 0, "auto", "auto", 0
+    it = iter(extra)
+    for k in it:
+        v = next(it)
+        name = k[2:].replace("-", "_")
+        setattr(la, name, int(v) if name in ("batch", "streams") else v)
+    la.target_s, la.warmup, la.prewarm_s, la.parity_cpis = 0.3, 3, 0.3, "last"
+    la.no_parity = a.no_parity
+    return la
+
+
+# ----------------------------------------------------------------------------- main
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=0,
+                    help="CPIs per step (per GPU); default 256 for the 2 MS/s configs (8 GB of fp32 IQ per step: a pulse is the scheduling unit of the range kernel, and 256 x 513 pulses are 42.75 rounds of its "
+                         "3072 resident waves -- measured on one box: 98.8 k / 107.7 k / 110.3 k CPIs/s at 32 / 128 / 256); "
+                         "32 for cfg3 (256 with --chain full, 41 GB of IQ: the Toeplitz solve takes 1.6 ms per launch whatever the batch -- "
+                         "4.69 k CPIs/s at 128, 4.92 k at 256), 8 for cfg5 -- "
+                         "measured: cfg3 93.9 / 88.8 / 84.7 us/CPI at 8 / 16 / 32, cfg5 142.8 / 138.4 / 138.8 at 4 / 8 / 16")
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--fmt", default="c32", choices=["c32", "i16", "f16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison after the timed region")
+    ap.add_argument("--chain", default="amb", choices=["amb", "full"],
+                    help="amb: range+Doppler+metrics (BASELINE headline); full: clutter filter + amb + CFAR (configs[2])")
+    ap.add_argument("--cfar", default="2d", choices=["1d", "2d"])
+    ap.add_argument("--n-doppler", type=int, default=0,
+                    help="explicit number of Doppler bins (extension; 0 = the reference constructor's rule, which gives "
+                         "513 at the headline configuration; 512 gives the literal BASELINE wording)")
+    ap.add_argument("--doppler-kernel", default="auto", help="force a Doppler kernel (auto, tile8, tile16, sub4, tilew, tilew2, tilem, column, direct)")
+    ap.add_argument("--prewarm-s", type=float, default=0.6,
+                    help="seconds of untimed steps BEFORE the W warmup steps: the shader clock needs ~0.3 s of load to ramp up "
+                         "from idle (measured: steps 5..25 of a cold run are 4-5 %% slower than steady state)")
+    ap.add_argument("--range-kernel", default="auto", choices=["auto", "wave", "wave1k", "ps", "e16", "e8"],
+                    help="range kernel: by transform length (F = 2048: the one-wave kernel, F = 4096: the two-wave kernel), or forced")
+    ap.add_argument("--fft-len", type=int, default=0, choices=[0, 1024, 2048, 4096],
+                    help="force the range transform length (0 = the planner's choice); diagnostics")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent CPI streams per GPU (engine handles on their own HIP streams); successive "
+                         "steps alternate between them so one batch's Doppler stage overlaps the next batch's range stage")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="headline only: skip the short legs for the other single-GPU BASELINE configurations (`configs` in the JSON line)")
+    ap.add_argument("--target-s", type=float, default=0.0,
+                    help="pick --steps so that the timed region lasts about this long (the legs of `configs` use it)")
+    ap.add_argument("--parity-cpis", default="both", choices=["both", "last"],
+                    help="CPIs of the last timed batch compared with the oracle: first and last, or the last only")
+    a = ap.parse_args(argv)
+
+    import torch
+    action, detail = plan_launch(a.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    if action == "error":
+        raise SystemExit(f"bench.py: {detail} (the HIP path has no CPU fallback)")
+    if action == "spawn":
+        raise SystemExit(spawn_ranks(detail, argv))
+
+    import numpy as np
+    import blah2_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if "RANK" in os.environ and "MASTER_ADDR" in os.environ:  # under torchrun, also at N = 1
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == a.gpus
+
+    import types
+    env = types.SimpleNamespace(torch=torch, np=np, b2=blah2_amd, rank=rank, world=world, local=local, dev=dev, dist=dist)
+    res, parity = measure(a, env)
+    if rank == 0:
+        cfg = CONFIGS[a.config][0]
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg)
             if a.config == "cfg2":
                 res["e2e_host"] = e2e_host(cfg, local, np, blah2_amd)
+        if world == 1 and not a.no_configs and (a.config, a.chain, a.fmt) == ("cfg2", "amb", "c32"):
+            res["configs"] = config_legs(a, env)  # every other single-GPU BASELINE configuration, same process, same box
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()  # rank 0 has been checking parity: every rank leaves the group together
         dist.destroy_process_group()
     if parity is not None and not parity["pass"]:
         raise SystemExit("bench.py: parity gate violated: " + json.dumps(parity))
+    bad = [c for c in (res or {}).get("configs", []) if "error" in c or (c.get("parity") and not c["parity"]["pass"])]
+    if bad:  # after the line has been printed: the headline stands, the exit status says a leg did not
+        raise SystemExit("bench.py: a secondary configuration failed: " + json.dumps(bad))
 
 
 if __name__ == "__main__":
