@@ -214,7 +214,9 @@ bool choose_plan(blah2hip_amb_s *h)
     // on four boxes, fp32 input; equal for int16)
     const bool w1k = (int64_t)h->dims.max_batch * h->dims.n_doppler_bins >= (int64_t)4 * RANGEW1K_WAVES_PER_SIMD * h->numCU;
     // handles whose largest launch stays below that (a lone CPI) run F = 1024 on the pulse-per-workgroup kernel when a
-    // pulse has at most seven segments: cfg 2, one CPI per launch: 19.0 vs 21.7 us on the F = 2048 workgroup kernel (round 4)
+    // pulse has at most two segments per wave of it: cfg 2, one CPI per launch: 19.0 vs 21.7 us on the F = 2048 workgroup
+    // kernel (round 4, the eight-wave form; the four-wave form of round 5 runs any segment count when forced)
+    constexpr int RANGEPS_SEG = 2 * RANGEPS_WAVES;
     const bool ps = r3 == 4 && nSeg <= RANGEPS_SEG && (int64_t)h->dims.max_batch * h->dims.n_doppler_bins <= (int64_t)4 * h->numCU;
     const double cost = (2.0 * nSeg + 1.0) * F * std::log2((double)F) * (r3 == 4 ? (w1k ? 0.985 : (ps ? 0.6 : 1.03)) : 1.0);
     if (cost < best) {
@@ -400,13 +402,13 @@ template <class In> int launch_rangew1k_t(blah2hip_amb_s *h, const RangeArgs &a,
   return BLAH2HIP_OK;
 }
 
-// F = 1024, at most seven segments, a launch that does not fill the one-wave kernel's slots (a lone CPI: 513 pulses): a
-// workgroup per pulse, its segments side by side (rangeps_kernel)
+// F = 1024, a launch that does not fill the one-wave kernel's slots (a lone CPI: 513 pulses): a workgroup of four waves
+// per pulse, its segments dealt round-robin to the waves (rangeps_kernel)
 bool use_ps_range(const blah2hip_amb_s *h, int nPulses)
 {
-  if (h->r3 != 4 || h->plan.nSeg > RANGEPS_SEG) return false;
+  if (h->r3 != 4) return false;
   if (h->rangeKernel == BLAH2HIP_RANGE_PS) return true;
-  return h->rangeKernel == 0 && nPulses <= 4 * h->numCU; // two rounds of its resident workgroups at most
+  return h->rangeKernel == 0 && nPulses <= 4 * h->numCU; // below two rounds of its resident workgroups
 }
 
 template <class In> int launch_rangeps_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
@@ -417,7 +419,7 @@ template <class In> int launch_rangeps_t(blah2hip_amb_s *h, const RangeArgs &a, 
   auto kern = shortx ? (out7 ? rangeps_kernel<In, true, true> : rangeps_kernel<In, true, false>)
                      : (out7 ? rangeps_kernel<In, false, true> : rangeps_kernel<In, false, false>);
   LDSCFG(kern, lds);
-  const int grid = std::min<int>(a.nPulses, range_grid_cap(h, lds, RANGEPS_WAVES, 16));
+  const int grid = std::min<int>(a.nPulses, range_grid_cap(h, lds, RANGEPS_WAVES, 12)); // 168 VGPRs: three waves per SIMD
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RANGEPS_WAVES), lds, st, a, in);
   HIPCHK(hipGetLastError());
   h->lastRange = BLAH2HIP_RANGE_PS;
@@ -827,8 +829,8 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
     if (value != 0 && value != BLAH2HIP_RANGE_WAVE && value != BLAH2HIP_RANGE_E16 && value != BLAH2HIP_RANGE_WAVE1K &&
         value != BLAH2HIP_RANGE_E8 && value != BLAH2HIP_RANGE_PS)
       return fail(BLAH2HIP_ERR_INVALID, "range kernel: 0 (by transform length), BLAH2HIP_RANGE_E16, _E8, _WAVE, _WAVE1K or _PS");
-    if (value == BLAH2HIP_RANGE_PS && (h->r3 != 4 || h->plan.nSeg > RANGEPS_SEG))
-      return fail(BLAH2HIP_ERR_UNSUPPORTED, "the pulse-per-workgroup range kernel is a 1024-point transform with at most 7 segments");
+    if (value == BLAH2HIP_RANGE_PS && h->r3 != 4)
+      return fail(BLAH2HIP_ERR_UNSUPPORTED, "the pulse-per-workgroup range kernel is a 1024-point transform");
     if ((value == BLAH2HIP_RANGE_WAVE1K || value == BLAH2HIP_RANGE_E8) && h->r3 != 4)
       return fail(BLAH2HIP_ERR_UNSUPPORTED, "the 16-points-per-lane one-wave kernel and the 8-points-per-thread kernel are 1024-point transforms");
     if (value == BLAH2HIP_RANGE_WAVE && h->r3 != 8)
@@ -889,7 +891,9 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   if (fmt != BLAH2HIP_FMT_C32 && fmt != BLAH2HIP_FMT_I16 && fmt != BLAH2HIP_FMT_F16 && fmt != BLAH2HIP_FMT_I16X_C32Y)
     return fail(BLAH2HIP_ERR_INVALID, "unknown sample format");
   if (!d_x || (fmt != BLAH2HIP_FMT_I16 && !d_y)) return fail(BLAH2HIP_ERR_INVALID, "NULL input pointer");
+#ifndef B2_EXPERIMENT_ALIASED_CPIS // tools/gpu_cfg3_bytes.py: a timing experiment's build lets every CPI of a batch sit at the same addresses
   if (n_cpi > 1 && cpi_stride < h->dims.n_used) return fail(BLAH2HIP_ERR_INVALID, "cpi_stride < samples used per CPI");
+#endif
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   const uint32_t nD = h->dims.n_doppler_bins, nDelay = h->dims.n_delay_bins;

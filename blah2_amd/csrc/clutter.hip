@@ -1265,7 +1265,9 @@ int blah2hip_clutter_process_dev_fmt(blah2hip_clutter_t h, int fmt, const void *
   if (fmt != BLAH2HIP_FMT_C32 && fmt != BLAH2HIP_FMT_I16) CFAIL(BLAH2HIP_ERR_INVALID, "clutter filter input: BLAH2HIP_FMT_C32 or BLAH2HIP_FMT_I16");
   if (fmt == BLAH2HIP_FMT_C32 && !d_y) CFAIL(BLAH2HIP_ERR_INVALID, "NULL argument");
   if (n_cpi == 0 || n_cpi > h->maxBatch) CFAIL(BLAH2HIP_ERR_INVALID, "n_cpi outside [1, max_batch]");
+#ifndef B2_EXPERIMENT_ALIASED_CPIS // tools/gpu_cfg3_bytes.py
   if (n_cpi > 1 && (cpi_stride < h->N || out_stride < h->N)) CFAIL(BLAH2HIP_ERR_INVALID, "cpi_stride / out_stride < nSamples");
+#endif
   CHIP(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   int32_t *ok = d_ok ? d_ok : h->d_ok;

@@ -569,20 +569,45 @@ __global__ __launch_bounds__(64 * RANGEW1K_WAVES, RANGEW1K_WAVES_PER_SIMD) void 
 // Range kernel for SMALL launches at F = 1024 (a lone CPI, the real-time shape of blah2.cpp:245-289: 513 pulses): the
 // one-wave kernel above gives a pulse to ONE wave, its segments in series -- with fewer pulses than wave slots the
 // chip is half empty and a pulse takes seven segments' time (41.8 us for a lone CPI at cfg 2); the workgroup kernels
-// put a pulse's segments in series too (22 us).  Here a pulse is a WORKGROUP and its segments run side by side: wave s
-// < nSeg loads and transforms segment s (x', y', the product Y conj X) and parks the product in its own exchange
-// region; the eighth wave sums the nSeg products (linearity: the inverse transform of the sum is the sum of the
-// segments' correlations), runs the one inverse and stores the lags -- while the segment waves are already on the
-// workgroup's next pulse.  Two barriers per pulse; 77 KB of LDS, two workgroups per CU.
-constexpr int RANGEPS_SEG = 7;               // segment waves
-constexpr int RANGEPS_WAVES = RANGEPS_SEG + 1;
+// put a pulse's segments in series too (22 us).  Here a pulse is a WORKGROUP of FOUR waves: wave q takes segments q,
+// q + 4, ... (cfg 2, seven segments: two each, the last wave one), exactly the loop body of rangew1k_kernel -- the next
+// segment's x' requested as soon as this one's has left its registers, its y' after the spectrum product -- with the
+// sum over ITS segments in registers; the four partial sums meet in LDS and the last wave, which had the fewest
+// segments, adds them (linearity: the inverse transform of the sum is the sum of the segments' correlations), runs the
+// one inverse and stores the lags.  Two barriers per pulse.
+//
+// Round 4's form had EIGHT waves per pulse (a wave per segment + a finisher), 77 KB of LDS, two workgroups per CU at 128
+// VGPRs -- and spilled (12-52 bytes of scratch per lane), and a lone CPI's 513 pulses were one more than its 512
+// resident workgroups: the last pulse ran alone after everything else (4 of 16 us).  Four waves need 41.5 KB: THREE
+// workgroups per CU at 168 VGPRs (no scratch), 768 resident workgroups, a lone CPI in one round; the work per SIMD is
+// the same 3.5 segments.
+constexpr int RANGEPS_WAVES = 4;
+// timing experiments: -DRANGEPS_ABLATE=1 the kernel's memory operations alone (no transforms),
+// =2 its transforms alone (no loads: zero records)
+#if defined(RANGEPS_ABLATE) && RANGEPS_ABLATE == 1
+#define PS_TR(...)
+#else
+#define PS_TR(...) __VA_ARGS__
+#endif
+#if defined(RANGEPS_ABLATE) && RANGEPS_ABLATE == 2
+#define PS_LIVE(c) false
+#else
+#define PS_LIVE(c) (c)
+#endif
+// (one instantiation -- fp32 planes, long segments, all sixteen outputs of the inverse -- is a register over three waves
+// per SIMD; it is built for two: its third workgroup per CU queues)
 template <class In, bool SHORTX, bool OUT7>
-__global__ __launch_bounds__(64 * RANGEPS_WAVES, 4) void rangeps_kernel(RangeArgs a, In in)
+__global__ __launch_bounds__(64 * RANGEPS_WAVES, (!SHORTX && !OUT7 && sizeof(typename RawBuiltin<typename BufLoad<In>::X>::raw) == 8) ? 2 : 3)
+void rangeps_kernel(RangeArgs a, In in)
 {
   using W = Wave1kFft;
   using RX = RawBuiltin<typename BufLoad<In>::X>;
   using RY = RawBuiltin<typename BufLoad<In>::Y>;
   constexpr int NX = SHORTX ? 9 : 16;
+  constexpr int FIN = RANGEPS_WAVES - 1; // the wave with the fewest segments finishes the pulse
+  // sixteen x' loads of eight bytes are 32 registers in flight through both transforms: with them the kernel is 2-4 registers
+  // over three waves per SIMD (scratch); that shape requests the next x' with the next y', after the spectrum product
+  constexpr bool XLATE = !SHORTX && sizeof(typename RX::raw) == 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf *table = reinterpret_cast<cf *>(smem);
   const int t = threadIdx.x & 63;
@@ -594,45 +619,91 @@ __global__ __launch_bounds__(64 * RANGEPS_WAVES, 4) void rangeps_kernel(RangeArg
   W::Tw w;
   W::load_twiddles(t, a.tw, table, w);
   const RangePlan p = a.plan;
-  const bool segw = wave < p.nSeg;
-  for (int pulse = blockIdx.x; pulse < a.nPulses; pulse += gridDim.x) {
-    const int cpi = pulse / p.nDoppler;
-    const int i = pulse - cpi * p.nDoppler;
-    if (segw) {
-      const int64_t base = (int64_t)cpi * a.cpiStride + (int64_t)i * p.nCorr;
-      typename RX::raw rx[NX];
-      typename RY::raw ry[16];
-      w1k_issue_x<In, NX>(in, p, base, wave, t, true, rx);
-      w1k_issue_y<In>(in, p, base, wave, t, true, ry);
-      cf v[16], yv[16];
+  const int stride = gridDim.x;
+  int pulse = blockIdx.x;
+  if (pulse >= a.nPulses) return; // the whole workgroup
+  int cpi = pulse / p.nDoppler;
+  int i = pulse - cpi * p.nDoppler;
+  int64_t base = (int64_t)cpi * a.cpiStride + (int64_t)i * p.nCorr;
+  // the walk of rangew1k_kernel with a stride of four segments; a wave whose index is beyond the pulse's segments (fewer
+  // than four of them) transforms zero records and parks a zero sum: the barriers below are reached by every wave
+  int s = wave;
+  typename RX::raw rx[NX];
+  typename RY::raw ry[16];
+  cf acc[16];
 #pragma unroll
-      for (int k = 0; k < NX; k++) v[k] = RX::cvt(rx[k]);
-      W::template transform<-1, NX>(t, v, w, X); // X spectrum
+  for (int e = 0; e < 16; e++) acc[e] = cmake(0.f, 0.f);
+  w1k_issue_x<In, NX>(in, p, base, s, t, PS_LIVE(s < p.nSeg), rx);
+  w1k_issue_y<In>(in, p, base, s, t, PS_LIVE(s < p.nSeg), ry);
+  for (;;) {
+    // the segment after this one (wave-uniform)
+    int ns = s + RANGEPS_WAVES, npulse = pulse, ncpi = cpi, ni = i;
+    int64_t nbase = base;
+    const bool done = ns >= p.nSeg; // this wave's share of the pulse is complete
+    if (done) {
+      ns = wave;
+      npulse = pulse + stride;
+      ncpi = npulse / p.nDoppler;
+      ni = npulse - ncpi * p.nDoppler;
+      nbase = (int64_t)ncpi * a.cpiStride + (int64_t)ni * p.nCorr;
+    }
+    const bool more = npulse < a.nPulses;
+    const bool live = PS_LIVE(more && ns < p.nSeg);
+    cf v[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) yv[k] = RY::cvt(ry[k]);
-      W::template transform<-1, 16>(t, yv, w, X); // Y spectrum
+    for (int k = 0; k < NX; k++) v[k] = RX::cvt(rx[k]);
+    PS_TR(W::s1<-1, NX>(v, w));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!XLATE) w1k_issue_x<In, NX>(in, p, nbase, ns, t, live, rx);
+    __builtin_amdgcn_sched_barrier(0);
+    PS_TR(W::finish<-1>(t, v, w, X)); // v = X spectrum
+    cf yin[16], yv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) yin[k] = RY::cvt(ry[k]);
+#if defined(RANGEPS_ABLATE) && RANGEPS_ABLATE == 1
+#pragma unroll
+    for (int k = 0; k < 16; k++) yv[k] = yin[k];
+#else
+    W::s1_nd<-1>(yv, yin, w);
+    W::finish<-1>(t, yv, w, X); // yv = Y spectrum
+#endif
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = cmacc(acc[e], yv[e], v[e]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (XLATE) w1k_issue_x<In, NX>(in, p, nbase, ns, t, live, rx);
+    w1k_issue_y<In>(in, p, nbase, ns, t, live, ry);
+    __builtin_amdgcn_sched_barrier(0);
+    if (done) {
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int e = 0; e < 16; e++) X[e * 64 + t] = cmacc(cmake(0.f, 0.f), yv[e], v[e]); // Y conj X, parked
-    }
-    __syncthreads(); // the products of this pulse are in the regions
-    cf acc[16];
-    if (wave == RANGEPS_SEG) {
+      for (int e = 0; e < 16; e++) X[e * 64 + t] = acc[e]; // this wave's share of sum_s Y_s conj X_s, parked
+      __syncthreads(); // the four partial sums of this pulse are in the regions
+      if (wave == FIN) {
 #pragma unroll
-      for (int e = 0; e < 16; e++) acc[e] = regions[e * 64 + t];
-      for (int sg = 1; sg < p.nSeg; sg++) {
-        const cf *r = regions + sg * W::X_ELEMS;
+        for (int q = 0; q < FIN; q++) {
+          const cf *r = regions + q * W::X_ELEMS;
 #pragma unroll
-        for (int e = 0; e < 16; e++) { const cf q = r[e * 64 + t]; acc[e] = cmake(acc[e].x + q.x, acc[e].y + q.y); }
+          for (int e = 0; e < 16; e++) { const cf u = r[e * 64 + t]; acc[e] = cmake(acc[e].x + u.x, acc[e].y + u.y); }
+        }
       }
+      __syncthreads(); // the regions are free for the next pulse's transforms
+      if (wave == FIN) {
+        PS_TR(W::template transform<+1, 16, OUT7>(t, acc, w, X));
+        store_lags_w<OUT7 ? 7 : 16>(a.out, p, cpi, i, t, acc);
+      }
+      if (!more) break;
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[e] = cmake(0.f, 0.f);
+      pulse = npulse;
+      cpi = ncpi;
+      i = ni;
     }
-    __syncthreads(); // the regions are free for the next pulse's transforms
-    if (wave == RANGEPS_SEG) {
-      W::template transform<+1, 16, OUT7>(t, acc, w, X);
-      store_lags_w<OUT7 ? 7 : 16>(a.out, p, cpi, i, t, acc);
-    }
+    s = ns;
+    base = nbase;
   }
 }
+#undef PS_TR
+#undef PS_LIVE
 
 // --------------------------------------------------------------------------
 // Doppler-centre shift, Ambiguity.cpp:95-102:  x[i] *= exp(+j 2 pi fMid i / fs),

@@ -160,7 +160,7 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 #define BLAH2HIP_RANGE_WAVE 3  /* one wave per pulse, 32 points per lane, no barriers (F = 2048) */
 /* 4: was BLAH2HIP_RANGE_WAVE2 (a pair of waves per pulse at F = 4096; measured 5 % slower than _E16 and removed in round 4) */
 #define BLAH2HIP_RANGE_WAVE1K 5 /* one wave per pulse, 16 points per lane, four waves per SIMD (F = 1024) */
-#define BLAH2HIP_RANGE_PS 6     /* small launches (a lone CPI) at F = 1024, at most 7 segments: one workgroup per pulse, one wave per segment */
+#define BLAH2HIP_RANGE_PS 6     /* small launches (a lone CPI) at F = 1024: one workgroup of four waves per pulse, its segments dealt round-robin to the waves */
 /* BLAH2HIP_ERR_UNSUPPORTED when the kernel does not cover the handle's Doppler length */
 int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value);
 #define BLAH2HIP_INFO_LAST_DOPPLER_KERNEL 1 /* BLAH2HIP_DOP_* the last process call launched (0 = none yet) */
