@@ -491,6 +491,7 @@ bool doppler_kernel_applicable(const blah2hip_amb_s *h, int which)
   const int nD = (int)h->dims.n_doppler_bins;
   switch (which) {
   case BLAH2HIP_DOP_TILE8:
+  case BLAH2HIP_DOP_TILE8K:
   case BLAH2HIP_DOP_TILE16WG:
   case BLAH2HIP_DOP_SUB4:
   case BLAH2HIP_DOP_TILE16: return h->dopR3 == 4;
@@ -986,17 +987,24 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   const int which = pick_doppler(h, n_cpi);
   switch (which) {
   case BLAH2HIP_DOP_TILE8:
+  case BLAH2HIP_DOP_TILE8K:
   case BLAH2HIP_DOP_TILE16WG:
   case BLAH2HIP_DOP_TILE16: {
-    const int ncol = which == BLAH2HIP_DOP_TILE8 ? 8 : 16;
+    const int ncol = (which == BLAH2HIP_DOP_TILE8 || which == BLAH2HIP_DOP_TILE8K) ? 8 : 16;
     const int grid = (int)((nDelay + ncol - 1) / ncol);
     // persistent: the resident workgroups (LDS: one of 16 columns or two of 8 per CU) walk the tiles of the batch
     if (which == BLAH2HIP_DOP_TILE16) {
       const size_t lds = (size_t)DOPT1K_LDS_ELEMS * sizeof(cf);
       const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, h->dopGridForce ? h->dopGridForce : h->numCU);
       dopGrid = wgs; dopTiles = grid * (int)n_cpi;
-      LDSCFG(doppler_tile1k_kernel, lds);
-      hipLaunchKernelGGL(doppler_tile1k_kernel, dim3(wgs), dim3(1024), lds, st, da, (int)n_cpi);
+      LDSCFG(doppler_tile1k_kernel<16>, lds);
+      hipLaunchKernelGGL(doppler_tile1k_kernel<16>, dim3(wgs), dim3(1024), lds, st, da, (int)n_cpi);
+    } else if (which == BLAH2HIP_DOP_TILE8K) {
+      const size_t lds = (size_t)dopt1k_lds_elems<8>() * sizeof(cf);
+      const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, h->dopGridForce ? h->dopGridForce : 2 * h->numCU);
+      dopGrid = wgs; dopTiles = grid * (int)n_cpi;
+      LDSCFG(doppler_tile1k_kernel<8>, lds);
+      hipLaunchKernelGGL(doppler_tile1k_kernel<8>, dim3(wgs), dim3(512), lds, st, da, (int)n_cpi);
     } else if (ncol == 16) {
       const size_t lds = (size_t)dopt_lds_elems<16>() * sizeof(cf);
       const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, h->dopGridForce ? h->dopGridForce : h->numCU);

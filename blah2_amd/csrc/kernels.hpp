@@ -1067,14 +1067,21 @@ __global__ __launch_bounds__(64 * NCOL) void doppler_tile_kernel(DopplerArgs a, 
 // per-lane constants of the walk live in registers across the tiles: the chirp of this lane's nine rows (zero for rows
 // beyond nD, which also zeroes the padding rows without a select) and where each output row goes after the rotation by
 // nD/2 + 1.  One exchange per transform instead of two; the kernel spectrum in natural order (a.bfn).
-constexpr int DOPT1K_LDS_ELEMS = 16 * DOPT_PITCH + Wave1kFft::TW_ELEMS + 1024;
-__global__ __launch_bounds__(1024) void doppler_tile1k_kernel(DopplerArgs a, int nCpi)
+// NCOL = 8 (round 5): HALF tiles, 512 threads.  8 regions + the stage-twiddle table are 75.6 KB; the kernel spectrum is the
+// transform of an EVEN sequence (b[m] = b[1024 - m], capi.hip), so it is even itself and entries 0 ... 512 (4 KB) serve
+// all 1024: 79.7 KB, TWO workgroups per CU, and the barrier-separated phases of one (transposes, row stores) run under
+// the transforms of the other; the sibling half of a tile is read by the next workgroup of the walk (same 128-byte lines).
+template <int NCOL> constexpr int dopt1k_lds_elems() { return NCOL * DOPT_PITCH + Wave1kFft::TW_ELEMS + (NCOL == 16 ? 1024 : 513); }
+constexpr int DOPT1K_LDS_ELEMS = dopt1k_lds_elems<16>();
+template <int NCOL> __global__ __launch_bounds__(64 * NCOL, 4) void doppler_tile1k_kernel(DopplerArgs a, int nCpi)
 {
   using K = Wave1kFft;
-  constexpr int NCOL = 16, T = 64, NR = 9, NT = 1024, SH = 4;
+  static_assert(NCOL == 16 || NCOL == 8, "");
+  constexpr int T = 64, NR = 9, NT = 64 * NCOL, SH = NCOL == 16 ? 4 : 3;
+  constexpr bool BF_FULL = NCOL == 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double wsum[16];
-  __shared__ float wmax[16];
+  __shared__ double wsum[NCOL];
+  __shared__ float wmax[NCOL];
   cf *lds = reinterpret_cast<cf *>(smem);
   const int tid = threadIdx.x;
   const int w = tid >> 6, t = tid & 63; // wave = column of the tile
@@ -1088,7 +1095,8 @@ __global__ __launch_bounds__(1024) void doppler_tile1k_kernel(DopplerArgs a, int
 
   // once per workgroup: tables, and this lane's constants
   K::fill_table(tid, NT, a.tw, table);
-  bfL[tid] = a.bfn[tid];
+  if (BF_FULL || tid <= 512) bfL[tid] = a.bfn[tid]; // NCOL = 8: 512 threads -> entries 0 ... 511, and 512 below
+  if (!BF_FULL && tid == 0) bfL[512] = a.bfn[512];
   K::Tw tw;
   K::load_twiddles(t, a.tw, table, tw);
   cf ch[NR];  // chirp of row t + 64 k; 0 beyond nD
@@ -1106,23 +1114,27 @@ __global__ __launch_bounds__(1024) void doppler_tile1k_kernel(DopplerArgs a, int
   }
 
   cf nt[NR];
-  auto tile_load = [&](int it) {
+  // NCOL = 8: the last four of a thread's nine cells are requested at the top of the tile's own iteration, not a tile
+  // ahead -- held through the transforms they were the registers that spilled (and a spill behind a load waits for it)
+  constexpr int PRE = NCOL == 16 ? NR : NR - 4;
+  auto tile_load = [&](int it, int j0, int j1) {
     const int cpi = it / tilesPerCpi, sub = it - cpi * tilesPerCpi;
     const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, sub * NCOL);
     const int tl = relaunder(tid);
 #pragma unroll
-    for (int j = 0; j < NR; j++) {
-      const int idx = tl + NT * j; // the tile is contiguous: cell idx = row * 16 + column
-      nt[j] = Rt[idx < cells ? idx : 0];
+    for (int j = j0; j < j1; j++) {
+      const int idx = tl + NT * j; // the 16-column tile is contiguous: cell = row * 16 + column (a half tile: 64-byte row pieces)
+      nt[j] = Rt[idx < cells ? (NCOL == 16 ? idx : (idx >> SH) * 16 + (idx & (NCOL - 1))) : 0];
     }
   };
   int it = blockIdx.x;
-  if (it < nTilesAll) tile_load(it);
+  if (it < nTilesAll) tile_load(it, 0, PRE);
   __syncthreads(); // tables
   for (; it < nTilesAll; it += gridDim.x) {
     const int cpi = it / tilesPerCpi, sub = it - cpi * tilesPerCpi;
     const int col0 = sub * NCOL;
     // phase 1: the tile, transposed into the per-column regions
+    if constexpr (PRE < NR) tile_load(it, PRE, NR);
     {
       const int tl = relaunder(tid);
       cf *dst = lds + (tl & (NCOL - 1)) * DOPT_PITCH + (tl >> SH); // idx + 1024 j: same column, row + 64 j
@@ -1136,12 +1148,20 @@ __global__ __launch_bounds__(1024) void doppler_tile1k_kernel(DopplerArgs a, int
     cf v[16];
     const cf r0 = region[0];
 #pragma unroll
-    for (int k = 0; k < NR; k++) v[k] = cmul(csub(region[ridx[k]], r0), ch[k]); // rows beyond nD: a valid cell times 0
-    if (it + (int)gridDim.x < nTilesAll) tile_load(it + gridDim.x);
+    for (int k = 0; k < NR; k++) // rows beyond nD: a valid cell times 0 (NCOL = 8 recomputes the clamped row: nine registers it needs elsewhere)
+      v[k] = cmul(csub(region[NCOL == 16 ? ridx[k] : min(t + T * k, nD - 1)], r0), ch[k]);
+    if (it + (int)gridDim.x < nTilesAll) tile_load(it + gridDim.x, 0, PRE);
     __builtin_amdgcn_wave_barrier();
     K::transform<-1, 9>(t, v, tw, region);
+    if constexpr (BF_FULL) {
 #pragma unroll
-    for (int e = 0; e < 16; e++) v[e] = cmul(v[e], bfL[e * T + t]);
+      for (int e = 0; e < 16; e++) v[e] = cmul(v[e], bfL[e * T + t]);
+    } else { // B[m] = B[1024 - m]: entries 0 ... 512 only
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = cmul(v[e], bfL[e * T + t]);
+#pragma unroll
+      for (int e = 8; e < 16; e++) v[e] = cmul(v[e], bfL[(16 - e) * T - t]);
+    }
     __builtin_amdgcn_wave_barrier();
     K::transform<+1>(t, v, tw, region);
     __builtin_amdgcn_wave_barrier();
@@ -1152,7 +1172,14 @@ __global__ __launch_bounds__(1024) void doppler_tile1k_kernel(DopplerArgs a, int
       for (int c = 0; c < NR; c++) {
         cf d = cmul(v[c], ch[c]);
         if (c == 0 && t == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
-        region[oidx[c]] = d;
+        if constexpr (NCOL == 16) {
+          region[oidx[c]] = d;
+        } else { // recomputed (registers): rotated by nD/2 + 1, rows that do not exist go to the spare slot
+          const int i = t + T * c;
+          int o = i - (nD / 2 + 1);
+          o = o < 0 ? o + nD : o;
+          region[i < nD ? o : DOPT_PITCH - 1] = d;
+        }
       }
     }
     __syncthreads();

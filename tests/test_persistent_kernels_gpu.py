@@ -31,12 +31,12 @@ G513 = (-7, 292, -256, 256, 1_026_000, 1_026_000)
 G65 = (-7, 292, -32, 32, 130_000, 130_000)
 
 
-@pytest.mark.parametrize("kernel,grid", [("tile8", 5), ("tile8", 7), ("tile16", 4), ("tile16", 5)])
+@pytest.mark.parametrize("kernel,grid", [("tile8", 5), ("tile8", 7), ("tile8k", 5), ("tile8k", 7), ("tile16", 4), ("tile16", 5)])
 @pytest.mark.parametrize("geom", [G513, G65], ids=["nD513", "nD65"])
 def test_tile_kernels_forced_small_grid(b2, kernel, grid, geom):
     amb = run_batch(b2, geom, 3, kernel, seeds=(11, 12, 13), targets=((37, -13.0, 0.05),), doppler_grid=grid)
     g, tiles = _assert_steady(amb)
-    assert g == grid and tiles == 3 * (38 if kernel == "tile8" else 19)
+    assert g == grid and tiles == 3 * (38 if kernel in ("tile8", "tile8k") else 19)
     assert tiles % grid != 0  # a last round in which only some workgroups still have a tile
 
 
@@ -73,6 +73,15 @@ def test_cfg2_tile8_natural_grid_runs_second_iterations(b2):
     """The half-tile kernel, two workgroups per CU: 12 x 52 = 624 half tiles on 512 workgroups."""
     from blah2_amd import _lib
     amb = run_batch(b2, CFG2, 12, "tile8", seeds=range(330, 342))
+    grid, tiles = amb.info(_lib.INFO_DOPPLER_GRID), amb.info(_lib.INFO_DOPPLER_TILES)
+    assert tiles == 624 and tiles > grid
+
+
+def test_cfg2_tile8k_natural_grid_runs_second_iterations(b2):
+    """doppler_tile1k_kernel<8> (round 5: the 16-column kernel on half tiles, two workgroups per CU, the even kernel
+    spectrum as a half table): 12 x 52 = 624 half tiles on 512 workgroups, every CPI against the oracle."""
+    from blah2_amd import _lib
+    amb = run_batch(b2, CFG2, 12, "tile8k", seeds=range(360, 372))
     grid, tiles = amb.info(_lib.INFO_DOPPLER_GRID), amb.info(_lib.INFO_DOPPLER_TILES)
     assert tiles == 624 and tiles > grid
 

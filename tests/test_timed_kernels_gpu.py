@@ -140,7 +140,7 @@ def test_cfg2_batched_int16_wire_format(b2):
     run_batch(b2, CFG2, 3, "auto", seeds=(50, 51, 52), fmt="i16", expect="tile8")
 
 
-@pytest.mark.parametrize("kernel", ["tile8", "tile16", "sub4", "column", "direct"])
+@pytest.mark.parametrize("kernel", ["tile8", "tile8k", "tile16", "sub4", "column", "direct"])
 def test_cfg2_every_doppler_kernel(b2, kernel):
     """The same two CPIs through each Doppler kernel that covers nD = 513, forced."""
     run_batch(b2, CFG2, 2, kernel, seeds=(60, 61))
@@ -149,7 +149,7 @@ def test_cfg2_every_doppler_kernel(b2, kernel):
 # Doppler lengths either side of each tile kernel's row grouping (64 rows per register at one wave
 # per column), ragged delay counts (last tile partly empty: 411 = 51*8+3, 300 = 18*16+12), B = 2.
 @pytest.mark.parametrize("fmax,n,nD", [(32, 130_000, 65), (255, 1_022_000, 511), (256, 1_026_000, 513)])
-@pytest.mark.parametrize("kernel", ["tile8", "tile16"])
+@pytest.mark.parametrize("kernel", ["tile8", "tile8k", "tile16"])
 def test_tile_kernels_row_groups_and_ragged_tiles(b2, fmax, n, nD, kernel):
     geom = (-7, 292, -fmax, fmax, n, n)  # fs = n: 1 s CPI, 1 Hz Doppler resolution, nCorr = 2000
     amb = run_batch(b2, geom, 2, kernel, seeds=(70 + nD, 71 + nD), targets=((37, -13.0, 0.05),))
