@@ -409,6 +409,8 @@ def measure(a, env):
         w_.set_timing(True)
     for i in range(a.steps):
         step(a.warmup + i)
+        if NS > 1:  # per-kernel durations are one kernel's own: with batches in flight on several streams the events of one
+            torch.cuda.synchronize()  # would bracket the other's kernels too; this pass runs the batches one after the other
     torch.cuda.synchronize()
     kt = {}
     for h_ in ambs + (whs if wh is not None else []):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun) from the repo root:
 #   gpurun --timeout 1500 -- 'bash tools/profile_round.sh'
-# then, back in the container:  python tools/summarize_prof.py r04 && python tools/collect_bench.py r04
+# then, back in the container:  python tools/summarize_prof.py r05 && python tools/collect_bench.py r05
 # For each profiled bench command (tag -> arguments below) leaves under gpurun_out/prof/<tag>/:
 # the rocprofv3 --kernel-trace --stats run and the separate PMC passes (never combined with a
 # trace domain other than --kernel-trace), plus the plain bench logs.
@@ -12,7 +12,7 @@ mkdir -p $OUT/prof
 cd /tmp && export TMPDIR=/tmp
 profile() { # tag, json description, bench args...
   local tag=$1; local desc=$2; shift 2
-  local B="python $REPO/bench.py $* --no-cpu-baseline --no-parity"
+  local B="python $REPO/bench.py $* --no-cpu-baseline --no-parity --no-configs"
   mkdir -p $OUT/prof/$tag
   echo "$desc" > $OUT/prof/$tag/bench_config.json
   timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof/$tag/trace -o bench --output-format csv -- $B > $OUT/prof/$tag/trace.log 2>&1
@@ -30,30 +30,22 @@ mkdir -p $OUT/cal
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/cal/fetch -o cal --output-format csv -- $REPO/tools/membench/pmccal > $OUT/cal/fetch.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/cal/write -o cal --output-format csv -- $REPO/tools/membench/pmccal > $OUT/cal/write.log 2>&1
 cd $REPO
-rm -f $OUT/bench_r4*.log
-python bench.py > $OUT/bench_r4.log 2>&1
-python bench.py --batch 1 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_r4_b1.log 2>&1
-python bench.py --fmt i16 --no-cpu-baseline > $OUT/bench_r4_i16.log 2>&1
-python bench.py --chain full --steps 20 --no-cpu-baseline > $OUT/bench_r4_full.log 2>&1
-python bench.py --config cfg3 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_r4_cfg3.log 2>&1
-python bench.py --config cfg3 --chain full --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_r4_cfg3_full.log 2>&1
-python bench.py --config cfg5 --fmt f16 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_r4_cfg5.log 2>&1
-python bench.py --config cfg5 --fmt f16 --batch 32 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_r4_cfg5_b32.log 2>&1
-python bench.py --config cfg3 --chain full --batch 32 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_r4_cfg3_full_b32.log 2>&1
-python bench.py --chain full --batch 1 --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_r4_full_b1.log 2>&1
-# two batches in flight (a filter handle and result buffers per stream)
-python bench.py --chain full --batch 64 --streams 2 --steps 40 --no-cpu-baseline > $OUT/bench_r4_full_b64_s2.log 2>&1
-python bench.py --config cfg3 --chain full --streams 2 --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_r4_cfg3_full_s2.log 2>&1
-python bench.py --config cfg3 --chain full --batch 32 --streams 2 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_r4_cfg3_full_b32_s2.log 2>&1
-python bench.py --config cfg3 --chain full --batch 64 --streams 2 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_r4_cfg3_full_b64_s2.log 2>&1
-python bench.py --config small --steps 40 --warmup 3 --no-cpu-baseline > $OUT/bench_r4_small.log 2>&1
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_r4_torchrun.log 2>&1
-python tools/replay_bench.py --out $OUT/replay.json > $OUT/replay_bench.log 2>&1
+rm -f $OUT/bench_r5*.log
+python bench.py > $OUT/bench_r5.log 2>&1                      # the default line: headline + configs[] legs + cpu_baseline + e2e_host
+python bench.py --fmt i16 --no-cpu-baseline --no-configs > $OUT/bench_r5_i16.log 2>&1
+python bench.py --chain full --steps 20 --no-cpu-baseline --no-configs > $OUT/bench_r5_full.log 2>&1
+python bench.py --config cfg3 --steps 20 --warmup 3 --no-cpu-baseline --no-configs > $OUT/bench_r5_cfg3.log 2>&1
+python bench.py --config cfg3 --chain full --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $OUT/bench_r5_cfg3_full.log 2>&1
+python bench.py --config cfg5 --fmt f16 --steps 10 --warmup 2 --no-cpu-baseline --no-configs > $OUT/bench_r5_cfg5.log 2>&1
+python bench.py --batch 1 --steps 2000 --warmup 50 --no-cpu-baseline --no-configs > $OUT/bench_r5_b1.log 2>&1
+python bench.py --chain full --cfar 1d --batch 1 --steps 500 --warmup 20 --no-cpu-baseline --no-configs > $OUT/bench_r5_full_b1.log 2>&1
+python bench.py --config small --steps 40 --warmup 3 --no-cpu-baseline --no-configs > $OUT/bench_r5_small.log 2>&1
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_r5_torchrun.log 2>&1
 # the Toeplitz solve on its own: HIP-event time per launch by taps / batch / form, and rocprofv3's kernel durations of the same
 python tools/gpu_solve.py --json $OUT/solve_timing.json > $OUT/solve_timing.log 2>&1
 mkdir -p $OUT/prof/solve
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof/solve/trace -o bench --output-format csv -- python $REPO/tools/gpu_solve.py --quick > $OUT/prof/solve/trace.log 2>&1)
 # the lone-CPI chain (small-launch kernels) under the profiler
 mkdir -p $OUT/prof/b1
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof/b1/trace -o bench --output-format csv -- python $REPO/bench.py --batch 1 --steps 200 --warmup 20 --no-cpu-baseline --no-parity > $OUT/prof/b1/trace.log 2>&1)
-tail -qn 1 $OUT/bench_r4*.log | cut -c1-200
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof/b1/trace -o bench --output-format csv -- python $REPO/bench.py --batch 1 --steps 500 --warmup 20 --no-cpu-baseline --no-parity --no-configs > $OUT/prof/b1/trace.log 2>&1)
+tail -qn 1 $OUT/bench_r5*.log | cut -c1-200
