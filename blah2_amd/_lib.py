@@ -28,9 +28,9 @@ CLUTTER_OPT_SOLVE_SPIN_LIMIT = 7
 CLUTTER_SOLVE_AUTO, CLUTTER_SOLVE_STEPWISE, CLUTTER_SOLVE_LOOKAHEAD = 0, 1, 2
 CLUTTER_INFO_SOLVE_FORM, CLUTTER_INFO_SOLVE_E, CLUTTER_INFO_SOLVE_G, CLUTTER_INFO_SOLVE_FAULT, CLUTTER_INFO_SOLVE_RETRIES = 1, 2, 3, 4, 5
 CLUTTER_CORR_AUTO, CLUTTER_CORR_HALF, CLUTTER_CORR_WINDOW = 0, 1, 2
-DOP_AUTO, DOP_TILE8, DOP_TILE16, DOP_TILEM, DOP_COLUMN, DOP_DIRECT, DOP_TILEW, DOP_TILEW2, DOP_TILE16WG, DOP_SUB4, DOP_TILE8K = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+DOP_AUTO, DOP_TILE8, DOP_TILE16, DOP_TILEM, DOP_COLUMN, DOP_DIRECT, DOP_TILEW, DOP_TILEW2, DOP_TILE16WG, DOP_SUB4, DOP_TILE8K, DOP_TILEW4 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 DOPPLER_KERNEL_NAMES = {DOP_AUTO: "auto", DOP_TILE8: "tile8", DOP_TILE16: "tile16", DOP_TILEM: "tilem",
-                        DOP_COLUMN: "column", DOP_DIRECT: "direct", DOP_TILEW: "tilew", DOP_TILEW2: "tilew2", DOP_TILE16WG: "tile16wg", DOP_SUB4: "sub4", DOP_TILE8K: "tile8k"}
+                        DOP_COLUMN: "column", DOP_DIRECT: "direct", DOP_TILEW: "tilew", DOP_TILEW2: "tilew2", DOP_TILE16WG: "tile16wg", DOP_SUB4: "sub4", DOP_TILE8K: "tile8k", DOP_TILEW4: "tilew4"}
 RANGE_E16, RANGE_E8, RANGE_WAVE, RANGE_WAVE1K, RANGE_PS = 1, 2, 3, 5, 6
 INFO_LAST_DOPPLER_KERNEL, INFO_LAST_RANGE_KERNEL, INFO_DOPPLER_FFT_LEN, INFO_RANGE_GRID, INFO_NUM_CU = 1, 2, 3, 4, 5
 INFO_DOPPLER_GRID, INFO_DOPPLER_TILES = 6, 7

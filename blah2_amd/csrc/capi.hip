@@ -498,6 +498,7 @@ bool doppler_kernel_applicable(const blah2hip_amb_s *h, int which)
   case BLAH2HIP_DOP_TILEM: return (h->dopR3 == 8 && nD <= DopM<8>::MAX_ND) || (h->dopR3 == 16 && nD <= DopM<16>::MAX_ND);
   case BLAH2HIP_DOP_TILEW: return h->dopR3 == 8 && nD <= DOPW_MAX_ND;
   case BLAH2HIP_DOP_TILEW2: return h->dopR3 == 16 && nD <= DOPW2_MAX_ND;
+  case BLAH2HIP_DOP_TILEW4: return h->dopR3 == 16 && nD <= DOPW4_MAX_ND;
   case BLAH2HIP_DOP_COLUMN: return h->dopR3 != 0;
   case BLAH2HIP_DOP_DIRECT: return true;
   default: return false;
@@ -1040,6 +1041,17 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, h->dopGridForce ? h->dopGridForce : h->numCU);
     dopGrid = wgs; dopTiles = grid * (int)n_cpi;
     hipLaunchKernelGGL(doppler_tilew_kernel, dim3(wgs), dim3(64 * DOPW_NCOL), lds, st, da, (int)n_cpi);
+    nPartsUsed = grid;
+    break;
+  }
+  case BLAH2HIP_DOP_TILEW4: {
+    const int grid = (int)((nDelay + DOPW4_NCOL - 1) / DOPW4_NCOL);
+    const size_t lds = (size_t)DOPW4_LDS_ELEMS * sizeof(cf);
+    LDSCFG(doppler_tilew4_kernel, lds);
+    // persistent: one workgroup per CU (LDS) walks the half tiles of the whole batch
+    const int wgs = (int)std::min<int64_t>((int64_t)grid * n_cpi, h->dopGridForce ? h->dopGridForce : h->numCU);
+    dopGrid = wgs; dopTiles = grid * (int)n_cpi;
+    hipLaunchKernelGGL(doppler_tilew4_kernel, dim3(wgs), dim3(64 * DOPW4_NCOL), lds, st, da, (int)n_cpi);
     nPartsUsed = grid;
     break;
   }

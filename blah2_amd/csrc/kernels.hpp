@@ -1763,6 +1763,300 @@ __global__ __launch_bounds__(128 * DOPW2_NCOL, 2) void doppler_tilew2_kernel(Dop
   }
 }
 
+// Tile variant for 1025 < nD <= 2049 with ONE wave per column (round 5): the 4096-point transform as FOUR one-wave
+// 1024-point transforms (fft_wave1k.hpp) of the samples 4 n + r, r = 0 ... 3, and a radix-4 step across them that never
+// leaves the lane -- the wave holds x[4 (T + 64 k) + r] in v[r][k], the sub-transforms are self-sorting (in T + 64 k, out
+// T + 64 a), so X[(T + 64 a) + 1024 q] = sum_r (-i)^(r q) W_4096^(r (T + 64 a)) X_r[T + 64 a] combines v[0..3][a] in
+// registers; the inverse is its mirror image and ends in the layout the forward transform started from.  No barrier and no
+// second wave inside a column: the structure of doppler_tilew_kernel, eight columns per 512-thread workgroup, instead of
+// doppler_tilew2_kernel's four pairs of waves behind workgroup-wide barriers.  MEASURED (round 5, cfg 5): parity-green at
+// the first run, and no faster -- 11.4 against 11.0 us/CPI at batch 8, 9.2 against 9.3 at batch 32:
+// the transforms are 30 % of its time, the row-piece stores and tile requests of a half tile (64-byte pieces: sixteen
+// cache lines per 1 KB instruction) 25 %, the three barriers 19 %.  Selectable (BLAH2HIP_DOP_TILEW4), not the default.
+// The price of one wave per column is registers and LDS: 128 data
+// registers per lane, so the kernel spectrum is read from L2 a quarter at a time, the stage twiddles W_4096^(r (T + 64 a)) are one product of a per-lane base and a constant, and the next
+// tile's cells are requested in two halves -- the upper rows after the spectrum product (they land during the inverse
+// transform), the lower ones after the column has been parked.  A column's region (2050 entries, stride = 2 mod 8) is its staging area and, in
+// its first 1088 entries, its exchange buffer: 8 x 16.0 KB + the 7.5 KB stage-twiddle table + the 18 KB chirp = 153.5 KB,
+// one workgroup per CU.
+constexpr int DOPW4_NCOL = 8;
+constexpr int DOPW4_MAX_ND = 2049;
+constexpr int DOPW4_RS = 2050; // 2049 rows + a spare slot; = 2 (mod 8) like doppler_tilew_kernel's
+constexpr int DOPW4_CHIRP_ELEMS = 2304; // rows 4 (t + 64 k) + r, k < 9
+static_assert(DOPW4_RS % 8 == 2 && DOPW4_RS > DOPW4_MAX_ND && Wave1kFft::X_ELEMS <= DOPW4_RS, "");
+constexpr int DOPW4_LDS_ELEMS = Wave1kFft::TW_ELEMS + DOPW4_NCOL * DOPW4_RS + DOPW4_CHIRP_ELEMS;
+// exp(-2 pi i j / 64), j = 0 ... 45 (r a, r <= 3, a <= 15)
+constexpr float DOPW4_W64[46][2] = {
+    {1.000000000f, -0.000000000f}, {0.995184727f, -0.098017140f}, {0.980785280f, -0.195090322f}, {0.956940336f, -0.290284677f},
+    {0.923879533f, -0.382683432f}, {0.881921264f, -0.471396737f}, {0.831469612f, -0.555570233f}, {0.773010453f, -0.634393284f},
+    {0.707106781f, -0.707106781f}, {0.634393284f, -0.773010453f}, {0.555570233f, -0.831469612f}, {0.471396737f, -0.881921264f},
+    {0.382683432f, -0.923879533f}, {0.290284677f, -0.956940336f}, {0.195090322f, -0.980785280f}, {0.098017140f, -0.995184727f},
+    {0.000000000f, -1.000000000f}, {-0.098017140f, -0.995184727f}, {-0.195090322f, -0.980785280f}, {-0.290284677f, -0.956940336f},
+    {-0.382683432f, -0.923879533f}, {-0.471396737f, -0.881921264f}, {-0.555570233f, -0.831469612f}, {-0.634393284f, -0.773010453f},
+    {-0.707106781f, -0.707106781f}, {-0.773010453f, -0.634393284f}, {-0.831469612f, -0.555570233f}, {-0.881921264f, -0.471396737f},
+    {-0.923879533f, -0.382683432f}, {-0.956940336f, -0.290284677f}, {-0.980785280f, -0.195090322f}, {-0.995184727f, -0.098017140f},
+    {-1.000000000f, -0.000000000f}, {-0.995184727f, 0.098017140f}, {-0.980785280f, 0.195090322f}, {-0.956940336f, 0.290284677f},
+    {-0.923879533f, 0.382683432f}, {-0.881921264f, 0.471396737f}, {-0.831469612f, 0.555570233f}, {-0.773010453f, 0.634393284f},
+    {-0.707106781f, 0.707106781f}, {-0.634393284f, 0.773010453f}, {-0.555570233f, 0.831469612f}, {-0.471396737f, 0.881921264f},
+    {-0.382683432f, 0.923879533f}, {-0.290284677f, 0.956940336f}};
+__global__ __launch_bounds__(64 * DOPW4_NCOL, 2) void doppler_tilew4_kernel(DopplerArgs a, int nCpi)
+{
+#ifdef DOPW_TRACE
+  uint64_t tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime();
+#define D4_T(k) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); tr[k] += now_ - t0_; t0_ = now_; }
+#else
+#define D4_T(k)
+#endif
+  using K = Wave1kFft;
+  constexpr int NCOL = DOPW4_NCOL, NT = 64 * NCOL, SH = 3;
+  constexpr int NK = 9;    // v[r][k], k < 9: rows 4 (t + 64 k) + r < 2304 cover nD <= 2049
+  constexpr int NRP = 17;  // tile cell PAIRS (two neighbouring columns, 16 bytes) per thread: nD * 4 / 512 <= 16.01
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double wsum[NCOL];
+  __shared__ float wmax[NCOL];
+  cf *table = reinterpret_cast<cf *>(smem);
+  cf *regions = table + K::TW_ELEMS;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, t = tid & 63; // wave = column of the half tile
+  const int nD = a.nD;
+  const int tilesPerCpi = (a.nDelay + NCOL - 1) / NCOL;
+  const int nTilesAll = tilesPerCpi * nCpi;
+  cf *region = regions + w * DOPW4_RS;
+
+  // a.tw = exp(-2 pi i k / 4096): the 1024-point roots are every fourth entry
+  for (int e = tid; e < K::TW_ELEMS; e += NT) table[e] = a.tw[4 * ((((e >> 6) + 1) * (e & 63)) & 1023)];
+  // The chirp (the same for every column) in LDS, zero beyond nD.  The interleaved column read touches rows up to 2303 of a
+  // 2050-entry region: what it finds there -- the next column's region, or the chirp behind the last one -- is finite and
+  // meets a zero chirp.  The regions start out finite too.
+  cf *chirpL = regions + NCOL * DOPW4_RS;
+  for (int i = tid; i < DOPW4_CHIRP_ELEMS; i += NT) {
+    const cf c = a.chirp[min(i, nD - 1)];
+    chirpL[i] = cmake(i < nD ? c.x : 0.f, i < nD ? c.y : 0.f);
+  }
+  for (int i = tid; i < NCOL * DOPW4_RS; i += NT) regions[i] = cmake(0.f, 0.f);
+  K::Tw tw;
+  tw.tab = table + t;
+  tw.w64 = a.tw[4 * 16 * (t & 31)];
+  tw.w32 = a.tw[4 * 32 * (t & 15)];
+  cf base[3]; // W_4096^(r t), r = 1, 2, 3
+#pragma unroll
+  for (int r = 1; r < 4; r++) base[r - 1] = a.tw[r * t];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  f4 nt[NRP];
+  auto tile_load = [&](int it, int j0, int j1) {
+    const int cpi = it / tilesPerCpi, sub = it - cpi * tilesPerCpi;
+    const cf *Rt = a.R + rmap_index(nD, a.nTiles, cpi, 0, sub * NCOL);
+    const __amdgpu_buffer_rsrc_t d = make_rsrc_b(Rt, (nD - 1) * 128 + NCOL * 8);
+    const int tl = relaunder(tid);
+    const int voff = (tl >> (SH - 1)) * 128 + (tl & (NCOL / 2 - 1)) * 16;
+#pragma unroll
+    for (int j = j0; j < j1; j++) {
+      const u4 r = __builtin_amdgcn_raw_buffer_load_b128(d, voff, j * (NT >> (SH - 1)) * 128, 0);
+      nt[j] = f4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+    }
+  };
+  int it = blockIdx.x;
+  if (it < nTilesAll) tile_load(it, 0, NRP);
+  __syncthreads(); // table, zeroed regions
+  for (; it < nTilesAll; it += gridDim.x) {
+    const int cpi = it / tilesPerCpi, sub = it - cpi * tilesPerCpi;
+    const int col0 = sub * NCOL;
+    // phase 1: the tile, transposed into the per-column regions
+    {
+      const int tl = relaunder(tid);
+      cf *dst = regions + (2 * (tl & (NCOL / 2 - 1))) * DOPW4_RS + (tl >> (SH - 1)); // pair idx + 512 j: same columns, row + 128 j
+#pragma unroll
+      for (int j = 0; j < NRP; j++) { // rows up to 2049 (the zeros of rows >= nD included); the last pair's rows beyond: dropped
+        if (j < NRP - 1 || (tl >> (SH - 1)) + (NT >> (SH - 1)) * j < DOPW4_RS) {
+          dst[(NT >> (SH - 1)) * j] = cmake(nt[j].x, nt[j].y);
+          dst[DOPW4_RS + (NT >> (SH - 1)) * j] = cmake(nt[j].z, nt[j].w);
+        }
+      }
+    }
+    D4_T(0)
+    __syncthreads();
+    D4_T(1)
+
+    // phase 2: this wave's column -> registers, rows 4 (t + 64 k) + r (DC removal + chirp)
+    cf v[4][16];
+    const cf r0 = region[0];
+    {
+      const int t2 = relaunder(t);
+#pragma unroll
+      for (int k = 0; k < NK; k++) { // (a row group at a time: all 36 chirp values requested at once are 72 registers)
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r][k] = cmul(csub(region[4 * t2 + 256 * k + r], r0), chirpL[4 * t2 + 256 * k + r]); // rows >= nD: (finite - r0) * 0
+        if (k & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cf bfa[16], bfb[16];
+    const cf *bfp = a.bfn + relaunder(t);
+    auto bf_load = [&](cf *dst, int q) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) dst[e] = bfp[64 * e + 1024 * q];
+    };
+    bf_load(bfa, 0);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    D4_T(2)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      K::transform<-1, 9>(t, v[r], tw, region);
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    D4_T(3)
+    // radix 4 across the sub-transforms: v[q][e] = X[(t + 64 e) + 1024 q]
+    // (The 45 constants W_64^(r e) must not be materialised ahead of their use: as operands of the packed-arithmetic asm they
+    // are two VGPRs each, loop-invariant, and hoisted out of the tile loop they are 90 registers.  Each is a literal plus a
+    // zero the compiler cannot see through, produced next to its one use.)
+    float zf = 0.f;
+    asm volatile("" : "+v"(zf));
+    auto w64 = [&](int j) -> cf { return cmake(DOPW4_W64[j][0] + zf, DOPW4_W64[j][1] + zf); };
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const cf t0 = v[0][e];
+      const cf t1 = cmul(v[1][e], e ? cmul(base[0], w64(e)) : base[0]);
+      const cf t2 = cmul(v[2][e], e ? cmul(base[1], w64(2 * e)) : base[1]);
+      const cf t3 = cmul(v[3][e], e ? cmul(base[2], w64(3 * e)) : base[2]);
+      const cf s02 = cadd(t0, t2), d02 = csub(t0, t2), s13 = cadd(t1, t3), d13 = csub(t1, t3);
+      v[0][e] = cadd(s02, s13);
+      v[2][e] = csub(s02, s13);
+      v[1][e] = cadd_i<-1>(d02, d13); // d02 - i d13
+      v[3][e] = csub_i<-1>(d02, d13); // d02 + i d13
+      if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    // x kernel spectrum (natural order, 32 KB shared by every workgroup: L2), a quarter at a time through two buffers of
+    // sixteen: the first quarter was requested before the forward transforms, each next one before the previous product
+    __builtin_amdgcn_sched_barrier(0);
+    bf_load(bfb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[0][e] = cmul(v[0][e], bfa[e]);
+    __builtin_amdgcn_sched_barrier(0);
+    bf_load(bfa, 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[1][e] = cmul(v[1][e], bfb[e]);
+    __builtin_amdgcn_sched_barrier(0);
+    bf_load(bfb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[2][e] = cmul(v[2][e], bfa[e]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[3][e] = cmul(v[3][e], bfb[e]);
+    __builtin_amdgcn_sched_barrier(0);
+    D4_T(4)
+    const bool more = it + (int)gridDim.x < nTilesAll;
+    // the inverse: radix 4 across q, conjugate twiddles, four inverse sub-transforms
+    asm volatile("" : "+v"(zf));
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const cf y0 = v[0][e], y1 = v[1][e], y2 = v[2][e], y3 = v[3][e];
+      const cf s02 = cadd(y0, y2), d02 = csub(y0, y2), s13 = cadd(y1, y3), d13 = csub(y1, y3);
+      v[0][e] = cadd(s02, s13);
+      const cf z1 = cadd_i<+1>(d02, d13); // d02 + i d13
+      const cf z2 = csub(s02, s13);
+      const cf z3 = csub_i<+1>(d02, d13); // d02 - i d13
+      v[1][e] = cmulc(z1, e ? cmul(base[0], w64(e)) : base[0]);
+      v[2][e] = cmulc(z2, e ? cmul(base[1], w64(2 * e)) : base[1]);
+      v[3][e] = cmulc(z3, e ? cmul(base[2], w64(3 * e)) : base[2]);
+      if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // the four inverse sub-transforms; the rows are parked only after the last one (a parked row's slot can lie in the
+    // exchange area, the region's first 1088 entries)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      K::transform<+1>(t, v[r], tw, region);
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    D4_T(5)
+    // phase 3: chirp, rotate rows by nD/2 + 1, park the column back in its region
+    {
+      const int t3 = relaunder(t);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+          const int i = 4 * t3 + 256 * k + r;
+          cf d = cmul(v[r][k], chirpL[i]);
+          if (k == 0 && r == 0 && t3 == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
+          int o = i - (nD / 2 + 1);
+          if (o < 0) o += nD;
+          region[i < nD ? o : DOPW4_RS - 1] = d; // rows beyond nD go to a spare slot: no branch per row
+          if (k == 4) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next tile: requested once the column's 128 data registers are free (68 registers of cells held through the
+    // inverse transform spill), in flight during the barrier and the row stores
+    // (unconditionally -- a workgroup's last iteration requests its own tile again: behind `if (more)` the cells of the
+    // previous request would count as live through the whole loop body, 68 registers the transforms do not have)
+    tile_load(more ? it + (int)gridDim.x : it, 0, NRP);
+    D4_T(6)
+    __syncthreads();
+    D4_T(1)
+
+    // phase 4: coalesced row-segment stores + Map::set_metrics partials
+    double lsum = 0.0;
+    float lmax = 0.f;
+    const int ncol = min(NCOL, a.nDelay - col0);
+    const int tl4 = relaunder(tid);
+    const bool wide = (a.nDelay & 1) == 0; // 16-byte row pieces need the rows to start 16-byte aligned
+    {
+      const __amdgpu_buffer_rsrc_t md = make_rsrc_b(a.map + (size_t)cpi * nD * a.nDelay, nD * a.nDelay * 8);
+      const int pc = tl4 & (NCOL / 2 - 1), o0 = tl4 >> (SH - 1);
+      const cf *src = regions + (2 * pc) * DOPW4_RS + o0;
+      const bool c0 = 2 * pc < ncol, c1 = 2 * pc + 1 < ncol;
+      const int off = (o0 * a.nDelay + col0 + 2 * pc) * 8;
+      const int rstep = (NT >> (SH - 1)) * a.nDelay * 8;
+#pragma unroll
+      for (int j = 0; j < NRP; j++) {
+        const int rj = min((NT >> (SH - 1)) * j, DOPW4_RS - 1 - o0); // (the last pair's rows beyond the region: any slot, not stored)
+        const cf d0 = src[rj], d1 = src[DOPW4_RS + rj];
+        if (wide) { // ncol is even with nDelay: both columns or none
+          const u4 q = {__float_as_uint(d0.x), __float_as_uint(d0.y), __float_as_uint(d1.x), __float_as_uint(d1.y)};
+          __builtin_amdgcn_raw_buffer_store_b128(q, md, c1 ? off : -1, j * rstep, 0);
+        } else {
+          bufstore_c32(md, (c0 ? off : -1), d0, j * rstep);
+          bufstore_c32(md, (c1 ? off + 8 : -1), d1, j * rstep);
+        }
+        const bool inr = o0 + (NT >> (SH - 1)) * j < nD;
+        const bool ok0 = inr && c0, ok1 = inr && c1;
+        const float db0 = db_of(d0), db1 = db_of(d1);
+        lsum += (ok0 ? (double)db0 : 0.0) + (ok1 ? (double)db1 : 0.0);
+        lmax = ok0 ? fmaxf(lmax, db0) : lmax;
+        lmax = ok1 ? fmaxf(lmax, db1) : lmax;
+      }
+    }
+    wave_sum_max(lsum, lmax);
+    if (t == 0) { const int wl = relaunder(tid) >> 6; wsum[wl] = lsum; wmax[wl] = lmax; }
+    D4_T(7)
+    __syncthreads(); // also: every thread has taken its rows out of the regions
+    if (tid == 0) {
+      double sacc = 0.0;
+      float m = 0.f; // Map.cpp:193: the running max starts at 0
+      for (int i = 0; i < NCOL; i++) { sacc += wsum[i]; m = fmaxf(m, wmax[i]); }
+      const size_t part = (size_t)cpi * tilesPerCpi + sub;
+      a.partSum[part] = sacc;
+      a.partMax[part] = m;
+    }
+    D4_T(1)
+  }
+#ifdef DOPW_TRACE // buckets: fill, barriers, column read, forward transforms, combine + spectrum, inverse, park + next tile's requests, stores
+  if (t == 0) trace_finish("dopw4", tr, blockIdx.x == 0);
+#endif
+}
+
 // Tile variant for multi-wave columns: 513 < nD <= 1025 (M = 2048, R3 = 8: a column is a
 // 128-thread, two-wave transform, 8 columns per 1024-thread workgroup) and 1025 < nD <= 2049
 // (M = 4096, R3 = 16: 256 threads per column, 4 columns per workgroup).  Same phases as

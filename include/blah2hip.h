@@ -154,6 +154,7 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 #define BLAH2HIP_DOP_TILEW 6   /* 513 < nD <= 1025: one-wave 2048-point columns, 8 per workgroup */
 #define BLAH2HIP_DOP_TILEW2 7  /* 1025 < nD <= 2049: two-wave 4096-point columns, 4 per workgroup */
 #define BLAH2HIP_DOP_TILE16WG 8 /* TILE16 on the workgroup transform of rounds 1-2 (twiddles in registers; kept for comparison) */
+#define BLAH2HIP_DOP_TILEW4 11 /* 1025 < nD <= 2049: ONE wave per column, the 4096-point transform as four one-wave 1024-point transforms + a radix-4 step in registers, 8 columns per workgroup (round 5) */
 #define BLAH2HIP_DOP_TILE8K 10 /* nD <= 513: TILE16's kernel on 8-column half tiles, two workgroups per CU (round 5) */
 #define BLAH2HIP_DOP_SUB4 9    /* nD <= 513, small launches (a lone CPI): 4-column workgroups, one wave per SIMD; Map::set_metrics finished by the last workgroup */
 #define BLAH2HIP_RANGE_E16 1   /* 16 points per thread, one workgroup per pulse (F = 4096; F = 2048 on request) */

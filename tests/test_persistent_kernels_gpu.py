@@ -112,3 +112,21 @@ def test_two_wave_tile_kernel(b2, fmax, n, nD, ndelay):
     assert amb.info(_lib.INFO_DOPPLER_FFT_LEN) == 4096
     grid, tiles = _assert_steady(amb)
     assert grid == 32 and tiles == 3 * 19 * 4
+
+
+@pytest.mark.parametrize("fmax,n,nD", [(513, 2_054_000, 1027), (800, 3_202_000, 1601), (1024, 4_098_000, 2049)])
+@pytest.mark.parametrize("ndelay,grid", [(300, 5), (304, 7)])
+def test_one_wave_4096_tile_kernel(b2, fmax, n, nD, ndelay, grid):
+    """doppler_tilew4_kernel (round 5; 1025 < nD <= 2049: ONE wave per column, the 4096-point transform as four one-wave
+    1024-point transforms of the samples 4 n + r and a radix-4 step across them in registers, eight columns per persistent
+    workgroup), forced, on 5 / 7 workgroups: three CPIs x 38 half tiles, 16-23 iterations per workgroup across CPI
+    boundaries, a ragged last half tile (300 = 37 x 8 + 4) and both store widths (odd / even delay counts); every CPI
+    against the oracle."""
+    from blah2_amd import _lib
+    geom = (-7, ndelay - 8, -fmax, fmax, n, n)
+    amb = run_batch(b2, geom, 3, "tilew4", seeds=(195 + nD, 196 + nD, 197 + nD), targets=((37, -13.0, 0.05),), cell_tol=1e-4,
+                    doppler_grid=grid)
+    assert amb.get_n_doppler_bins() == nD and amb.get_n_delay_bins() == ndelay
+    assert amb.info(_lib.INFO_DOPPLER_FFT_LEN) == 4096
+    g, tiles = _assert_steady(amb)
+    assert g == grid and tiles == 3 * 38
