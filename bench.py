@@ -652,7 +652,7 @@ def main(argv=None):
     ap.add_argument("--n-doppler", type=int, default=0,
                     help="explicit number of Doppler bins (extension; 0 = the reference constructor's rule, which gives "
                          "513 at the headline configuration; 512 gives the literal BASELINE wording)")
-    ap.add_argument("--doppler-kernel", default="auto", help="force a Doppler kernel (auto, tile8, tile8k, tile16, tile16wg, sub4, tilew, tilew2, tilem, column, direct)")
+    ap.add_argument("--doppler-kernel", default="auto", help="force a Doppler kernel (auto, tile8, tile8k, tile16, tile16wg, sub4, tilew, tilew2, tilew4, tilem, column, direct)")
     ap.add_argument("--prewarm-s", type=float, default=0.6,
                     help="seconds of untimed steps BEFORE the W warmup steps: the shader clock needs ~0.3 s of load to ramp up "
                          "from idle (measured: steps 5..25 of a cold run are 4-5 %% slower than steady state)")
