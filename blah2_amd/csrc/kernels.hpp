@@ -2056,6 +2056,7 @@ __global__ __launch_bounds__(64 * DOPW4_NCOL, 2) void doppler_tilew4_kernel(Dopp
   if (t == 0) trace_finish("dopw4", tr, blockIdx.x == 0);
 #endif
 }
+#undef D4_T
 
 // Tile variant for multi-wave columns: 513 < nD <= 1025 (M = 2048, R3 = 8: a column is a
 // 128-thread, two-wave transform, 8 columns per 1024-thread workgroup) and 1025 < nD <= 2049
