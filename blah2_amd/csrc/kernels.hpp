@@ -1075,6 +1075,12 @@ template <int NCOL> constexpr int dopt1k_lds_elems() { return NCOL * DOPT_PITCH 
 constexpr int DOPT1K_LDS_ELEMS = dopt1k_lds_elems<16>();
 template <int NCOL> __global__ __launch_bounds__(64 * NCOL, 4) void doppler_tile1k_kernel(DopplerArgs a, int nCpi)
 {
+#ifdef DOPW_TRACE
+  uint64_t tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime();
+#define D1_T(k) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); tr[k] += now_ - t0_; t0_ = now_; }
+#else
+#define D1_T(k)
+#endif
   using K = Wave1kFft;
   static_assert(NCOL == 16 || NCOL == 8, "");
   constexpr int T = 64, NR = 9, NT = 64 * NCOL, SH = NCOL == 16 ? 4 : 3;
@@ -1142,7 +1148,9 @@ template <int NCOL> __global__ __launch_bounds__(64 * NCOL, 4) void doppler_tile
       for (int j = 0; j < NR; j++)
         if (tl + NT * j < cells) dst[T * j] = nt[j];
     }
+    D1_T(0)
     __syncthreads();
+    D1_T(1)
 
     // phase 2: this wave's column -> registers (DC removal + chirp), next tile's loads, both transforms
     cf v[16];
@@ -1152,7 +1160,9 @@ template <int NCOL> __global__ __launch_bounds__(64 * NCOL, 4) void doppler_tile
       v[k] = cmul(csub(region[NCOL == 16 ? ridx[k] : min(t + T * k, nD - 1)], r0), ch[k]);
     if (it + (int)gridDim.x < nTilesAll) tile_load(it + gridDim.x, 0, PRE);
     __builtin_amdgcn_wave_barrier();
+    D1_T(2)
     K::transform<-1, 9>(t, v, tw, region);
+    D1_T(3)
     if constexpr (BF_FULL) {
 #pragma unroll
       for (int e = 0; e < 16; e++) v[e] = cmul(v[e], bfL[e * T + t]);
@@ -1163,8 +1173,10 @@ template <int NCOL> __global__ __launch_bounds__(64 * NCOL, 4) void doppler_tile
       for (int e = 8; e < 16; e++) v[e] = cmul(v[e], bfL[(16 - e) * T - t]);
     }
     __builtin_amdgcn_wave_barrier();
+    D1_T(4)
     K::transform<+1>(t, v, tw, region);
     __builtin_amdgcn_wave_barrier();
+    D1_T(3)
 
     // phase 3: chirp, rotate rows by nD/2 + 1, park the column back in its region
     {
@@ -1182,7 +1194,9 @@ template <int NCOL> __global__ __launch_bounds__(64 * NCOL, 4) void doppler_tile
         }
       }
     }
+    D1_T(5)
     __syncthreads();
+    D1_T(1)
 
     // phase 4: coalesced row-segment stores + Map::set_metrics partials
     double lsum = 0.0;
@@ -1207,6 +1221,7 @@ template <int NCOL> __global__ __launch_bounds__(64 * NCOL, 4) void doppler_tile
     }
     wave_sum_max(lsum, lmax);
     if (t == 0) { const int wl = relaunder(tid) >> 6; wsum[wl] = lsum; wmax[wl] = lmax; }
+    D1_T(6)
     __syncthreads(); // also: every thread has taken its rows out of the regions
     if (tid == 0) {
       double sacc = 0.0;
@@ -1216,8 +1231,13 @@ template <int NCOL> __global__ __launch_bounds__(64 * NCOL, 4) void doppler_tile
       a.partSum[part] = sacc;
       a.partMax[part] = m;
     }
+    D1_T(1)
   }
+#ifdef DOPW_TRACE // buckets: fill, barriers, column read + next tile's requests, transforms, kernel-spectrum product, park, stores + metrics
+  if (t == 0) trace_finish("dop1k", tr, blockIdx.x == 0);
+#endif
 }
+#undef D1_T
 
 // The reduction of metrics_kernel (below) by the 256 threads of a workgroup: the same order of operations, so that the
 // fused finish and the separate launch give the same bits.
