@@ -1280,6 +1280,12 @@ constexpr int DOPS_NCOL = 4;
 constexpr int DOPS_LDS_ELEMS = DOPS_NCOL * DOPT_PITCH + Wave1kFft::TW_ELEMS + 1024;
 __global__ __launch_bounds__(64 * DOPS_NCOL) void doppler_sub1k_kernel(DopplerArgs a, int nCpi)
 {
+#ifdef DOPW_TRACE
+  uint64_t tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime();
+#define DS_T(k) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); tr[k] += now_ - t0_; t0_ = now_; }
+#else
+#define DS_T(k)
+#endif
   using K = Wave1kFft;
   constexpr int NCOL = DOPS_NCOL, T = 64, NR = 9, NT = 64 * NCOL, SH = 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1333,7 +1339,9 @@ __global__ __launch_bounds__(64 * DOPS_NCOL) void doppler_sub1k_kernel(DopplerAr
     for (int j = 0; j < NR; j++)
       if (tid + NT * j < cells) dst[T * j] = nt[j];
   }
+  DS_T(0)
   __syncthreads(); // tables and tile
+  DS_T(1)
   K::Tw tw;
   K::load_twiddles(t, a.tw, table, tw);
 
@@ -1343,12 +1351,14 @@ __global__ __launch_bounds__(64 * DOPS_NCOL) void doppler_sub1k_kernel(DopplerAr
 #pragma unroll
   for (int k = 0; k < NR; k++) v[k] = cmul(csub(region[ridx[k]], r0), ch[k]);
   __builtin_amdgcn_wave_barrier();
+  DS_T(2)
   K::transform<-1, 9>(t, v, tw, region);
 #pragma unroll
   for (int e = 0; e < 16; e++) v[e] = cmul(v[e], bfL[e * T + t]);
   __builtin_amdgcn_wave_barrier();
   K::transform<+1>(t, v, tw, region);
   __builtin_amdgcn_wave_barrier();
+  DS_T(3)
 
   // phase 3: chirp, rotate rows by nD/2 + 1, park the column back in its region
 #pragma unroll
@@ -1357,7 +1367,9 @@ __global__ __launch_bounds__(64 * DOPS_NCOL) void doppler_sub1k_kernel(DopplerAr
     if (c == 0 && t == 0) d = cmake(d.x + (float)nD * r0.x, d.y + (float)nD * r0.y);
     region[oidx[c]] = d;
   }
+  DS_T(4)
   __syncthreads();
+  DS_T(1)
 
   // phase 4: row-piece stores (32 bytes) + Map::set_metrics partials
   double lsum = 0.0;
@@ -1381,7 +1393,9 @@ __global__ __launch_bounds__(64 * DOPS_NCOL) void doppler_sub1k_kernel(DopplerAr
   }
   wave_sum_max(lsum, lmax);
   if (t == 0) { ssum[w] = lsum; smax[w] = lmax; }
+  DS_T(5)
   __syncthreads();
+  DS_T(1)
   if (tid == 0) {
     double sacc = 0.0;
     float m = 0.f; // Map.cpp:193: the running max starts at 0
@@ -1403,7 +1417,12 @@ __global__ __launch_bounds__(64 * DOPS_NCOL) void doppler_sub1k_kernel(DopplerAr
   }
   __syncthreads();
   if (lastWg) metrics_finish_256(a.partSum, a.partMax, subsPerCpi, cpi, (double)nD * (double)a.nDelay, a.metrics, ssum, smax);
+  DS_T(6)
+#ifdef DOPW_TRACE // buckets: requests + tables + tile fill, barriers, column read, transforms + product, park, stores + metrics, ticket + finish
+  if (t == 0) trace_finish("dops", tr, blockIdx.x == 0);
+#endif
 }
+#undef DS_T
 
 // Tile variant for 513 < nD <= 1025 on the ONE-WAVE 2048-point transform (fft_wave.hpp): the phases of
 // doppler_tile_kernel<8> with one wave per column doing both transforms of the chirp-z convolution in
