@@ -223,37 +223,52 @@ def e2e_host(cfg, local, np, blah2_amd):
 
 
 # ----------------------------------------------------------------------------- parity gate
-def parity_check(np, O, cfg, fmt, chain, cfar, n_doppler, x_h, y_h, got_map, got_met, got_hits=None, amb=None):
-    """One CPI of the timed batch against the fp64 oracle.  x_h / y_h: the exact values the device read."""
+def parity_check(np, O, G, cfg, fmt, chain, cfar, n_doppler, x_h, y_h, got_map, got_met, det_params=None, got_hits=None,
+                 got_ok=None):
+    """One CPI of the timed batch against the fp64 oracle, by the gates of oracle/gates.py (= SURVEY.md 8d, the ones the
+    tests apply).  x_h / y_h: the exact values the device read.  For the full chain also: the filter's ``ok`` flag and the
+    detector's hit list ``got_hits`` = (delay[], doppler[]) of this CPI, by the margin rule sized from the measured map error."""
     dmin, dmax, fmin, fmax, fs, n = cfg
     d = O.ambiguity_dims(dmin, dmax, fmin, fmax, fs, n, True, n_doppler_bins=n_doppler)
     res = {}
+    got = got_map.astype(np.complex128)
     if chain == "full":
         ok, yf, w, r, b = O.wiener_hopf(x_h, y_h, dmin, dmax, return_filter=True)
         ref = O.ambiguity_process(d, x_h, yf)
+        noise, mx = O.map_metrics(ref)
         level = float(np.max(np.abs(b))) * (d.n_corr * d.n_doppler_bins / n)  # uncancelled direct-path level
-        err = np.abs(got_map.astype(np.complex128) - ref)
-        res["chain_err_over_direct_path"] = float(err.max() / level)
-        res["pass"] = bool(ok and res["chain_err_over_direct_path"] <= GATE_CHAIN_DIRECT)
+        res["chain_err_over_direct_path"] = float(np.abs(got - ref).max() / level)
+        res["filter_ok"] = bool(ok) == bool(got_ok) if got_ok is not None else None
+        res["pass"] = bool(ok and res["chain_err_over_direct_path"] <= GATE_CHAIN_DIRECT and res["filter_ok"] is not False)
+        nm = G.notch_mask(ref.shape, d.doppler, d.delay, dmin, dmax)
+        cell = G.map_cell_gate(got, ref, noise, notch=nm)                          # 1e-4 on every cell above the map's own mean level
+        dbg = G.db_map_gate(got, got_met[0], ref, noise, notch=nm)
+        res["cell_rel_above_mean"], res["peak_rel"] = cell["cell_rel_above_mean"], cell["peak_rel"]
+        res["cell_rel_above_mean_outside_notch"] = cell["cell_rel_above_mean_outside_notch"]
+        res["db_max"], res["db_max_all_cells"] = dbg["db_max_shown"], dbg["db_max_all"]
+        res["notch_db_max"], res["notch_abs_err_over_mean_level"] = dbg.get("notch_db_max"), dbg.get("notch_abs_err_over_mean_level")
+        res["pass"] = bool(res["pass"] and cell["ok"] and dbg["ok"])
+        if got_hits is not None:
+            if cfar == "2d":
+                dl, dp, _, margin = O.cfar2d(ref, d.delay, d.doppler, noise, *det_params, return_margin=True)
+            else:
+                dl, dp, _ = O.cfar1d_fast(ref, d.delay, d.doppler, noise, *det_params)
+                margin = G.cfar1d_margins(ref, det_params[0], det_params[1], det_params[2])
+            dg = G.detection_gate(zip(dl, dp), zip(*got_hits), margin, d.doppler, d.delay[0], G.margin_eps(cell))
+            res["detections_ok"] = dg["ok"]
+            res["detections"] = {k: dg[k] for k in ("n_ref", "n_got", "n_differ", "margin_tol", "worst_margin_off_one")}
+            res["pass"] = bool(res["pass"] and dg["ok"])
     else:
         ref = O.ambiguity_process(d, x_h, y_h)
-        err = np.abs(got_map.astype(np.complex128) - ref)
-        res["peak_rel"] = float(err.max() / np.abs(ref).max())
-        res["pass"] = bool(res["peak_rel"] <= GATE_PEAK_REL)
-    noise, mx = O.map_metrics(ref)
-    with np.errstate(divide="ignore"):
-        db_got = 10.0 * np.log10(np.abs(got_map.astype(np.complex128))) - got_met[0]
-        db_ref = 10.0 * np.log10(np.abs(ref)) - noise
-    if chain != "full":  # after cancellation the weakest cells are rounding noise in both
-        d_db = np.abs(db_got - db_ref)
-        shown = db_ref >= -DB_FLOOR
-        floor_level = 10.0 ** ((noise - DB_FLOOR) / 10.0)
-        res["db_max"] = float(d_db[shown].max())               # the gated figure: cells within DB_FLOOR of the mean level
-        res["db_max_all_cells"] = float(d_db.max())            # reported: includes the deep nulls
-        res["cells_over_gate_below_floor"] = int((d_db[~shown] > GATE_DB_MAP).sum())
-        res["abs_err_below_floor_over_floor_level"] = float(err[~shown].max() / floor_level) if (~shown).any() else 0.0
-        res["pass"] = bool(res["pass"] and res["db_max"] <= GATE_DB_MAP
-                           and res["abs_err_below_floor_over_floor_level"] <= 10.0 ** (GATE_DB_MAP / 10.0) - 1.0)
+        noise, mx = O.map_metrics(ref)
+        cell = G.map_cell_gate(got, ref, noise, peak_tol=GATE_PEAK_REL)
+        dbg = G.db_map_gate(got, got_met[0], ref, noise)
+        res["peak_rel"], res["cell_rel_above_mean"] = cell["peak_rel"], cell["cell_rel_above_mean"]
+        res["db_max"] = dbg["db_max_shown"]                    # the gated figure: cells within DB_FLOOR of the mean level
+        res["db_max_all_cells"] = dbg["db_max_all"]            # reported: includes the deep nulls
+        res["cells_over_gate_below_floor"] = dbg["cells_over_all"] - dbg["cells_over_shown"]
+        res["abs_err_below_floor_over_floor_level"] = dbg["abs_err_over_floor_level"]
+        res["pass"] = bool(cell["ok"] and dbg["ok"])
     res["metrics_db"] = float(max(abs(got_met[0] - noise), abs(got_met[1] - mx)))
     res["pass"] = bool(res["pass"] and res["metrics_db"] <= GATE_METRICS_DB)
     return res
@@ -263,16 +278,30 @@ def parity_check(np, O, cfg, fmt, chain, cfar, n_doppler, x_h, y_h, got_map, got
 def measure(a, env):
     """One bench line's worth of measurement for the configuration in ``a``: data, handles, the timed region (barrier +
     synchronize on both sides), a second region with every kernel bracketed by HIP events, the parity gate.  Returns
-    (result dict on rank 0 else None, parity dict or None).  Frees what it allocated: the default run calls it once for
-    the headline and once per secondary BASELINE configuration (``config_legs``)."""
+    (result dict on rank 0 else None, parity dict or None).  Frees what it allocated, also when it raises: the default run
+    calls it once for the headline and once per secondary BASELINE configuration (``config_legs``)."""
+    handles = []
+    try:
+        return _measure(a, env, handles)
+    finally:
+        for h_ in handles:
+            try:
+                h_.close()
+            except Exception as e:  # a close that fails must not hide what the measurement raised
+                print(f"bench.py: closing an engine handle failed: {e}", file=sys.stderr)
+
+
+def _measure(a, env, handles):
     torch, np, blah2_amd = env.torch, env.np, env.b2
     rank, world, local, dev, dist = env.rank, env.world, env.local, env.dev, env.dist
     cfg, cfg_desc = CONFIGS[a.config]
     dmin, dmax, fmin, fmax, fs, n = cfg
     B = a.batch if a.batch > 0 else ({"cfg3": 256 if a.chain == "full" else 32, "cfg5": 8, "small": 1024}.get(a.config, 256))
     NS = max(1, a.streams)  # independent batches in flight, each on its own stream with its own handles and result buffers
-    ambs = [blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B, n_doppler_bins=a.n_doppler)
-            for _ in range(NS)]
+    ambs = []
+    for _ in range(NS):
+        ambs.append(blah2_amd.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, device=local, max_batch=B, n_doppler_bins=a.n_doppler))
+        handles.append(ambs[-1])
     for h_ in ambs:
         h_.set_doppler_kernel(a.doppler_kernel)
         if a.fft_len:
@@ -310,15 +339,18 @@ def measure(a, env):
             raise SystemExit("--chain full needs --fmt c32 or i16")
         # one filter handle and one set of intermediate / result buffers per stream: with --streams 2 the (latency-bound, few
         # workgroups) Toeplitz solve of one batch runs beside the transforms of the other
-        whs = [blah2_amd.WienerHopf(dmin, dmax, n, device=local, max_batch=B) for _ in range(NS)]  # config.yml uses the same lag window
+        whs = []
+        for _ in range(NS):
+            whs.append(blah2_amd.WienerHopf(dmin, dmax, n, device=local, max_batch=B))  # config.yml uses the same lag window
+            handles.append(whs[-1])
         wh = whs[0]
         yfilts = [torch.empty((B, n), dtype=torch.complex64, device=dev) for _ in range(NS)]
         okflags = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NS)]
         hitss = [torch.zeros((B, CAP, 2), dtype=torch.float64, device=dev) for _ in range(NS)]  # 16-byte records
         hitcnts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NS)]
         yfilt, okflag, hits, hitcnt = yfilts[0], okflags[0], hitss[0], hitcnts[0]
-        det = (blah2_amd.CfarDetector2D(1e-5, 2, 6, 1, 3, 5, 15.0) if a.cfar == "2d"
-               else blah2_amd.CfarDetector1D(1e-5, 2, 6, 5, 15.0))  # config.yml:36-40 (+ Doppler guard 1, train 3)
+        det_params = (1e-5, 2, 6, 1, 3, 5, 15.0) if a.cfar == "2d" else (1e-5, 2, 6, 5, 15.0)  # config.yml:36-40 (+ Doppler guard 1, train 3)
+        det = blah2_amd.CfarDetector2D(*det_params) if a.cfar == "2d" else blah2_amd.CfarDetector1D(*det_params)
     outs = [torch.zeros((B, nD, nC), dtype=torch.complex64, device=dev) for _ in range(NS)]
     mets = [torch.zeros((B, 2), dtype=torch.float64, device=dev) for _ in range(NS)]
     out, met = outs[0], mets[0]
@@ -389,11 +421,43 @@ def measure(a, env):
         elapsed, ranks_seen = float(t[0].item()), int(round(float(t[1].item())))
         assert ranks_seen == world
 
-    # the last timed step's outputs, kept for the parity gate
+    # the same region again, long enough (>= --long-s) that clock ramps and box-to-box jitter average out: `headline_long`
     last = a.warmup + a.steps - 1
+    long_res = None
+    if a.long_s > 0:
+        n_long = int(min(20000, max(a.steps, math.ceil(a.long_s / (elapsed / a.steps)))))
+        sync()
+        t0 = time.perf_counter()
+        for i in range(n_long):
+            step(a.warmup + a.steps + i)
+        sync()
+        el_long = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el_long], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_long = float(t.item())
+        last = a.warmup + a.steps + n_long - 1
+        long_res = {"steps": n_long, "seconds": el_long, "ms_per_step": el_long / n_long * 1e3,
+                    "value": world * B * n_long / el_long, "unit": "CPIs/s", "us_per_cpi": el_long / (B * n_long) * 1e6,
+                    "chain_frac": (2 * n * s_in + cells * 8) * B * n_long / el_long / 1e9 / HBM_PEAK_GBS,
+                    "note": "the timed region of `value` repeated for >= --long-s seconds (same steps, same buffers, barrier + "
+                            "synchronize on both sides, max over ranks); `value` itself stays the driver's --steps region"}
+
+    # the last timed step's outputs, kept for the parity gate
     q_last, r_last = (last % NS, last % ring)
     keep_map = outs[q_last][[0, B - 1]].cpu().numpy()
     keep_met = mets[q_last][[0, B - 1]].cpu().numpy()
+    keep_ok = keep_hits = None
+    if wh is not None:  # what the filter and the detector of the timed chain left for the same two CPIs
+        keep_ok = okflags[q_last][[0, B - 1]].cpu().numpy()
+        keep_cnt = hitcnts[q_last][[0, B - 1]].cpu().numpy()
+        keep_hits = []
+        for c_, k_ in zip((0, B - 1), keep_cnt):
+            if int(k_) > CAP:
+                raise RuntimeError(f"bench.py: {int(k_)} detections in CPI {c_}, capacity {CAP}")
+            rec = hitss[q_last][c_, :max(int(k_), 1)].cpu().numpy().view(blah2_amd.HIT_DTYPE).reshape(-1)
+            dt_ = blah2_amd.hits_to_detection(ambs[q_last], rec, int(k_), CAP)
+            keep_hits.append((dt_.get_delay(), dt_.get_doppler()))
 
     # second, identical region with every kernel bracketed by HIP events on the
     # launch stream: per-kernel durations for the roofline line
@@ -487,6 +551,17 @@ def measure(a, env):
     e1.record()
     torch.cuda.synchronize()
     copy_gbs = 10 * 2 * src_.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    # ... and what the memory system delivers to a kernel that only READS (16-byte loads over the same 1 GiB): the ceiling
+    # for the range kernel, whose traffic is 99 % loads (blah2hip_stream_read_dev, csrc/capi.hip)
+    L_ = blah2_amd._lib.load()
+    for _ in range(3):
+        blah2_amd._lib.check(L_.blah2hip_stream_read_dev(src_.data_ptr(), src_.numel() * 4, None, st))
+    e0.record()
+    for _ in range(10):
+        blah2_amd._lib.check(L_.blah2hip_stream_read_dev(src_.data_ptr(), src_.numel() * 4, None, st))
+    e1.record()
+    torch.cuda.synchronize()
+    read_gbs = 10 * src_.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del src_, dst_
     # reference-formulation flops per CPI (5 n log2 n per FFT, 3 nfft-point FFTs
     # per pulse + one nD-point FFT per delay column) -- what the CPU path would execute
@@ -497,6 +572,7 @@ def measure(a, env):
     parity = None
     if rank == 0 and not a.no_parity:
         from oracle import blah2_oracle as O  # checker only; nothing above this line touched it
+        from oracle import gates as G         # the gates the tests apply, stated once
         checks = []
         for slot, c in enumerate((0, B - 1) if B > 1 else (0,)):  # the last CPI's tiles are later iterations of the persistent kernels
             if a.parity_cpis == "last" and c != B - 1:
@@ -510,17 +586,30 @@ def measure(a, env):
             else:
                 v = iqs[r_last][c].cpu().numpy().astype(np.float64)
                 x_h, y_h = v[:, 0] + 1j * v[:, 1], v[:, 2] + 1j * v[:, 3]
-            checks.append(dict(cpi=c, **parity_check(np, O, cfg, a.fmt, a.chain, a.cfar, a.n_doppler, x_h, y_h,
-                                                     keep_map[slot], keep_met[slot])))
+            sl = slot if B > 1 else 0
+            checks.append(dict(cpi=c, **parity_check(np, O, G, cfg, a.fmt, a.chain, a.cfar, a.n_doppler, x_h, y_h,
+                                                     keep_map[sl], keep_met[sl],
+                                                     det_params if wh is not None else None,
+                                                     keep_hits[sl] if keep_hits is not None else None,
+                                                     int(keep_ok[sl]) if keep_ok is not None else None)))
         parity = {"pass": all(c_["pass"] for c_ in checks), "cpis": checks,
                   "oracle": "oracle/blah2_oracle.py (fp64 NumPy restatement of Ambiguity.cpp:92-172, Map.cpp:187-206"
-                            + (", WienerHopf.cpp:58-163)" if a.chain == "full" else ")"),
-                  "gates": {"peak_rel": GATE_PEAK_REL, "db_max": GATE_DB_MAP, "db_floor_below_mean_level": DB_FLOOR,
-                            "metrics_db": GATE_METRICS_DB, "chain_err_over_direct_path": GATE_CHAIN_DIRECT}}
-        for key in ("peak_rel", "db_max", "metrics_db", "chain_err_over_direct_path"):
-            vals = [c_[key] for c_ in checks if key in c_]
+                            + (", WienerHopf.cpp:58-163, CfarDetector1D.cpp:23-100)" if a.chain == "full" else ")")
+                            + "; gates: oracle/gates.py",
+                  "gates": {"peak_rel": GATE_PEAK_REL if a.chain != "full" else G.CELL_TOL, "cell_rel_above_mean": G.CELL_TOL,
+                            "db_max": GATE_DB_MAP, "db_floor_below_mean_level": DB_FLOOR,
+                            "metrics_db": GATE_METRICS_DB, "chain_err_over_direct_path": GATE_CHAIN_DIRECT,
+                            "detections": f"identical up to cells whose threshold margin is within {G.MARGIN_K:g} x the measured map error of 1",
+                            "notch_abs_err_over_mean_level": G.NOTCH_ABS}}
+        for key in ("peak_rel", "cell_rel_above_mean", "db_max", "metrics_db", "chain_err_over_direct_path",
+                    "notch_db_max", "notch_abs_err_over_mean_level"):
+            vals = [c_[key] for c_ in checks if c_.get(key) is not None]
             if vals:
                 parity[key] = max(vals)
+        if a.chain == "full":
+            parity["detections_ok"] = all(c_.get("detections_ok", False) for c_ in checks)
+            parity["filter_ok"] = all(c_.get("filter_ok") is True for c_ in checks)
+            parity["detections"] = [c_.get("detections") for c_ in checks]
 
     res = None
     if rank == 0:
@@ -545,11 +634,18 @@ def measure(a, env):
             "us_per_cpi": elapsed / (B * a.steps) * 1e6,
             "per_gpu_cpis_per_s": total_cpis / elapsed / world,
             "parity": parity,
+            "headline_long": long_res,
             "roofline": {"bound": "hbm", "kernel": {1: "range_kernel", 2: "range8_kernel", 3: "rangew_kernel", 5: "rangew1k_kernel", 6: "rangeps_kernel"}.get(
                              amb.info(blah2_amd._lib.INFO_LAST_RANGE_KERNEL), "range_kernel"), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes,
+                         "traffic_measured_on": (None if traffic is None else
+                                                 f"the builder's box: rocprofv3 PMC passes of this same command, {traffic_src} "
+                                                 "(not a measurement of this run)"),
                          "copy_ceiling": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
+                         "read_ceiling": read_gbs, "frac_of_read_ceiling": achieved / read_gbs,
+                         "ceilings_note": "measured in this process: copy = torch device-to-device copy of 1 GiB (read + written "
+                                          "bytes per second); read = a kernel of 16-byte loads over the same 1 GiB",
                          "valu": {"achieved_tflops": range_tflops, "peak_tflops": VALU_PEAK_TFLOPS,
                                   "frac": range_tflops / VALU_PEAK_TFLOPS,
                                   "flops_counted": "(2 nSeg + 1) transforms x 5 F log2 F + nSeg x 8 F per pulse"},
@@ -562,8 +658,6 @@ def measure(a, env):
                          "kernel_us_per_step": {k: v[0] / max(v[1], 1) * 1e3 for k, v in kt.items() if v[1]},
                          "chain_us_per_step": chain_s * 1e6},
         }
-    for h_ in ambs + (whs if wh is not None else []):
-        h_.close()
     return res, parity
 
 
@@ -583,10 +677,25 @@ LEGS = [
 ]
 
 
+def _could_not_run(e, env):
+    """The errors that mean a leg COULD NOT RUN on this box (memory on a shared device, /dev/shm too small) -- anything
+    else (a HIP launch failure, an illegal address, a Python error, a violated gate) is a regression and propagates."""
+    if isinstance(e, env.torch.cuda.OutOfMemoryError):
+        return True
+    if isinstance(e, env.b2.Blah2HipError) and e.code == env.b2._lib.ERR_HIP and "out of memory" in str(e).lower():
+        return True
+    return isinstance(e, LegSkipped)
+
+
+class LegSkipped(RuntimeError):
+    """A leg that has nothing to measure on this box (says why)."""
+
+
 def config_legs(a, env):
     """Short measurements of every other single-GPU configuration BASELINE.json names, in this process after the
-    headline: the same measure() (same timed region, same HIP-event pass, same oracle gate on the last CPI of the last
-    timed batch), about 0.3 s of timed work each.  A leg that fails is reported as such; it never voids the headline."""
+    headline: the same measure() (same timed region, same HIP-event pass, same oracle gates on the last CPI of the last
+    timed batch), about 0.3 s of timed work each.  A leg that cannot run for lack of memory is recorded as such; any other
+    error -- and a violated gate -- ends the run with a non-zero status (after the line has been printed, see main)."""
     out = []
     for key, extra, what in LEGS:
         t0 = time.perf_counter()
@@ -605,12 +714,146 @@ def config_legs(a, env):
                         "range_kernel": r["config"]["range_kernel"], "doppler_kernel": r["config"]["doppler_kernel"],
                         "chain_frac": rl["chain_frac"],  # B_amb over the time of the whole chain, against 8 TB/s
                         "dominant_kernel": dom, "kernels": ks,
-                        "parity": None if par is None else {k: par[k] for k in ("pass", "peak_rel", "db_max", "metrics_db",
-                                                                                 "chain_err_over_direct_path") if k in par},
+                        "parity": None if par is None else {k: par[k] for k in (
+                            "pass", "peak_rel", "cell_rel_above_mean", "db_max", "metrics_db", "chain_err_over_direct_path",
+                            "detections_ok", "filter_ok", "detections", "notch_db_max", "notch_abs_err_over_mean_level") if k in par},
                         "leg_wall_s": time.perf_counter() - t0})
-        except BaseException as e:  # SystemExit of a violated gate included: recorded, the headline stands on its own
-            out.append({"baseline_config": key, "error": f"{type(e).__name__}: {e}"[:600], "leg_wall_s": time.perf_counter() - t0})
+        except Exception as e:
+            if not _could_not_run(e, env):
+                env.failed_legs.append((key, e))  # main() raises it after the line is out
+                out.append({"baseline_config": key, "failed": f"{type(e).__name__}: {e}"[:600], "leg_wall_s": time.perf_counter() - t0})
+                if isinstance(e, env.b2.Blah2HipError) or "HIP" in str(e):
+                    break  # a sticky device error would fail every later leg the same way
+            else:
+                out.append({"baseline_config": key, "error": f"{type(e).__name__}: {e}"[:600], "leg_wall_s": time.perf_counter() - t0})
         env.torch.cuda.empty_cache()
+    return out
+
+
+# ----------------------------------------------------------------------------- replay legs (host buffers: never `value`)
+REPLAY_LEGS = [
+    # (key, config, CPIs in the /dev/shm capture, batch, clutter filter, what BASELINE.json calls it)
+    ("configs[3] at N = 1", "cfg3", 96, 16, False,
+     "8xMI355X CPI-sharded replay over xGMI, 10 MS/s, 1 s CPI, 1024 Doppler bins -- its one-rank point: "
+     "int16 capture -> pinned ring -> PCIe -> range + Doppler + metrics + 1-D CFAR (RspDuo.cpp:150-179, blah2.cpp:254-258)"),
+    ("configs[1] geometry, replay", "cfg2", 512, 16, False, "the same path at 2 MS/s, 1 s CPI, 513 x 411"),
+]
+
+
+def write_capture(torch, path, n, n_cpis, fs, dev, distinct=2):
+    """A seeded synthetic .rspduo capture (int16 I1 Q1 I2 Q2, RspDuo.cpp:512-526): `distinct` CPIs synthesised on the
+    device, repeated to n_cpis (the replay's cost does not depend on the values)."""
+    x, y = synth_batch(torch, distinct, n, 4242, fs, dev)
+    iq = torch.stack([x.real, x.imag, y.real, y.imag], dim=-1).to(torch.int16).contiguous().cpu().numpy()
+    blobs = [iq[k].tobytes() for k in range(distinct)]
+    del x, y, iq
+    with open(path, "wb") as f:
+        for k in range(n_cpis):
+            f.write(blobs[k % distinct])
+
+
+def pinned_h2d_rate(torch, dev, nbytes=256 << 20):
+    """The pinned host-to-device rate of this box (bytes/s), the bound of a replay: the best of three timed stretches of
+    eight 256 MB copies after an untimed one (the first copies out of a fresh pinned buffer run at half the rate)."""
+    h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    h.fill_(1)
+    d_ = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    best = 0.0
+    for rep in range(4):
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(8):
+            d_.copy_(h, non_blocking=True)
+        torch.cuda.synchronize()
+        if rep:
+            best = max(best, 8 * nbytes / (time.perf_counter() - tc))
+    del h, d_
+    return best
+
+
+def replay_legs(a, env, min_seconds=2.0):
+    """BASELINE configs[3] ("CPI-sharded replay") at N = 1, measured in this process: a capture in /dev/shm read
+    cyclically for >= 2 s through blah2_amd.replay.GpuChain (reader threads -> pinned ring -> copy stream -> the device
+    chain -> results back), one rank.  Reports CPIs/s, the fraction of the pinned host-to-device rate measured beside it,
+    and the share of the wall clock the GPU spent computing.  Host buffers cross PCIe here: this is never `value`."""
+    torch = env.torch
+    from blah2_amd import replay as R
+    out = []
+    for key, config, n_file, batch, clutter, what in REPLAY_LEGS:
+        t0 = time.perf_counter()
+        path = f"/dev/shm/blah2_bench_{os.getpid()}_{config}.rspduo"
+        chain = None
+        try:
+            (dmin, dmax, fmin, fmax, fs, n), desc = CONFIGS[config]
+            bytes_per_cpi = n * R.BYTES_PER_SAMPLE
+            st_ = os.statvfs("/dev/shm")
+            if st_.f_bavail * st_.f_frsize < 1.25 * n_file * bytes_per_cpi:
+                raise LegSkipped(f"/dev/shm has {st_.f_bavail * st_.f_frsize / 1e9:.1f} GB free, the capture needs {n_file * bytes_per_cpi / 1e9:.1f}")
+            torch.cuda.empty_cache()
+            R.pin_to_device_node(torch, env.local)  # the capture's page-cache pages on the GPU's NUMA node too
+            write_capture(torch, path, n, n_file, fs, env.dev)
+            t_written = time.perf_counter() - t0
+            rate = pinned_h2d_rate(torch, env.dev)
+            cfg = {"fs": fs, "n_samples": n,
+                   "ambiguity": {"delayMin": dmin, "delayMax": dmax, "dopplerMin": fmin, "dopplerMax": fmax},
+                   "clutter": {"enable": clutter, "delayMin": dmin, "delayMax": dmax},
+                   "detection": {"enable": True, "pfa": 1e-5, "nGuard": 2, "nTrain": 6, "minDelay": 5, "minDoppler": 15.0}}
+            chain = R.GpuChain(cfg, env.local, batch, depth=3, reader_threads=4, read_mode="memmove")
+            warm = R.LoopedCapture(path, n, 1)
+            R.replay(warm, chain, batch, emit=lambda r: None)  # untimed: clock ramp, first touch of the pinned ring
+            warm.close()
+            est = n_file * bytes_per_cpi / (0.85 * rate)
+            times = max(1, math.ceil(min_seconds / est))
+            chain.busy_ms, chain.batches_done = 0.0, 0
+            first, cnt, last_r = [None], [0], [None]
+
+            def emit(r):
+                if first[0] is None:
+                    first[0] = time.perf_counter() - tr
+                cnt[0] += 1
+                last_r[0] = r
+
+            el, cpu_s, expect = 0.0, 0.0, 0
+            while el < min_seconds:  # one pipelined stream of `times` passes; again if the estimate was short
+                cap = R.LoopedCapture(path, n, times)
+                cpu0 = time.process_time()
+                tr = time.perf_counter()
+                R.replay(cap, chain, batch, emit=emit)
+                el += time.perf_counter() - tr
+                cpu_s += time.process_time() - cpu0
+                expect += n_file * times
+                cap.close()
+            nD, nC = chain.amb.get_n_doppler_bins(), chain.amb.get_n_delay_bins()
+            if cnt[0] != expect or "noisePower" not in (last_r[0] or {}):
+                raise RuntimeError(f"replay emitted {cnt[0]} of {expect} CPIs")
+            out.append({"baseline_config": key, "baseline_wording": what, "workload": f"{desc} -> {nD} x {nC}, int16 .rspduo capture "
+                        f"of {n_file} CPIs ({n_file * bytes_per_cpi / 1e9:.1f} GB) in /dev/shm read cyclically ({expect // n_file} passes), one rank",
+                        "n_gpus": 1, "chain": ("clutter+" if clutter else "") + "ambiguity+metrics+cfar1d", "batch_cpis": batch,
+                        "reader_threads": 4, "read_mode": chain.read_mode, "cpis_timed": cnt[0], "seconds": el,
+                        "cpis_per_s": cnt[0] / el, "cells_per_s": cnt[0] * nD * nC / el,
+                        "effective_GBps": cnt[0] * bytes_per_cpi / el / 1e9, "pinned_h2d_GBps": rate / 1e9,
+                        "frac_of_pinned_link": cnt[0] * bytes_per_cpi / el / rate,
+                        "gpu_busy_share": chain.busy_ms * 1e-3 / el, "gpu_us_per_cpi": chain.busy_ms * 1e3 / max(cnt[0], 1),
+                        "first_result_after_s": first[0], "host_cpu_s_per_cpi": cpu_s / max(cnt[0], 1),
+                        "cpus_allowed": len(os.sched_getaffinity(0)), "capture_written_s": t_written,
+                        "last_cpi": {k: last_r[0][k] for k in ("noisePower", "maxPower")} | {"detections": len(last_r[0].get("delay", []))},
+                        "note": "PCIe-inclusive (host buffers): bound by the host link, not by the kernels; never `value`",
+                        "leg_wall_s": time.perf_counter() - t0})
+        except Exception as e:
+            if not _could_not_run(e, env):
+                env.failed_legs.append((key, e))
+                out.append({"baseline_config": key, "failed": f"{type(e).__name__}: {e}"[:600], "leg_wall_s": time.perf_counter() - t0})
+            else:
+                out.append({"baseline_config": key, "error": f"{type(e).__name__}: {e}"[:600], "leg_wall_s": time.perf_counter() - t0})
+        finally:
+            if chain is not None:
+                try:
+                    chain.close()
+                except Exception as e:
+                    print(f"bench.py: closing the replay chain failed: {e}", file=sys.stderr)
+            if os.path.exists(path):
+                os.remove(path)
+            torch.cuda.empty_cache()
     return out
 
 
@@ -624,7 +867,7 @@ def _leg_args(a, extra):
         v = next(it)
         name = k[2:].replace("-", "_")
         setattr(la, name, int(v) if name in ("batch", "streams") else v)
-    la.target_s, la.warmup, la.prewarm_s, la.parity_cpis = 0.3, 3, 0.3, "last"
+    la.target_s, la.warmup, la.prewarm_s, la.parity_cpis, la.long_s = 0.3, 3, 0.3, "last", 0.0
     la.no_parity = a.no_parity
     return la
 
@@ -665,6 +908,10 @@ def main(argv=None):
                          "steps alternate between them so one batch's Doppler stage overlaps the next batch's range stage")
     ap.add_argument("--no-configs", action="store_true",
                     help="headline only: skip the short legs for the other single-GPU BASELINE configurations (`configs` in the JSON line)")
+    ap.add_argument("--long-s", type=float, default=0.5,
+                    help="after the K timed steps, the same region again for at least this long (`headline_long` in the line); 0 = skip")
+    ap.add_argument("--no-replay", action="store_true",
+                    help="skip the PCIe-inclusive replay legs (`replay` in the JSON line: BASELINE configs[3] at N = 1)")
     ap.add_argument("--target-s", type=float, default=0.0,
                     help="pick --steps so that the timed region lasts about this long (the legs of `configs` use it)")
     ap.add_argument("--parity-cpis", default="both", choices=["both", "last"],
@@ -694,7 +941,8 @@ def main(argv=None):
         assert dist.get_world_size() == a.gpus
 
     import types
-    env = types.SimpleNamespace(torch=torch, np=np, b2=blah2_amd, rank=rank, world=world, local=local, dev=dev, dist=dist)
+    env = types.SimpleNamespace(torch=torch, np=np, b2=blah2_amd, rank=rank, world=world, local=local, dev=dev, dist=dist,
+                                failed_legs=[])
     res, parity = measure(a, env)
     if rank == 0:
         cfg = CONFIGS[a.config][0]
@@ -704,22 +952,28 @@ def main(argv=None):
                 res["e2e_host"] = e2e_host(cfg, local, np, blah2_amd)
         if world == 1 and not a.no_configs and (a.config, a.chain, a.fmt) == ("cfg2", "amb", "c32"):
             res["configs"] = config_legs(a, env)  # every other single-GPU BASELINE configuration, same process, same box
+            if not a.no_replay and not env.failed_legs:
+                res["replay"] = replay_legs(a, env)  # BASELINE configs[3] at N = 1 (PCIe-inclusive; never `value`)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()  # rank 0 has been checking parity: every rank leaves the group together
         dist.destroy_process_group()
     if parity is not None and not parity["pass"]:
         raise SystemExit("bench.py: parity gate violated: " + json.dumps(parity))
-    # after the line has been printed: the headline stands.  A leg whose ORACLE GATE failed sets the exit status like the
-    # headline's would; a leg that could not run (recorded as `error` in its entry, e.g. out of memory on a shared device)
-    # is reported on stderr only -- it says nothing about the headline the driver asked for
-    legs = (res or {}).get("configs", [])
+    # after the line has been printed: the headline stands.  A leg whose ORACLE GATE failed, or that raised anything but
+    # "could not run on this box" (out of memory on a shared device, no room in /dev/shm), sets the exit status like the
+    # headline's would; a leg that could not run is reported on stderr only -- it says nothing about the headline
+    legs = (res or {}).get("configs", []) + (res or {}).get("replay", [])
     for c in legs:
         if "error" in c:
             print(f"bench.py: leg {c['baseline_config']} did not run: {c['error']}", file=sys.stderr)
     bad = [c for c in legs if c.get("parity") and not c["parity"]["pass"]]
     if bad:
         raise SystemExit("bench.py: parity gate violated in a secondary configuration: " + json.dumps(bad))
+    if env.failed_legs:
+        key, e = env.failed_legs[0]
+        print(f"bench.py: leg {key} FAILED: {type(e).__name__}: {e}", file=sys.stderr)
+        raise e
 
 
 if __name__ == "__main__":

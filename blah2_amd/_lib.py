@@ -22,6 +22,8 @@ CK_CORR, CK_REDUCE, CK_SOLVE, CK_FIR, CK_COUNT = 0, 1, 2, 3, 4
 CLUTTER_KERNEL_NAMES = {CK_CORR: "clutter_corr", CK_REDUCE: "clutter_reduce", CK_SOLVE: "clutter_solve",
                         CK_FIR: "clutter_fir"}
 OPT_DOPPLER_KERNEL, OPT_RANGE_GRID, OPT_RANGE_KERNEL, OPT_DOPPLER_GRID, OPT_FFT_LEN, OPT_CFAR2D_KERNEL = 1, 2, 3, 4, 5, 6
+OPT_LEAK_COMPENSATION = 7
+LEAK_OFF, LEAK_AUTO, LEAK_ALWAYS = 0, 1, 2
 CFAR2D_AUTO, CFAR2D_TILE, CFAR2D_SAT, CFAR2D_STREAM = 0, 1, 2, 3
 CLUTTER_OPT_SOLVE_K, CLUTTER_OPT_FFT_LEN, CLUTTER_OPT_CORR, CLUTTER_OPT_SOLVE_FORM, CLUTTER_OPT_SOLVE_E, CLUTTER_OPT_FIR_CARRY = 1, 2, 3, 4, 5, 6
 CLUTTER_OPT_SOLVE_SPIN_LIMIT = 7
@@ -34,6 +36,7 @@ DOPPLER_KERNEL_NAMES = {DOP_AUTO: "auto", DOP_TILE8: "tile8", DOP_TILE16: "tile1
 RANGE_E16, RANGE_E8, RANGE_WAVE, RANGE_WAVE1K, RANGE_PS = 1, 2, 3, 5, 6
 INFO_LAST_DOPPLER_KERNEL, INFO_LAST_RANGE_KERNEL, INFO_DOPPLER_FFT_LEN, INFO_RANGE_GRID, INFO_NUM_CU = 1, 2, 3, 4, 5
 INFO_DOPPLER_GRID, INFO_DOPPLER_TILES = 6, 7
+INFO_LEAK_LAGS, INFO_LEAK_MAX_E12 = 8, 9
 
 
 class Blah2HipError(RuntimeError):
@@ -116,6 +119,7 @@ SYMBOLS = {
     "blah2hip_ctx_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "blah2hip_ctx_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "blah2hip_ctx_d2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "blah2hip_stream_read_dev": (C.c_int, [_vp, C.c_size_t, _vp, _vp]),
     "blah2hip_amb_result_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "blah2hip_amb_set_timing": (C.c_int, [_vp, C.c_int]),
     "blah2hip_amb_get_timing": (C.c_int, [_vp, _vp, _vp]),

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <set>
 #include <string>
@@ -117,6 +118,15 @@ struct blah2hip_amb_s {
   double *d_sat = nullptr;          // 2-D CFAR summed-area table [max_batch][nD+1][nDelay+1]
 
   KernelTimer<BLAH2HIP_K_COUNT> timer;
+
+  // Fixed-pattern leak compensation (see leak_calibrate): per (range kernel, Doppler kernel) the lags of the zero-Doppler row
+  // into which the fp32 transform chain leaks a fixed fraction g of the lag-0 cell, measured once on a synthetic CPI
+  struct LeakCal { int nLags = 0; double maxAbs = 0.0; bool active = false; int32_t *d_lag = nullptr; cf *d_g = nullptr; };
+  std::map<int, LeakCal> leak;      // key = range kernel id * 64 + Doppler kernel id
+  int leakMode = 1;                 // BLAH2HIP_OPT_LEAK_COMPENSATION: 0 off, 1 auto (applied where it can reach 3e-5 of the mean level), 2 always
+  bool inLeakCal = false;
+  int lastLeakLags = 0;             // BLAH2HIP_INFO_LEAK_LAGS: lags corrected by the last process call (0 = not applied)
+  double lastLeakMax = 0.0;         // BLAH2HIP_INFO_LEAK_MAX_E12: the largest |g| of the calibration the last call ran under
 };
 
 namespace {
@@ -635,6 +645,188 @@ void cfar2d_stream_launch(const blah2hip_amb_s *h, const Cfar2dArgs &a, uint32_t
 #undef B2_X
 }
 
+// ------------------------------------------------------------ leak compensation --
+// What it is.  The range transforms multiply by fp32 constants (the 8-/16-/32-point butterflies' roots, the stage twiddles):
+// each is off by up to 3e-8 of itself, and it is off THE SAME WAY in every transform.  The data-dependent roundings of a
+// transform average out over the 1e6-1e7 samples of a CPI; the constants' errors do not: they add up coherently, and what
+// they add up to is a fixed linear response -- a fraction g[d] (measured: 1e-9 rms, 0.8e-8 ... 1.5e-8 at a few dozen lags
+// that are multiples of 4 or 8 away from the source) of every pulse's lag-0 correlation appears at lag d.  Summed over the
+// pulses that is g[d] x M[k][lag 0] in Doppler row k: invisible wherever column lag 0 is at the floor, and
+// g[d] x (direct-path peak) in the zero-Doppler row, where the peak stands sqrt(N) = 1.4e3 ... 6.3e3 above the mean
+// level -- 1.2e-5 of a mean-level cell at configs[1], 4e-5 at configs[2], 1e-4 at configs[4] (tools/gpu_cell_err.py:
+// two of eight CPIs over north_star's 1e-4 there, every one of them at 2e-5 once the leak is taken out).
+// How it is measured.  The chain is run once on a synthetic CPI of white integer-valued samples, x = y, whose zero-Doppler
+// row has an EXACT value that a small fp64 kernel sums directly (integers below 2^53); g[d] = (engine - exact)[d] / exact[0].
+// The engine's data-dependent rounding on that CPI is 6e-7 of the floor per cell, i.e. 1e-10 of the peak: two orders under
+// the pattern.  (A CPI of sparse unit impulses, whose exact row is zero without any reference, was tried first and measures
+// a DIFFERENT pattern -- lags F/40, F/20, F/8 ... -- the roundings of products with exact roots of unity are not random;
+// subtracting it made the maps worse.)
+// How it is applied.  After the Doppler kernel, one 64-thread workgroup per CPI subtracts g[d] x M[k0][lag 0] from the
+// listed cells of row k0 (the Map::set_metrics partials were taken before: the mean of 2e5 dB values moves by < 1e-6 dB).
+// Auto mode launches it only where max|g| sqrt(N) can reach 3e-5 (not at configs[1]: the headline's launch train is what
+// it was).  Calibrated per (range kernel, Doppler kernel) at the first launch that runs the pair.
+// calibration input: white, integer-valued (exact in every sample format), x = y
+__global__ void leak_noise_kernel(cf *x, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull; // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    x[i] = cmake((float)((int)(z & 1023) - 512), (float)((int)((z >> 20) & 1023) - 512));
+  }
+}
+
+// ... and its exact zero-Doppler row (Ambiguity.cpp:106-169 at Doppler zero: the plain sum over the pulses of
+// sum_n x[n + d] conj(x[n]), samples of the same pulse only), by direct summation in fp64 -- every term is an integer
+// below 2^20 and every sum below 2^53: EXACT.  grid (lag blocks of 256, pulse slices); Z += through fp64 atomics.
+__global__ __launch_bounds__(256) void leak_ref_kernel(const cf *__restrict__ x, int nCorr, int nPulses, int delayMin, int nDelay,
+                                                        double *Z)
+{
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int d = delayMin + j;
+  double ar = 0.0, ai = 0.0;
+  for (int p = blockIdx.y; p < nPulses; p += gridDim.y) {
+    const cf *xp = x + (size_t)p * nCorr;
+    const int lo = max(0, -d), hi = min(nCorr, nCorr - d);
+    if (j < nDelay)
+      for (int n = lo; n < hi; n++) {
+        const cf a = xp[n], b = xp[n + d]; // b conj(a)
+        ar += (double)b.x * (double)a.x + (double)b.y * (double)a.y;
+        ai += (double)b.y * (double)a.x - (double)b.x * (double)a.y;
+      }
+  }
+  if (j < nDelay) {
+    atomicAdd(&Z[2 * j], ar);
+    atomicAdd(&Z[2 * j + 1], ai);
+  }
+}
+
+__global__ __launch_bounds__(64) void leak_fix_kernel(cf *map, size_t cells, size_t row0, int col0, int n,
+                                                       const int32_t *__restrict__ col, const cf *__restrict__ g)
+{
+  cf *row = map + (size_t)blockIdx.x * cells + row0;
+  const cf m0 = row[col0];
+  for (int j = threadIdx.x; j < n; j += 64) {
+    const cf gj = g[j], v = row[col[j]];
+    row[col[j]] = cmake(v.x - (gj.x * m0.x - gj.y * m0.y), v.y - (gj.x * m0.y + gj.y * m0.x));
+  }
+}
+
+int predict_range(const blah2hip_amb_s *h, int nPulses)
+{
+  if (use_wave_range(h, nPulses)) return BLAH2HIP_RANGE_WAVE;
+  if (use_wave1k_range(h, nPulses)) return BLAH2HIP_RANGE_WAVE1K;
+  if (use_ps_range(h, nPulses)) return BLAH2HIP_RANGE_PS;
+  return h->r3 == 4 ? BLAH2HIP_RANGE_E8 : BLAH2HIP_RANGE_E16;
+}
+
+void leak_clear(blah2hip_amb_s *h)
+{
+  for (auto &kv : h->leak) {
+    if (kv.second.d_lag) (void)hipFree(kv.second.d_lag);
+    if (kv.second.d_g) (void)hipFree(kv.second.d_g);
+  }
+  h->leak.clear();
+}
+
+// index of the zero-Doppler row / the lag-0 column, or -1
+int leak_row0(const blah2hip_amb_s *h)
+{
+  for (size_t k = 0; k < h->dopplerAxis.size(); k++)
+    if (std::fabs(h->dopplerAxis[k]) < 1e-9) return (int)k;
+  return -1;
+}
+int leak_col0(const blah2hip_amb_s *h)
+{
+  for (size_t j = 0; j < h->delayAxis.size(); j++)
+    if (h->delayAxis[j] == 0) return (int)j;
+  return -1;
+}
+
+constexpr double LEAK_KEEP = 2.0e-9;   // lags whose |g| is above the positions' own rounding (1.4e-9)
+constexpr double LEAK_REACH = 3.0e-5;  // auto mode: apply where max|g| sqrt(N) can move a mean-level cell by this much (a third of the 1e-4 gate)
+constexpr int LEAK_MAX_LAGS = 512;
+
+int leak_calibrate(blah2hip_amb_s *h, int rangeId, int dopId, hipStream_t st, blah2hip_amb_s::LeakCal *out)
+{
+  blah2hip_amb_s::LeakCal cal;
+  const int k0 = leak_row0(h), c0 = leak_col0(h);
+  const int nDelay = (int)h->dims.n_delay_bins, nD = (int)h->dims.n_doppler_bins, nCorr = (int)h->dims.n_corr;
+  const int reach = std::max(std::abs(h->delayMin), std::abs(h->delayMax));
+  // not calibrated (the entry stays inactive): no zero-Doppler row or lag-0 column, a rotated reference channel, a lag window
+  // run as chunks (aliased lags), a window longer than a pulse
+  // ... nor, in auto mode, a CPI so short that no pattern of this chain (max|g| <= 3e-8 on every kernel measured) could reach
+  // LEAK_REACH: the small handles of a test suite do not pay for a measurement they would never use
+  const bool tooShort = h->leakMode == 1 && 4.0e-8 * std::sqrt((double)h->dims.n_used) < LEAK_REACH;
+  if (k0 < 0 || c0 < 0 || h->dopplerMin + h->dopplerMax != 0 || h->chunks.size() != 1 || reach >= nCorr || tooShort) {
+    *out = cal;
+    return BLAH2HIP_OK;
+  }
+  const size_t n = (size_t)h->dims.n_samples, cells = (size_t)nD * nDelay;
+  cf *d_x = nullptr, *d_m = nullptr;
+  double *d_met = nullptr, *d_Z = nullptr;
+  std::vector<cf> row(nDelay);
+  std::vector<double> Z(2 * (size_t)nDelay);
+  const int savedRange = h->rangeKernel, savedDop = h->dopForce;
+  const bool savedTiming = h->timer.enabled;
+  int rc = BLAH2HIP_OK;
+  hipError_t e = hipMalloc(&d_x, n * sizeof(cf));
+  if (e == hipSuccess) e = hipMalloc(&d_m, cells * sizeof(cf));
+  if (e == hipSuccess) e = hipMalloc(&d_met, 2 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&d_Z, 2 * (size_t)nDelay * sizeof(double));
+  if (e == hipSuccess) e = hipMemsetAsync(d_Z, 0, 2 * (size_t)nDelay * sizeof(double), st);
+  if (e == hipSuccess) {
+    leak_noise_kernel<<<dim3(h->numCU * 8), dim3(256), 0, st>>>(d_x, n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) {
+    h->rangeKernel = rangeId; h->dopForce = dopId; h->timer.enabled = false; h->inLeakCal = true;
+    rc = blah2hip_amb_process_dev(h, BLAH2HIP_FMT_C32, d_x, d_x, 1, 0, d_m, d_met, (void *)st);
+    h->rangeKernel = savedRange; h->dopForce = savedDop; h->timer.enabled = savedTiming; h->inLeakCal = false;
+    if (rc == BLAH2HIP_OK) {
+      const int lagBlocks = (nDelay + 255) / 256;
+      const int slices = std::max(1, std::min(nD, (4 * h->numCU + lagBlocks - 1) / lagBlocks));
+      leak_ref_kernel<<<dim3(lagBlocks, slices), dim3(256), 0, st>>>(d_x, nCorr, nD, h->delayMin, nDelay, d_Z);
+      e = hipGetLastError();
+    }
+    if (rc == BLAH2HIP_OK && e == hipSuccess) e = hipMemcpyAsync(row.data(), d_m + (size_t)k0 * nDelay, (size_t)nDelay * sizeof(cf), hipMemcpyDeviceToHost, st);
+    if (rc == BLAH2HIP_OK && e == hipSuccess) e = hipMemcpyAsync(Z.data(), d_Z, 2 * (size_t)nDelay * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (rc == BLAH2HIP_OK && e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  if (d_Z) (void)hipFree(d_Z);
+  if (d_x) (void)hipFree(d_x);
+  if (d_m) (void)hipFree(d_m);
+  if (d_met) (void)hipFree(d_met);
+  if (rc != BLAH2HIP_OK) return rc;
+  if (e != hipSuccess) return fail(BLAH2HIP_ERR_HIP, std::string("leak calibration: ") + hipGetErrorString(e));
+  const std::complex<double> peak(Z[2 * c0], Z[2 * c0 + 1]);
+  if (!(std::abs(peak) > 0.0)) { *out = cal; return BLAH2HIP_OK; }
+  std::vector<std::pair<double, int>> order;
+  std::vector<std::complex<double>> g(nDelay);
+  for (int j = 0; j < nDelay; j++) {
+    g[j] = j == c0 ? std::complex<double>(0.0, 0.0)
+                   : (std::complex<double>(row[j].x, row[j].y) - std::complex<double>(Z[2 * j], Z[2 * j + 1])) / peak;
+    if (std::abs(g[j]) >= LEAK_KEEP) order.push_back({-std::abs(g[j]), j});
+    cal.maxAbs = std::max(cal.maxAbs, std::abs(g[j]));
+  }
+  std::sort(order.begin(), order.end());
+  if ((int)order.size() > LEAK_MAX_LAGS) order.resize(LEAK_MAX_LAGS);
+  cal.nLags = (int)order.size();
+  if (cal.nLags) {
+    std::vector<int32_t> lag(cal.nLags);
+    std::vector<cf> gv(cal.nLags);
+    for (int i = 0; i < cal.nLags; i++) { lag[i] = order[i].second; gv[i] = cmake((float)g[order[i].second].real(), (float)g[order[i].second].imag()); }
+    HIPCHK(hipMalloc(&cal.d_lag, cal.nLags * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&cal.d_g, cal.nLags * sizeof(cf)));
+    HIPCHK(hipMemcpy(cal.d_lag, lag.data(), cal.nLags * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(cal.d_g, gv.data(), cal.nLags * sizeof(cf), hipMemcpyHostToDevice));
+  }
+  cal.active = cal.nLags > 0 && cal.maxAbs * std::sqrt((double)h->dims.n_used) >= LEAK_REACH;
+  *out = cal;
+  return BLAH2HIP_OK;
+}
+
 int ensure_sat(blah2hip_amb_s *h)
 {
   if (h->d_sat) return BLAH2HIP_OK;
@@ -793,6 +985,7 @@ int blah2hip_amb_destroy(blah2hip_amb_t h)
   for (auto &t : h->alphaTables)
     if (t.d) (void)hipFree(t.d);
   if (h->h_pin) (void)hipHostFree(h->h_pin);
+  leak_clear(h);
   h->timer.destroy();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -862,9 +1055,19 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
     h->rangeKernel = 0; // a forced kernel belongs to a transform length
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize()); // the table may still be in use by enqueued work
+    leak_clear(h);                  // the leak pattern belongs to a transform length too
     int rc = upload_range_table(h);
     return rc;
   }
+  case BLAH2HIP_OPT_LEAK_COMPENSATION:
+    if (value < 0 || value > 2) return fail(BLAH2HIP_ERR_INVALID, "leak compensation: 0 (off), 1 (auto) or 2 (always)");
+    if (h->leakMode != (int)value) { // entries skipped as "too short" in auto mode are measured in always mode
+      HIPCHK(hipSetDevice(h->device));
+      HIPCHK(hipDeviceSynchronize());
+      leak_clear(h);
+    }
+    h->leakMode = (int)value;
+    return BLAH2HIP_OK;
   default: return fail(BLAH2HIP_ERR_INVALID, "unknown option");
   }
 }
@@ -880,6 +1083,8 @@ int blah2hip_amb_get_info(blah2hip_amb_t h, int key, int64_t *value)
   case BLAH2HIP_INFO_NUM_CU: *value = h->numCU; return BLAH2HIP_OK;
   case BLAH2HIP_INFO_DOPPLER_GRID: *value = h->dopGridLast; return BLAH2HIP_OK;
   case BLAH2HIP_INFO_DOPPLER_TILES: *value = h->dopTilesLast; return BLAH2HIP_OK;
+  case BLAH2HIP_INFO_LEAK_LAGS: *value = h->lastLeakLags; return BLAH2HIP_OK;
+  case BLAH2HIP_INFO_LEAK_MAX_E12: *value = (int64_t)std::llround(h->lastLeakMax * 1e12); return BLAH2HIP_OK;
   default: return fail(BLAH2HIP_ERR_INVALID, "unknown info key");
   }
 }
@@ -901,6 +1106,22 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   const uint32_t nD = h->dims.n_doppler_bins, nDelay = h->dims.n_delay_bins;
   cf *map = d_map ? (cf *)d_map : h->d_map;
   double *met = d_metrics ? d_metrics : h->d_metrics;
+
+  // the fixed-pattern leak of the kernel pair this launch will run (calibrated at the pair's first launch)
+  const blah2hip_amb_s::LeakCal *leak = nullptr;
+  if (h->leakMode != 0 && !h->inLeakCal) {
+    const int rid = predict_range(h, (int)(n_cpi * nD)), did = pick_doppler(h, n_cpi);
+    auto it = h->leak.find(rid * 64 + did);
+    if (it == h->leak.end()) {
+      blah2hip_amb_s::LeakCal cal;
+      const int rcc = leak_calibrate(h, rid, did, st, &cal);
+      if (rcc) return rcc;
+      it = h->leak.emplace(rid * 64 + did, cal).first;
+    }
+    h->lastLeakMax = it->second.maxAbs;
+    if (it->second.nLags > 0 && (it->second.active || h->leakMode == 2)) leak = &it->second;
+  }
+  if (!h->inLeakCal) h->lastLeakLags = leak ? leak->nLags : 0;
 
   RangeArgs ra;
   ra.plan = h->plan;
@@ -1102,6 +1323,11 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   h->lastDoppler = which;
   h->dopGridLast = dopGrid;
   h->dopTilesLast = dopTiles;
+  if (leak) { // inside the Doppler bracket: one 64-thread workgroup per CPI on a few dozen cells of the zero-Doppler row
+    leak_fix_kernel<<<dim3(n_cpi), dim3(64), 0, st>>>(map, (size_t)nD * nDelay, (size_t)leak_row0(h) * nDelay, leak_col0(h),
+                                                      leak->nLags, leak->d_lag, leak->d_g);
+    HIPCHK(hipGetLastError());
+  }
   if ((rc = toc(h, BLAH2HIP_K_DOPPLER, st))) return rc;
 
   if (nPartsUsed) {
@@ -1691,6 +1917,43 @@ int blah2hip_ctx_d2h(blah2hip_ctx_t c, void *hptr, const void *dptr, size_t byte
   if (!c || !dptr || !hptr) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
+  return BLAH2HIP_OK;
+}
+
+// A streaming read of `bytes` of device memory and nothing else (16-byte loads, four in flight per lane, the sum kept
+// behind a condition that never holds): what the memory system delivers to a kernel that only reads, the ceiling the
+// range kernel's loads are priced against beside the copy (bench.py `roofline.read_ceiling`).
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_read_kernel(const v4f_t *__restrict__ src, size_t n16, float *sink)
+{
+  // a workgroup takes contiguous 64 KB chunks (16 loads of 16 bytes per lane, all requested before the first is used:
+  // the shape tools/membench measured at 6.3 TB/s), chunk c + k * gridDim.x
+  constexpr size_t CH = 16 * 256;
+  float acc = 0.f;
+  const size_t nch = n16 / CH;
+  for (size_t c = blockIdx.x; c < nch; c += gridDim.x) {
+    const v4f_t *p = src + c * CH + threadIdx.x;
+    v4f_t v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = __builtin_nontemporal_load(p + 256 * k);
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+  for (size_t i = nch * CH + (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+    const v4f_t a = src[i];
+    acc += a.x + a.y + a.z + a.w;
+  }
+  if (acc == 1.2345678e-30f && sink) *sink = acc;
+}
+
+int blah2hip_stream_read_dev(const void *d_src, size_t bytes, void *d_sink, void *stream)
+{
+  if (!d_src || ((uintptr_t)d_src & 15)) return fail(BLAH2HIP_ERR_INVALID, "stream_read_dev: source NULL or not 16-byte aligned");
+  int dev = 0, cus = 256;
+  HIPCHK(hipGetDevice(&dev));
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  stream_read_kernel<<<dim3(cus * 6), dim3(256), 0, (hipStream_t)stream>>>((const v4f_t *)d_src, bytes / 16, (float *)d_sink);
+  HIPCHK(hipGetLastError());
   return BLAH2HIP_OK;
 }
 

@@ -220,6 +220,15 @@ class Ambiguity:
             which = {"auto": _lib.CFAR2D_AUTO, "tile": _lib.CFAR2D_TILE, "sat": _lib.CFAR2D_SAT, "stream": _lib.CFAR2D_STREAM}[which]
         check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_CFAR2D_KERNEL, int(which)))
 
+    def set_leak_compensation(self, mode):
+        """BLAH2HIP_OPT_LEAK_COMPENSATION: "off", "auto" (default) or "always" (include/blah2hip.h)."""
+        mode = {"off": _lib.LEAK_OFF, "auto": _lib.LEAK_AUTO, "always": _lib.LEAK_ALWAYS}.get(mode, mode)
+        check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_LEAK_COMPENSATION, int(mode)))
+
+    def leak_info(self):
+        """(cells of the zero-Doppler row the last call corrected, largest |g| of the kernel pair it ran)."""
+        return self.info(_lib.INFO_LEAK_LAGS), self.info(_lib.INFO_LEAK_MAX_E12) * 1e-12
+
     def set_fft_len(self, F):
         """Force the range transform length (1024 / 2048 / 4096; 0 = planner); re-plans the segmentation."""
         check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_FFT_LEN, int(F)))

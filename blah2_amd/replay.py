@@ -126,6 +126,35 @@ class RspduoFile:
         self._mm = np.zeros(0, dtype="<i2")  # the mapping goes with its last reference (anything registered of it must be released first)
 
 
+class LoopedCapture(RspduoFile):
+    """A capture read ``times`` times over, end to end, as ONE stream of ``times * n_cpis`` CPIs (throughput measurements
+    that must last seconds from a file that fits /dev/shm: CPI k is CPI k mod n of the file).  A batch must not straddle
+    the wrap: the file's CPI count has to be a multiple of the batch."""
+
+    def __init__(self, path: str, n_samples: int, times: int):
+        super().__init__(path, n_samples)
+        self.n_file = self.n_cpis
+        self.n_cpis = self.n_file * max(1, int(times))
+
+    def _fold(self, k0: int, count: int) -> int:
+        k = k0 % self.n_file
+        if k + count > self.n_file:
+            raise ValueError(f"batch [{k0}, {k0 + count}) straddles the end of a {self.n_file}-CPI capture read cyclically")
+        return k
+
+    def cpi(self, k: int) -> np.ndarray:
+        if not 0 <= k < self.n_cpis:
+            raise IndexError(k)
+        k %= self.n_file
+        return np.asarray(self._mm[k * self.n_samples * 4:(k + 1) * self.n_samples * 4]).reshape(self.n_samples, 4)
+
+    def read_into(self, k0, count, dst, pool=None, parts=8, how="memmove"):
+        return super().read_into(self._fold(k0, count), count, dst, pool, parts, how)
+
+    def window(self, k0, count):
+        return super().window(self._fold(k0, count), count)
+
+
 def page_split(addr: int, nbytes: int, parts: int, page: int = PAGE):
     """The byte range [addr, addr + nbytes) as (head, [whole-page pieces], tail): ``head`` and ``tail`` are the ragged
     ends (offset, length) relative to ``addr`` that do not fill a page, the pieces are at most ``parts`` page-aligned
@@ -426,6 +455,7 @@ class GpuChain:
             self.read_mode = "memmove"
         # the filtered surveillance channel (one buffer: the compute stream is in order)
         self.yf = torch.empty((B, n), dtype=torch.complex64, device=dev) if self.wh is not None else None
+        self.busy_ms, self.batches_done = 0.0, 0  # kernels' time on the compute stream / batches collected, since construction
         self.slots = []
         for _ in range(self.depth):
             s = {
@@ -443,7 +473,10 @@ class GpuChain:
                 "h_hits": torch.zeros((B, self.hit_copy, 2), dtype=torch.float64).pin_memory(),
                 "h_cnt": torch.zeros(B, dtype=torch.int32).pin_memory(),
                 "h_map": torch.zeros((B, nD, nC), dtype=torch.complex64).pin_memory() if self.need_map else None,
-                "uploaded": torch.cuda.Event(), "computed": torch.cuda.Event(), "downloaded": torch.cuda.Event(),
+                "uploaded": torch.cuda.Event(), "downloaded": torch.cuda.Event(),
+                # the two ends of the batch's kernels on the (in-order) compute stream, timed: their sum over a replay is the
+                # time the GPU spent computing (`busy_ms`), the rest of the wall clock it waited for the host link
+                "started": torch.cuda.Event(enable_timing=True), "computed": torch.cuda.Event(enable_timing=True),
             }
             self.slots.append(s)
 
@@ -502,6 +535,7 @@ class GpuChain:
             slot["uploaded"].record(self.copy)
         with torch.cuda.stream(self.compute):
             self.compute.wait_event(slot["uploaded"])
+            slot["started"].record(self.compute)
             st = self.compute.cuda_stream
             iq = slot["d_iq"].data_ptr()
             if self.wh is None:
@@ -529,6 +563,8 @@ class GpuChain:
     def _collect(self, slot: dict, k0: int, cnt: int) -> List[dict]:
         b2, amb = self.b2, self.amb
         slot["downloaded"].synchronize()
+        self.busy_ms += slot["started"].elapsed_time(slot["computed"])
+        self.batches_done += 1
         met_h = slot["h_met"].numpy()
         ok_h = slot["h_ok"].numpy() if self.wh is not None else np.ones(cnt, dtype=np.int32)
         res = []

@@ -141,6 +141,14 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
                                        * for -- C2S_SHAPES in csrc/cfar_kernels.hpp, among them config.yml's 2 / 6 along delay with 1 / 3 along
                                        * Doppler --, the one-pass tile kernel for other windows with nGf + nTf <= 24 and nGd + nTd <= 40, else the
                                        * summed-area table), _STREAM / _TILE (BLAH2HIP_ERR_UNSUPPORTED at the call for other windows) or _SAT */
+#define BLAH2HIP_OPT_LEAK_COMPENSATION 7 /* Fixed-pattern leak of the fp32 transform chain (csrc/capi.hip, "leak compensation"): the butterfly
+                                       * and twiddle constants are each off by up to 3e-8 of themselves, the same way in every transform, and
+                                       * what that adds up to over a CPI is a FIXED fraction g[d] (<= 1.5e-8) of the lag-0 column appearing at a
+                                       * few dozen lags d -- in the zero-Doppler row, where the direct-path peak stands sqrt(N) above the floor,
+                                       * up to 1e-4 of a floor cell at 4e7 samples per CPI.  g is measured once per (range kernel, Doppler
+                                       * kernel) on a synthetic CPI of sparse impulses (exact answer: zero) and subtracted from that row.
+                                       * 1 (default): where max|g| sqrt(N) >= 3e-5 (not at 2 MS/s x 1 s); 2: wherever a pattern was measured;
+                                       * 0: never.  No reference counterpart (the reference computes in fp64). */
 #define BLAH2HIP_CFAR2D_AUTO 0
 #define BLAH2HIP_CFAR2D_TILE 1
 #define BLAH2HIP_CFAR2D_SAT 2
@@ -171,6 +179,9 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value);
 #define BLAH2HIP_INFO_RANGE_GRID 4
 #define BLAH2HIP_INFO_NUM_CU 5
 #define BLAH2HIP_INFO_DOPPLER_GRID 6        /* workgroups of the last Doppler launch */
+#define BLAH2HIP_INFO_LEAK_LAGS 8            /* cells of the zero-Doppler row the last process call corrected (0 = compensation not applied) */
+#define BLAH2HIP_INFO_LEAK_MAX_E12 9         /* 1e12 x the largest |g| measured for the kernel pair the last call ran (0 = not measurable: no
+                                              * zero-Doppler row / lag-0 column, rotated reference channel, chunked lag window) */
 #define BLAH2HIP_INFO_DOPPLER_TILES 7       /* tiles (units of work the persistent workgroups walk) of the last Doppler launch; 0 for the
                                              * non-persistent kernels */
 int blah2hip_amb_get_info(blah2hip_amb_t h, int key, int64_t *value);
@@ -388,6 +399,10 @@ int blah2hip_ctx_free_host(blah2hip_ctx_t c, void *hptr);
 int blah2hip_ctx_h2d(blah2hip_ctx_t c, void *dptr, const void *hptr, size_t bytes); /* enqueues on the stream */
 int blah2hip_ctx_d2h(blah2hip_ctx_t c, void *hptr, const void *dptr, size_t bytes); /* enqueues on the stream */
 int blah2hip_ctx_d2d(blah2hip_ctx_t c, void *dst, const void *src, size_t bytes);  /* enqueues on the stream */
+/* Measurement helper (no reference counterpart): enqueues a kernel that READS `bytes` of device memory at d_src
+ * (16-byte aligned) and does nothing else -- the streaming-read rate of the memory system, which bench.py reports
+ * beside the copy rate as the ceiling for the range kernel's loads.  d_sink: 4 device bytes, never written, or NULL. */
+int blah2hip_stream_read_dev(const void *d_src, size_t bytes, void *d_sink, void *stream);
 /* device pointers of a handle's internal results of the last blah2hip_amb_process_dev with NULL outputs:
  * map [max_batch][n_doppler][n_delay] complex fp32 and metrics [max_batch][2] doubles */
 int blah2hip_amb_result_ptrs(blah2hip_amb_t h, const void **d_map, const double **d_metrics);

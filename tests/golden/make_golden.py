@@ -45,7 +45,13 @@ CASES = {
     "ncorr_wraps_uint16": (200_000, 200_000, -3, 20, -1, 1, True, 19, ((7, 0.4, 0.05),), (-3, 20)),
     # 4201 delay bins (more than one on-chip transform holds: the engine runs the window as lag chunks)
     "many_delay_bins": (60_000, 60_000, -20, 4180, -2, 2, True, 17, ((4000, 1.0, 0.05), (17, -1.0, 0.05)), (-3, 20)),
+    # round 6, deep cancellation: receiver noise at 1 LSB (sigma = 1 per component before the int16 rounding), the direct
+    # path 58 dB above it (0.8 x 1000), one target 40 dB under the direct path.  After WienerHopf::process the channel is
+    # 800 x smaller than what the filter subtracted: the case where fp32 `y - w*x` is nearest the 1e-4 gate
+    "deep_cancel": (1_000_000, 100_000, -10, 100, -100, 100, True, 26, ((37, -63.0, 0.008),), (-10, 100)),
 }
+# name -> synth_iq keyword overrides (amplitudes); everything else uses the generator's defaults
+SYNTH_KW = {"deep_cancel": dict(ref_amp=1000.0, noise_amp=1.0, direct=0.8)}
 # name -> (n, bandwidth, seed)
 SPECTRUM_CASES = {
     "ragged_odd_decimation": (30_011, 2000.0, 21),     # D = 15, nS = 2000, nfft = 30000 < n
@@ -64,7 +70,7 @@ def main():
     for name, (fs, n, dmin, dmax, fmin, fmax, rh, seed, targets, clut) in CASES.items():
         if only and name not in only:
             continue
-        x, y = O.synth_iq(n, seed=seed, fs=fs, targets=targets)
+        x, y = O.synth_iq(n, seed=seed, fs=fs, targets=targets, **SYNTH_KW.get(name, {}))
         iq = np.empty((n, 4), dtype=np.int16)
         iq[:, 0], iq[:, 1], iq[:, 2], iq[:, 3] = x.real, x.imag, y.real, y.imag
         amb = R.RefAmbiguity(dmin, dmax, fmin, fmax, fs, n, rh)
