@@ -271,3 +271,70 @@ def test_numa_pinning_is_a_no_op_without_a_device():
         assert R.device_numa_cpus(torch, 0) is None
         assert R.pin_to_device_node(torch, 0) is False
         assert os.sched_getaffinity(0) == before
+
+
+def _worker_world8(rank, world, port, path, n_cpis, batch, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def counting(iq):
+            calls.append(len(iq))
+            return stub(iq)
+
+        def serialise(r):
+            return {"cpi": r["cpi"], "by": rank, "noisePower": r["noisePower"]}
+
+        seen = []
+        stats = {}
+        n = R.replay(R.RspduoFile(path, N_SAMPLES), counting, batch=batch, dist=dist, serialise=serialise, stats=stats,
+                     emit=lambda r: seen.append((r["cpi"], r["by"], r["noisePower"], len(calls))))
+        mine = R.shard_batches(n_cpis, batch, rank, world)
+        assert calls == [c for _, c in mine]                       # this rank processed exactly its own batches, in order
+        assert stats["cpis_owned"] == sum(c for _, c in mine)
+        np.save(os.path.join(out_dir, f"owned_{rank}.npy"), np.array([stats["cpis_owned"], len(calls)]))
+        if rank == 0:
+            assert n == n_cpis
+            np.save(os.path.join(out_dir, "seen.npy"), np.array(seen))
+        else:
+            assert n is None and not seen
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_cpis,batch", [(37, 2), (5, 1)])
+def test_eight_rank_replay_with_idle_ranks_gloo(tmp_path, n_cpis, batch):
+    """The shape the 8-GPU node runs (blah2.cpp:254-258 cut into batches over 8 ranks), as 8 gloo PROCESSES: 37 CPIs in
+    batches of 2 are 19 batches = two full rounds + a ragged third (ranks 0..2 busy, the last batch one CPI short,
+    ranks 3..7 idle in it); 5 single-CPI batches leave ranks 5..7 with NOTHING for the whole capture.  Every rank takes part
+    in every round's gather, rank 0 emits each CPI once, in file order, round by round while later rounds are unprocessed."""
+    import torch.multiprocessing as mp
+    world = 8
+    p = str(tmp_path / "w8.rspduo")
+    make_capture(p, n_cpis)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_world8, args=(world, port, p, n_cpis, batch, str(tmp_path)), nprocs=world, join=True)
+    seen = np.load(str(tmp_path / "seen.npy"))
+    f = R.RspduoFile(p, N_SAMPLES)
+    want = stub(f.batch(list(range(n_cpis))))
+    assert seen[:, 0].tolist() == list(range(n_cpis))                      # each CPI once, in file order
+    assert np.allclose(seen[:, 2], [w["noisePower"] for w in want])
+    assert seen[:, 1].tolist() == [(k // batch) % world for k in range(n_cpis)]   # serialised by the rank that owns the batch
+    # streaming: a CPI of round g is emitted after rank 0's (g+1)-th own batch (or its last, in rounds where it has none)
+    n_batches = -(-n_cpis // batch)
+    own0 = len(R.shard_batches(n_cpis, batch, 0, world))
+    for k in range(n_cpis):
+        g = (k // batch) // world
+        assert seen[k, 3] == min(g + 1, own0), (k, seen[k, 3])
+    owned = [np.load(str(tmp_path / f"owned_{r}.npy")) for r in range(world)]
+    assert sum(int(o[0]) for o in owned) == n_cpis
+    idle = [r for r in range(world) if int(owned[r][1]) == 0]
+    assert idle == list(range(min(n_batches, world), world))                # ranks beyond the batch count never work
+    if n_batches % world:
+        last_round_busy = n_batches % world
+        assert all(int(owned[r][1]) == n_batches // world + (1 if r < last_round_busy else 0) for r in range(world))
