@@ -395,8 +395,31 @@ bool use_wave1k_range(const blah2hip_amb_s *h, int nPulses)
   return nPulses >= 4 * RANGEW1K_WAVES_PER_SIMD * h->numCU;
 }
 
+#ifdef B2_RANGEW1K_GLDS
+// the LDS-DMA experiment build: fp32 planes with an even first lag run rangew1k_glds_kernel instead (kernels.hpp)
+inline bool launch_rangew1k_glds(blah2hip_amb_s *h, const RangeArgs &a, InC32 in, hipStream_t st, int *rc)
+{
+  if (a.plan.delayMin & 1) return false;
+  const size_t lds = (size_t)(Wave1kFft::TW_ELEMS + RANGEG_WAVES * Wave1kFft::X_ELEMS) * sizeof(cf);
+  const bool shortx = a.plan.segLen <= 9 * 64, out7 = a.plan.nDelay <= 7 * 64;
+  auto kern = shortx ? (out7 ? rangew1k_glds_kernel<true, true> : rangew1k_glds_kernel<true, false>)
+                     : (out7 ? rangew1k_glds_kernel<false, true> : rangew1k_glds_kernel<false, false>);
+  *rc = BLAH2HIP_OK;
+  if (blah2hip_ensure_lds_((const void *)kern, (int)lds) != hipSuccess) { *rc = fail(BLAH2HIP_ERR_HIP, "LDS size (glds experiment)"); return true; }
+  const int grid = std::min<int>((a.nPulses + RANGEG_WAVES - 1) / RANGEG_WAVES, range_grid_cap(h, lds, RANGEG_WAVES, 16));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RANGEG_WAVES), lds, st, a, in);
+  if (hipGetLastError() != hipSuccess) *rc = fail(BLAH2HIP_ERR_HIP, "launch (glds experiment)");
+  h->lastRange = BLAH2HIP_RANGE_WAVE1K;
+  return true;
+}
+template <class In> inline bool launch_rangew1k_glds(blah2hip_amb_s *, const RangeArgs &, In, hipStream_t, int *) { return false; }
+#endif
+
 template <class In> int launch_rangew1k_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
 {
+#ifdef B2_RANGEW1K_GLDS
+  { int rc_ = 0; if (launch_rangew1k_glds(h, a, in, st, &rc_)) return rc_; }
+#endif
   const size_t lds = (size_t)(Wave1kFft::TW_ELEMS + RANGEW1K_WAVES * Wave1kFft::X_ELEMS) * sizeof(cf);
   const bool shortx = a.plan.segLen <= 9 * 64;
   const bool out7 = a.plan.nDelay <= 7 * 64;

@@ -565,6 +565,101 @@ __global__ __launch_bounds__(64 * RANGEW1K_WAVES, RANGEW1K_WAVES_PER_SIMD) void 
   }
 }
 
+#ifdef B2_RANGEW1K_GLDS
+// EXPERIMENT (round 6; built only with -DB2_RANGEW1K_GLDS, tools/build_variant.sh): rangew1k_kernel
+// with a segment's x' and y' windows landing in the wave's exchange region by LDS-DMA (`buffer_load_dwordx4 ... lds`)
+// instead of in 18 + 32 registers requested a segment ahead.  156 -> <= 128 VGPRs: FOUR waves per SIMD, 16 waves per
+// workgroup, LDS = table + 16 x 8.5 KB = 147 KB.  There is no room for a second landing zone (a prefetched y' window of
+// 8 KB per wave would need 128 KB more), so each window lands JUST IN TIME -- x' before the segment's first transform, y'
+// between its two -- and its round trip is covered by the SIMD's other three waves, not by this wave's own arithmetic.
+// (First form: x' kept its 18 prefetch registers, only y' by LDS-DMA: 128 VGPRs with 27 spilled.)
+// A window of 128 n samples = n pieces of 1 KiB (lane L of piece j: samples 128 j + 2 L, + 1, lane-linear: the LDS image
+// IS the window); the descriptor's range check zero-pads a window's END dword by dword, but a NEGATIVE offset drops all
+// 16 bytes (tools/membench/gldsprobe.hip), so the y' window must start on an even sample of the pulse: delayMin even,
+// checked by the launcher (only segment 0 reaches below the pulse's first sample).
+// No whole-register reuse of the y' windows' overlap (REUSE): every y' sample is requested nDelay / segLen more often.
+constexpr int RANGEG_WAVES = 16;
+typedef __attribute__((address_space(3))) void b2_lds_void;
+template <bool SHORTX, bool OUT7>
+__global__ __launch_bounds__(64 * RANGEG_WAVES, 4) void rangew1k_glds_kernel(RangeArgs a, InC32 in)
+{
+  using W = Wave1kFft;
+  constexpr int NX = SHORTX ? 9 : 16, PX = SHORTX ? 5 : 8; // x' values per lane; 1 KiB pieces of its window
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf *table = reinterpret_cast<cf *>(smem);
+  const int t = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  cf *X = table + W::TW_ELEMS + wave * W::X_ELEMS;
+  W::fill_table(threadIdx.x, 64 * RANGEG_WAVES, a.tw, table);
+  __syncthreads(); // the only barrier: waves without a pulse leave after it
+  W::Tw w;
+  W::load_twiddles(t, a.tw, table, w);
+  const RangePlan p = a.plan;
+  const int stride = gridDim.x * RANGEG_WAVES;
+  int pulse = blockIdx.x * RANGEG_WAVES + wave;
+  if (pulse >= a.nPulses) return;
+  int cpi = pulse / p.nDoppler;
+  int i = pulse - cpi * p.nDoppler;
+  int64_t base = (int64_t)cpi * a.cpiStride + (int64_t)i * p.nCorr;
+  int s = 0;
+  cf acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; e++) acc[e] = cmake(0.f, 0.f);
+  for (;;) {
+    cf v[16];
+    {
+      // x' of this segment: sample m of the segment at X[m], zeros from the segment's (or the pulse's) end on
+      const int s0 = s * p.segLen;
+      const __amdgpu_buffer_rsrc_t d = make_rsrc_b(in.x + base + s0, min(p.segLen, p.nCorr - s0) * 8);
+#pragma unroll
+      for (int j = 0; j < PX; j++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(d, (b2_lds_void *)(X + 128 * j), 16, 16 * t + 1024 * j, 0, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < NX; k++) v[k] = X[t + 64 * k];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // in registers before the transform's first exchange overwrites the window
+    }
+    W::s1<-1, NX>(v, w);
+    W::finish<-1>(t, v, w, X); // v = X spectrum; the exchange region is free again
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // ... once the transform's last reads have returned: nothing else orders an LDS-DMA behind them
+    cf yv[16];
+    {
+      // y' of this segment: sample m of the window at X[m]
+      const __amdgpu_buffer_rsrc_t d = make_rsrc_b(in.y + base, p.nCorr * 8);
+      const int voff = (s * p.segLen + p.delayMin + 2 * t) * 8; // negative below the pulse's first sample: zeros
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        // the whole offset in the VGPR, opaque: split into voffset + immediate, a negative voffset is out of range whatever
+        // the immediate adds (bufload.hpp) -- the lanes below the pulse's first sample would lose their later pieces
+        int vo = voff + 1024 * j;
+        asm volatile("" : "+v"(vo));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(d, (b2_lds_void *)(X + 128 * j), 16, vo, 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 16; k++) yv[k] = X[t + 64 * k];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    W::template transform<-1, 16, false>(t, yv, w, X);
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = cmacc(acc[e], yv[e], v[e]);
+    s++;
+    if (s == p.nSeg) { // the pulse is complete
+      W::template transform<+1, 16, OUT7>(t, acc, w, X);
+      store_lags_w<OUT7 ? 7 : 16>(a.out, p, cpi, i, t, acc);
+      pulse += stride;
+      if (pulse >= a.nPulses) break;
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[e] = cmake(0.f, 0.f);
+      cpi = pulse / p.nDoppler;
+      i = pulse - cpi * p.nDoppler;
+      base = (int64_t)cpi * a.cpiStride + (int64_t)i * p.nCorr;
+      s = 0;
+    }
+  }
+}
+#endif
+
 // --------------------------------------------------------------------------
 // Range kernel for SMALL launches at F = 1024 (a lone CPI, the real-time shape of blah2.cpp:245-289: 513 pulses): the
 // one-wave kernel above gives a pulse to ONE wave, its segments in series -- with fewer pulses than wave slots the
