@@ -306,6 +306,8 @@ def _measure(a, env, handles):
         h_.set_doppler_kernel(a.doppler_kernel)
         if a.fft_len:
             h_.set_fft_len(a.fft_len)
+        if a.range_grid:
+            h_.set_range_grid(a.range_grid)
         if a.range_kernel != "auto":
             h_.set_range_kernel({"wave": blah2_amd._lib.RANGE_WAVE, "wave1k": blah2_amd._lib.RANGE_WAVE1K, "ps": blah2_amd._lib.RANGE_PS, "e8": blah2_amd._lib.RANGE_E8,
                                  "e16": blah2_amd._lib.RANGE_E16}[a.range_kernel])
@@ -861,7 +863,7 @@ def _leg_args(a, extra):
     import copy
     la = copy.copy(a)
     la.config, la.chain, la.fmt, la.cfar, la.batch, la.streams = "cfg2", "amb", "c32", "2d", 0, 1
-    la.n_doppler, la.doppler_kernel, la.range_kernel, la.fft_len = 0, "auto", "auto", 0
+    la.n_doppler, la.doppler_kernel, la.range_kernel, la.fft_len, la.range_grid = 0, "auto", "auto", 0, 0
     it = iter(extra)
     for k in it:
         v = next(it)
@@ -903,6 +905,8 @@ def main(argv=None):
                     help="range kernel: by transform length (F = 2048: the one-wave kernel, F = 4096: the two-wave kernel), or forced")
     ap.add_argument("--fft-len", type=int, default=0, choices=[0, 1024, 2048, 4096],
                     help="force the range transform length (0 = the planner's choice); diagnostics")
+    ap.add_argument("--range-grid", type=int, default=0,
+                    help="cap the range kernel's grid (workgroups; 0 = its residency): e.g. the CU count for ONE workgroup per CU; diagnostics")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent CPI streams per GPU (engine handles on their own HIP streams); successive "
                          "steps alternate between them so one batch's Doppler stage overlaps the next batch's range stage")
