@@ -8,7 +8,10 @@ resulting ``blah2_amd/libblah2hip.so`` travels to the GPU box with the tree.
 """
 from __future__ import annotations
 
+import contextlib
+import fcntl
 import os
+import shlex
 import shutil
 import subprocess
 import sys
@@ -45,37 +48,86 @@ def hipcc():
     return exe
 
 
-def build_hip(force=False, verbose=True):
-    srcs = _sources(CSRC, (".hip",))
-    deps = srcs + _sources(CSRC, (".hpp",)) + [os.path.join(ROOT, "include", "blah2hip.h")]
-    if not force and not _newer(LIB, deps):
-        return LIB
-    # one hipcc per translation unit, side by side (capi.hip alone is 40 s of the build), then one link
-    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize",
-             "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+@contextlib.contextmanager
+def _build_lock():
+    """One builder at a time per tree: ranks of a job and pytest workers that import against a stale library would otherwise
+    compile into the same object files and link each other's half-written ones."""
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(objdir, ".lock"), "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
+def extra_flags():
+    """Extra hipcc flags for the product build from BLAH2HIP_EXTRA_HIPCC_FLAGS (shell-quoted).  They are part of the
+    staleness check (a library built with other flags is rebuilt).  Experiment builds that must not replace the product
+    library go through tools/build_variant.sh instead."""
+    return shlex.split(os.environ.get("BLAH2HIP_EXTRA_HIPCC_FLAGS", ""))
+
+
+def build_hip(force=False, verbose=True):
+    with _build_lock():
+        return _build_hip_locked(force, verbose)
+
+
+def _build_hip_locked(force, verbose):
+    srcs = _sources(CSRC, (".hip",))
+    deps = srcs + _sources(CSRC, (".hpp",)) + [os.path.join(ROOT, "include", "blah2hip.h")]
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize",
+             *extra_flags(), "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    objdir = os.path.join(PKG, "build")
+    stamp = os.path.join(objdir, "flags.txt")
+    flag_text = " ".join(flags[:-4])
+    same_flags = os.path.exists(stamp) and open(stamp).read() == flag_text
+    # (a library that came with the tree and has no stamp beside it was built by this script with the default flags)
+    if not force and not _newer(LIB, deps) and (same_flags or (not os.path.exists(stamp) and not extra_flags())):
+        return LIB
+    # one hipcc per translation unit, side by side (capi.hip alone is 40 s of the build), then one link
     procs = []
-    for src in srcs:
-        obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [hipcc(), *flags, "-c", src, "-o", obj]
-        if verbose:
-            print("[blah2_amd.build]", " ".join(cmd), flush=True)
-        procs.append((cmd, obj, subprocess.Popen(cmd)))
-    objs = []
-    for cmd, obj, p_ in procs:
-        if p_.wait() != 0:
-            raise subprocess.CalledProcessError(p_.returncode, cmd)
-        objs.append(obj)
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-fPIC", "-shared", *objs, "-o", LIB]
+    try:
+        for src in srcs:
+            obj = os.path.join(objdir, os.path.relpath(src, CSRC).replace(os.sep, "__") + ".o")  # same-named files in subdirectories do not collide
+            cmd = [hipcc(), *flags, "-c", src, "-o", obj]
+            if verbose:
+                print("[blah2_amd.build]", " ".join(cmd), flush=True)
+            procs.append((cmd, obj, subprocess.Popen(cmd)))
+        objs = []
+        for cmd, obj, p_ in procs:
+            if p_.wait() != 0:
+                raise subprocess.CalledProcessError(p_.returncode, cmd)
+            objs.append(obj)
+    except BaseException:
+        for _, _, p_ in procs:  # a failed unit (or an interrupt): the siblings do not keep compiling behind our back
+            if p_.poll() is None:
+                p_.kill()
+            p_.wait()
+        raise
+    tmp = LIB + f".{os.getpid()}.tmp"
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-fPIC", "-shared", *objs, "-o", tmp]
     if verbose:
         print("[blah2_amd.build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)  # a process that has the old library mapped keeps it; nobody sees a half-written file
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    with open(stamp, "w") as f:
+        f.write(flag_text)
     return LIB
 
 
 def build_host(force=False, verbose=True):
     """C++ classes with the reference's own surface (Ambiguity, Map, IqData, ...)."""
+    with _build_lock():
+        return _build_host_locked(force, verbose)
+
+
+def _build_host_locked(force, verbose):
     srcs = _sources(HOST, (".cpp",))
     srcs = [s for s in srcs if not os.path.basename(s).startswith("test_")]
     if not srcs:

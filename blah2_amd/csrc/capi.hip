@@ -441,7 +441,9 @@ bool use_ps_range(const blah2hip_amb_s *h, int nPulses)
 {
   if (h->r3 != 4) return false;
   if (h->rangeKernel == BLAH2HIP_RANGE_PS) return true;
-  return h->rangeKernel == 0 && nPulses <= 4 * h->numCU; // below two rounds of its resident workgroups
+  // automatic: below two rounds of its resident workgroups, and at most two segments per wave -- the shape the planner's
+  // cost factor and every timing of this kernel assume (a forced kernel walks any segment count; tested up to 13)
+  return h->rangeKernel == 0 && nPulses <= 4 * h->numCU && h->plan.nSeg <= 2 * RANGEPS_WAVES;
 }
 
 template <class In> int launch_rangeps_t(blah2hip_amb_s *h, const RangeArgs &a, In in, hipStream_t st)
@@ -1482,7 +1484,16 @@ int blah2hip_cfar1d_dev(blah2hip_amb_t h, const void *d_map, const double *d_met
   a.minDoppler = min_doppler;
   a.cap = cap;
   if ((rc = tic(h, BLAH2HIP_K_CFAR, st))) return rc;
-  hipLaunchKernelGGL(cfar1d_kernel, dim3(a.nD, n_cpi), dim3(256), (size_t)a.nDelay * sizeof(double), st, a);
+  {
+    // the row as fp64 |z|^2 in LDS while it fits (150 KB: 19 200 delay bins), straight from L2 beyond
+    const size_t rowBytes = (size_t)a.nDelay * sizeof(double);
+    if (rowBytes <= 150 * 1024) {
+      if (rowBytes > 48 * 1024) LDSCFG(cfar1d_kernel<true>, 150 * 1024); // the attribute is set once per (device, kernel): its largest use
+      hipLaunchKernelGGL(cfar1d_kernel<true>, dim3(a.nD, n_cpi), dim3(256), rowBytes, st, a);
+    } else {
+      hipLaunchKernelGGL(cfar1d_kernel<false>, dim3(a.nD, n_cpi), dim3(256), 0, st, a);
+    }
+  }
   HIPCHK(hipGetLastError());
   if ((rc = toc(h, BLAH2HIP_K_CFAR, st))) return rc;
   return BLAH2HIP_OK;
@@ -1540,7 +1551,6 @@ int blah2hip_cfar1d_map(const float *map, uint32_t n_doppler, uint32_t n_delay, 
   if (n_doppler == 0 || n_delay == 0) return fail(BLAH2HIP_ERR_INVALID, "empty map");
   if (n_guard < 0 || n_guard > 127 || n_train < 0 || n_train > 127 || min_delay < -128 || min_delay > 127)
     return fail(BLAH2HIP_ERR_INVALID, "nGuard/nTrain/minDelay outside int8 range");
-  if ((size_t)n_delay * sizeof(double) > 64 * 1024) return fail(BLAH2HIP_ERR_UNSUPPORTED, "more than 8192 delay bins");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(BLAH2HIP_ERR_NO_DEVICE, "no HIP device visible (the HIP path is the only path)");
@@ -1576,7 +1586,13 @@ int blah2hip_cfar1d_map(const float *map, uint32_t n_doppler, uint32_t n_delay, 
     a.delayAxis = (const int32_t *)(pool + oAxis); // x->delay[j] of a caller-built map need not be delay[0] + j (CfarDetector1D.cpp:53)
     a.nGuard = n_guard; a.nTrain = n_train; a.minDelay = min_delay; a.minDoppler = min_doppler;
     a.cap = (uint32_t)cells;
-    hipLaunchKernelGGL(cfar1d_kernel, dim3(a.nD, 1), dim3(256), (size_t)a.nDelay * sizeof(double), 0, a);
+    const size_t rowBytes = (size_t)a.nDelay * sizeof(double);
+    if (rowBytes <= 150 * 1024) {
+      if (rowBytes > 48 * 1024) HIPCHK(blah2hip_ensure_lds_((const void *)cfar1d_kernel<true>, 150 * 1024));
+      hipLaunchKernelGGL(cfar1d_kernel<true>, dim3(a.nD, 1), dim3(256), rowBytes, 0, a);
+    } else {
+      hipLaunchKernelGGL(cfar1d_kernel<false>, dim3(a.nD, 1), dim3(256), 0, 0, a);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(&n, pool + oCnt, sizeof(uint32_t), hipMemcpyDeviceToHost)); // synchronises with the null stream
     hits.resize(n);

@@ -38,6 +38,9 @@ struct CfarArgs {
   uint32_t cap;
 };
 
+// STAGED = false: rows longer than the LDS holds as fp64 (more than 19 k delay bins; blah2hip_cfar1d_map on a host-built
+// map): the same window sums with |z|^2 formed straight from the L2-resident row.
+template <bool STAGED>
 __global__ void cfar1d_kernel(CfarArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -45,29 +48,37 @@ __global__ void cfar1d_kernel(CfarArgs a)
   const int row = blockIdx.x, cpi = blockIdx.y;
   if (fabs(a.doppler[row]) < a.minDoppler) return; // :40
   const cf *z = a.map + ((size_t)cpi * a.nD + row) * a.nDelay;
-  for (int j = threadIdx.x; j < a.nDelay; j += blockDim.x) {
-    const cf c = z[j];
-    sq[j] = (double)c.x * (double)c.x + (double)c.y * (double)c.y; // |z*z| (:47)
+  auto sqv = [&](int k) -> double {
+    if (STAGED) return sq[k];
+    const cf c = z[k];
+    return (double)c.x * (double)c.x + (double)c.y * (double)c.y;
+  };
+  if (STAGED) {
+    for (int j = threadIdx.x; j < a.nDelay; j += blockDim.x) {
+      const cf c = z[j];
+      sq[j] = (double)c.x * (double)c.x + (double)c.y * (double)c.y; // |z*z| (:47)
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const double noisePower = a.metrics[2 * cpi];
   for (int j = threadIdx.x; j < a.nDelay; j += blockDim.x) {
     if ((a.delayAxis ? a.delayAxis[j] : j + a.delayMin) < a.minDelay) continue; // :53  x->delay[j] < minDelay
     int n = 0;
     double tot = 0.0;
     for (int k = j - a.nGuard - a.nTrain; k < j - a.nGuard; k++)
-      if (k > 0 && k < a.nDelay) { tot += sq[k]; n++; }
+      if (k > 0 && k < a.nDelay) { tot += sqv(k); n++; }
     for (int k = j + a.nGuard + 1; k < j + a.nGuard + a.nTrain + 1; k++)
-      if (k >= 0 && k < a.nDelay) { tot += sq[k]; n++; }
+      if (k >= 0 && k < a.nDelay) { tot += sqv(k); n++; }
     if (n == 0) continue; // alpha = 0*inf = NaN in the reference: never exceeds
     const double thr = a.alpha[n] * (tot / n);
-    if (sq[j] > thr) {
+    const double sj = sqv(j);
+    if (sj > thr) {
       const uint32_t slot = atomicAdd(&a.count[cpi], 1u);
       if (slot < a.cap) {
         blah2hip_hit_t h;
         h.row = row;
         h.col = j;
-        h.snr = 5.0 * log10(sq[j]) - noisePower; // 10 log10|z| - noisePower (:48)
+        h.snr = 5.0 * log10(sj) - noisePower; // 10 log10|z| - noisePower (:48)
         a.hits[(size_t)cpi * a.cap + slot] = h;
       }
     }

@@ -156,7 +156,10 @@ struct CorrArgs {
 // grid (nJobs, nCpi): per segment FFT(x' = zero-padded xs segment) ONCE, then the
 // xs window (-> r) and the y window (-> b) against it; both partial correlations
 // accumulate in registers across the workgroup's segments.
-template <int R3, class In> __global__ __launch_bounds__(16 * R3, 2) void clutter_corr_kernel(CorrArgs a)
+// (F = 4096: built for ONE workgroup of 256 threads per SIMD set -- 257 registers are what the three live windows, two
+// accumulators and two twiddle sets need there, and at the two-workgroup cap of 256 one value went to scratch in every
+// build of rounds 2-5.  That instantiation only runs for filters of 2050 ... 4081 taps: the half-window form takes the rest.)
+template <int R3, class In> __global__ __launch_bounds__(16 * R3, R3 == 16 ? 1 : 2) void clutter_corr_kernel(CorrArgs a)
 {
   using W = WgFft<R3>;
   constexpr int T = W::T;
@@ -177,28 +180,36 @@ template <int R3, class In> __global__ __launch_bounds__(16 * R3, 2) void clutte
   for (int r = sw.first; r < sw.count; r += sw.step) {
     const int g = sw.base + r;
     const uint32_t n0 = (uint32_t)g * (uint32_t)a.segLen;
-    // all 32 loads of the segment first (the y window is consumed last)
+    // all 32 loads of the segment first (the y window is consumed last) -- except at F = 4096, where the kernel sits at the
+    // 256-register cap: there the y window is requested inside the second transform (its 32 registers are free until
+    // then), which removed the one spilled register (8 bytes of scratch per lane) of rounds 2-5; this instantiation
+    // only runs for filters of 2050 ... 4081 taps (the half-window form takes the others)
     cf v[16], wv[16], yw[16];
     uint32_t j0;
     int xcnt;
     const bool whole = (uint64_t)n0 + 16 * T <= a.N; // the window does not run around the end of the CPI
-    if (whole && xs_window_plain((int)n0, 16 * T, a.xs, &j0, &xcnt)) { // all but a CPI's first and last windows: immediates only
+    const bool plain = whole && xs_window_plain((int)n0, 16 * T, a.xs, &j0, &xcnt); // all but a CPI's first and last windows: immediates only
+    auto load_y = [&]() {
+      if (plain) {
+        using CY = typename BufChanOf<In>::Y;
+        const __amdgpu_buffer_rsrc_t yd = make_rsrc_b(BufChanOf<In>::y(a.x, a.y, (int64_t)cpi * a.cpiStride + n0), 16 * T * CY::STRIDE);
+#pragma unroll
+        for (int k = 0; k < 16; k++) yw[k] = RawBuiltin<CY>::cvt(RawBuiltin<CY>::ld(yd, (t + T * k) * CY::STRIDE, 0));
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) yw[k] = Y[wrapN(n0 + (uint32_t)(t + T * k), a.N)]; // y window (mode b)
+      }
+    };
+    if (plain) {
       using CX = typename BufChanOf<In>::X;
-      using CY = typename BufChanOf<In>::Y;
       const __amdgpu_buffer_rsrc_t xd = make_rsrc_b(BufChanOf<In>::x(a.x, a.y, (int64_t)cpi * a.cpiStride + j0), 16 * T * CX::STRIDE);
-      const __amdgpu_buffer_rsrc_t yd = make_rsrc_b(BufChanOf<In>::y(a.x, a.y, (int64_t)cpi * a.cpiStride + n0), 16 * T * CY::STRIDE);
 #pragma unroll
       for (int k = 0; k < 16; k++) wv[k] = RawBuiltin<CX>::cvt(RawBuiltin<CX>::ld(xd, (t + T * k) * CX::STRIDE, 0));
-#pragma unroll
-      for (int k = 0; k < 16; k++) yw[k] = RawBuiltin<CY>::cvt(RawBuiltin<CY>::ld(yd, (t + T * k) * CY::STRIDE, 0));
     } else {
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
-        const uint32_t nw = wrapN(n0 + (uint32_t)(t + T * k), a.N); // circular window index, n0 + m < N + F
-        wv[k] = X[xs_index(nw, a.xs)];                      // xs window (mode r)
-        yw[k] = Y[nw];                                      // y window (mode b)
-      }
+      for (int k = 0; k < 16; k++) wv[k] = X[xs_index(wrapN(n0 + (uint32_t)(t + T * k), a.N), a.xs)]; // xs window (mode r): circular index, n0 + m < N + F
     }
+    if (R3 < 16) load_y();
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int m = t + T * k;
@@ -212,6 +223,7 @@ template <int R3, class In> __global__ __launch_bounds__(16 * R3, 2) void clutte
     W::fwd_s1(t, wv, tw1, P);
     __syncthreads();
     W::fwd_s2(t, wv, P, Q);
+    if (R3 == 16) load_y(); // behind the second transform's last exchange write: wv's 32 registers are about to be consumed
     __syncthreads();
     W::fwd_s3(t, wv, tw3, Q);
 #pragma unroll
@@ -789,6 +801,7 @@ struct blah2hip_clutter_s {
   int fftLenForce = 0;       // BLAH2HIP_CLUTTER_OPT_FFT_LEN (0 = planner)
   int corrForce = 0;         // BLAH2HIP_CLUTTER_OPT_CORR
   int32_t *lastOk = nullptr; // where the last process call wrote its flags
+  hipStream_t lastStream = nullptr; // ... and the stream it was enqueued on (blah2hip_clutter_get_info waits for that one only)
   KernelTimer<BLAH2HIP_CK_COUNT> timer;
 };
 
@@ -1028,6 +1041,7 @@ template <int R3, class In> int launch_clutter(blah2hip_clutter_s *h, const void
   CHIP(hipGetLastError());
   CHIP(h->timer.toc(BLAH2HIP_CK_FIR, st));
   h->lastOk = ok;
+  h->lastStream = st;
   return BLAH2HIP_OK;
 }
 
@@ -1111,20 +1125,15 @@ int blah2hip_clutter_get_info(blah2hip_clutter_t h, int what, int64_t *value)
   case BLAH2HIP_CLUTTER_INFO_SOLVE_FORM: *value = h->lastForm; return BLAH2HIP_OK;
   case BLAH2HIP_CLUTTER_INFO_SOLVE_E: *value = h->lastE; return BLAH2HIP_OK;
   case BLAH2HIP_CLUTTER_INFO_SOLVE_G: *value = h->lastG; return BLAH2HIP_OK;
-  case BLAH2HIP_CLUTTER_INFO_SOLVE_FAULT: {
-    uint32_t v = 0;
-    CHIP(hipSetDevice(h->device));
-    CHIP(hipDeviceSynchronize());
-    if (h->d_epoch) CHIP(hipMemcpy(&v, h->d_epoch + 1, sizeof(v), hipMemcpyDeviceToHost));
-    *value = v;
-    return BLAH2HIP_OK;
-  }
+  case BLAH2HIP_CLUTTER_INFO_SOLVE_FAULT:
   case BLAH2HIP_CLUTTER_INFO_SOLVE_RETRIES: {
-    uint32_t v = 0;
+    // the stream the handle's last call ran on, not the device (a poll in a pipeline must not stall other streams and
+    // handles); both words in one copy
+    uint32_t v[2] = {0, 0};
     CHIP(hipSetDevice(h->device));
-    CHIP(hipDeviceSynchronize());
-    if (h->d_epoch) CHIP(hipMemcpy(&v, h->d_epoch + 2, sizeof(v), hipMemcpyDeviceToHost));
-    *value = v;
+    CHIP(hipStreamSynchronize(h->lastStream));
+    if (h->d_epoch) CHIP(hipMemcpy(v, h->d_epoch + 1, sizeof v, hipMemcpyDeviceToHost));
+    *value = what == BLAH2HIP_CLUTTER_INFO_SOLVE_FAULT ? v[0] : v[1];
     return BLAH2HIP_OK;
   }
   default: CFAIL(BLAH2HIP_ERR_INVALID, "unknown info");
@@ -1223,6 +1232,7 @@ int blah2hip_clutter_solve(blah2hip_clutter_t h, const double *rb, uint32_t n_cp
   sa.partial = nullptr; sa.rb = h->d_rb; sa.w = h->d_w; sa.ok = h->d_ok; sa.nBins = h->nBins; sa.nJobs = 0; sa.epoch = h->d_epoch;
   { const int rc_ = launch_solve(h, sa, n_cpi, h->stream); if (rc_) return rc_; }
   h->lastOk = h->d_ok;
+  h->lastStream = h->stream;
   CHIP(hipMemcpyAsync(w, h->d_w, (size_t)n_cpi * n * sizeof(cf), hipMemcpyDeviceToHost, h->stream));
   CHIP(hipMemcpyAsync(ok, h->d_ok, (size_t)n_cpi * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   CHIP(hipStreamSynchronize(h->stream));
@@ -1239,6 +1249,7 @@ int blah2hip_clutter_solve_dev(blah2hip_clutter_t h, const double *d_rb, uint32_
   SolveArgs sa;
   sa.partial = nullptr; sa.rb = (dcx *)d_rb; sa.w = (cf *)d_w; sa.ok = d_ok; sa.nBins = h->nBins; sa.nJobs = 0; sa.epoch = h->d_epoch;
   h->lastOk = d_ok;
+  h->lastStream = (hipStream_t)stream;
   return launch_solve(h, sa, n_cpi, st);
 }
 

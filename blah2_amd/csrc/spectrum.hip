@@ -162,6 +162,69 @@ __global__ __launch_bounds__(DFT_SLICES * DFT_BINS) void spectrum_dft_kernel(Spe
   }
 }
 
+// ---- nS > 65536: the nS-point DFT of the folded sequence as a chirp-z (Bluestein) product on a power-of-two fp64 transform ----
+// The direct evaluation above is quadratic in nS (1.7e10 complex multiply-adds at the old cap of 65536; the reference
+// accepts any bandwidth, SpectrumAnalyser.cpp:9-30).  With ch[p] = exp(-i pi p^2 / nS) (the angle reduced exactly:
+// p^2 mod 2 nS in integers):  X[m] = ch[m] sum_p (u[p] ch[p]) conj(ch[m - p])  -- a convolution, run as three M-point
+// transforms (M = 2^k >= 2 nS - 1; the kernel spectrum is formed once per handle).  A radix-2 autosort (Stockham) pass per
+// launch between two global buffers: log2 M launches of M / 2 butterflies, every twiddle from one exact table.  This is an
+// envelope path (a bandwidth above 65 kHz of spectrum bins), written for correctness in fp64, not for speed: 20-odd
+// launches of a few MB each.
+struct BluArgs {
+  const dcx *u;      // [nCpi][nS]
+  const dcx *chirp;  // [nS]
+  const dcx *kspec;  // [M]: transform of the wrapped conj chirp, times 1 / M
+  const dcx *tw;     // [M / 2]: exp(-2 pi i k / M)
+  dcx *a, *b;        // [nCpi][M] ping-pong
+  dcx *out;          // [nCpi][nS]
+  uint32_t nS, M, hq;
+};
+
+// a[p] = u[p] ch[p] (p < nS), 0 beyond
+__global__ void blu_load_kernel(BluArgs g)
+{
+  const uint32_t cpi = blockIdx.y;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < g.M; p += gridDim.x * blockDim.x)
+    g.a[(size_t)cpi * g.M + p] = p < g.nS ? dmul(g.u[(size_t)cpi * g.nS + p], g.chirp[p]) : dmake(0.0, 0.0);
+}
+
+// one Stockham radix-2 pass, src -> dst: butterflies of span `half` (1, 2, 4, ...), INV: conjugate twiddles
+template <bool INV>
+__global__ void blu_pass_kernel(const dcx *src, dcx *dst, const dcx *tw, uint32_t M, uint32_t half)
+{
+  const uint32_t cpi = blockIdx.y;
+  src += (size_t)cpi * M;
+  dst += (size_t)cpi * M;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < M / 2; i += gridDim.x * blockDim.x) {
+    // Stockham: x_out[q + 2 half p'] ... with j = i / half (block), k = i % half
+    const uint32_t k = i & (half - 1), j = i - k; // j = block * half
+    const dcx a0 = src[i], a1 = src[i + M / 2];
+    dcx w = tw[k * (M / 2 / half)];
+    if (INV) w.y = -w.y;
+    const dcx t = dmul(a1, w);
+    dst[2 * j + k] = dmake(a0.x + t.x, a0.y + t.y);
+    dst[2 * j + k + half] = dmake(a0.x - t.x, a0.y - t.y);
+  }
+}
+
+__global__ void blu_mul_kernel(dcx *a, const dcx *kspec, uint32_t M)
+{
+  const uint32_t cpi = blockIdx.y;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < M; p += gridDim.x * blockDim.x)
+    a[(size_t)cpi * M + p] = dmul(a[(size_t)cpi * M + p], kspec[p]);
+}
+
+// spectrum[k] = Xd[(k + hq) mod nS],  Xd[m] = conv[m] ch[m]
+__global__ void blu_store_kernel(BluArgs g, const dcx *conv)
+{
+  const uint32_t cpi = blockIdx.y;
+  const uint32_t hqm = g.hq % g.nS;
+  for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < g.nS; m += gridDim.x * blockDim.x) {
+    const uint32_t k = m >= hqm ? m - hqm : m + g.nS - hqm;
+    g.out[(size_t)cpi * g.nS + k] = dmul(conv[(size_t)cpi * g.M + m], g.chirp[m]);
+  }
+}
+
 } // namespace
 
 extern "C" void blah2hip_set_error_(const char *msg);
@@ -189,7 +252,23 @@ struct blah2hip_spectrum_s {
   hipStream_t stream = nullptr;
   dcx *d_wD = nullptr, *d_wS = nullptr, *d_part = nullptr, *d_u = nullptr, *d_out = nullptr;
   cf *d_stage = nullptr;
+  // nS > DIRECT_MAX: the chirp-z path
+  uint32_t M = 0;
+  dcx *d_chirp = nullptr, *d_kspec = nullptr, *d_btw = nullptr, *d_ba = nullptr, *d_bb = nullptr;
 };
+constexpr uint32_t DIRECT_MAX = 65536; // bins evaluated directly (quadratic); beyond: chirp-z on a power-of-two transform
+
+// the M-point forward (INV = false) or unnormalised inverse transform of every CPI's row of `a` (ping-pong with `b`);
+// returns the buffer that holds the result
+template <bool INV> dcx *blu_transform(blah2hip_spectrum_s *h, dcx *a, dcx *b, uint32_t n_cpi, hipStream_t st)
+{
+  const dim3 grid(std::min<uint32_t>((h->M / 2 + 255) / 256, 4096), n_cpi);
+  for (uint32_t half = 1; half < h->M; half <<= 1) {
+    hipLaunchKernelGGL(blu_pass_kernel<INV>, grid, dim3(256), 0, st, a, b, h->d_btw, h->M, half);
+    std::swap(a, b);
+  }
+  return a;
+}
 
 extern "C" {
 
@@ -203,7 +282,7 @@ int blah2hip_spectrum_create(uint32_t n_samples, double bandwidth, int device, u
   const uint32_t nS = n_samples / D;                             // :17
   // the kept bins come from a direct nS-point DFT (nS ~ bandwidth in Hz / 1, 2000 in the reference's configs): quadratic, so
   // bounded where it would take seconds
-  if (nS > 65536) SFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nSpectrum > 65536");
+  if (nS > (1u << 26)) SFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nSpectrum > 2^26 (the chirp-z buffers: 3 x 2^28 bytes per CPI)");
   int count = 0;
   SHIP(hipGetDeviceCount(&count));
   if (device < 0 || device >= count) SFAIL(BLAH2HIP_ERR_NO_DEVICE, "no such HIP device");
@@ -229,6 +308,37 @@ int blah2hip_spectrum_create(uint32_t n_samples, double bandwidth, int device, u
   std::vector<dcx> wD(D), wS(nS);
   for (uint32_t m = 0; m < D; m++) { wD[m].x = std::cos(-2.0 * M_PI * (double)m / D); wD[m].y = std::sin(-2.0 * M_PI * (double)m / D); }
   for (uint32_t m = 0; m < nS; m++) { wS[m].x = std::cos(-2.0 * M_PI * (double)m / nS); wS[m].y = std::sin(-2.0 * M_PI * (double)m / nS); }
+  if (nS > DIRECT_MAX) { // chirp-z: the chirp, the transform's root table, and the kernel spectrum (formed below, on the device)
+    h->M = 1;
+    while (h->M < 2 * nS - 1) h->M <<= 1;
+    const uint32_t M = h->M;
+    std::vector<dcx> ch(nS), btw(M / 2), kb(M);
+    for (uint32_t p = 0; p < nS; p++) {
+      const uint64_t q = ((uint64_t)p * p) % (2ull * nS); // exp(-i pi p^2 / nS) has period 2 nS in p^2
+      ch[p].x = std::cos(-M_PI * (double)q / nS); ch[p].y = std::sin(-M_PI * (double)q / nS);
+    }
+    for (uint32_t k = 0; k < M / 2; k++) { btw[k].x = std::cos(-2.0 * M_PI * (double)k / M); btw[k].y = std::sin(-2.0 * M_PI * (double)k / M); }
+    for (auto &v : kb) v.x = v.y = 0.0;
+    for (uint32_t p = 0; p < nS; p++) { // conj chirp, wrapped: index p and M - p
+      kb[p].x = ch[p].x; kb[p].y = -ch[p].y;
+      if (p) { kb[M - p].x = ch[p].x; kb[M - p].y = -ch[p].y; }
+    }
+    SHIP(hipMalloc(&h->d_chirp, nS * sizeof(dcx)));
+    SHIP(hipMalloc(&h->d_btw, (M / 2) * sizeof(dcx)));
+    SHIP(hipMalloc(&h->d_kspec, (size_t)M * sizeof(dcx)));
+    SHIP(hipMalloc(&h->d_ba, (size_t)max_batch * M * sizeof(dcx)));
+    SHIP(hipMalloc(&h->d_bb, (size_t)max_batch * M * sizeof(dcx)));
+    SHIP(hipMemcpy(h->d_chirp, ch.data(), nS * sizeof(dcx), hipMemcpyHostToDevice));
+    SHIP(hipMemcpy(h->d_btw, btw.data(), (M / 2) * sizeof(dcx), hipMemcpyHostToDevice));
+    SHIP(hipMemcpy(h->d_ba, kb.data(), (size_t)M * sizeof(dcx), hipMemcpyHostToDevice));
+    dcx *res = blu_transform<false>(h, h->d_ba, h->d_bb, 1, h->stream);
+    SHIP(hipGetLastError());
+    SHIP(hipStreamSynchronize(h->stream));
+    std::vector<dcx> ks(M);
+    SHIP(hipMemcpy(ks.data(), res, (size_t)M * sizeof(dcx), hipMemcpyDeviceToHost));
+    for (auto &v : ks) { v.x /= (double)M; v.y /= (double)M; } // the inverse below is unnormalised
+    SHIP(hipMemcpy(h->d_kspec, ks.data(), (size_t)M * sizeof(dcx), hipMemcpyHostToDevice));
+  }
   SHIP(hipMalloc(&h->d_wD, D * sizeof(dcx)));
   SHIP(hipMalloc(&h->d_wS, nS * sizeof(dcx)));
   SHIP(hipMalloc(&h->d_part, (size_t)max_batch * h->nJ * nS * sizeof(dcx)));
@@ -257,6 +367,8 @@ int blah2hip_spectrum_destroy(blah2hip_spectrum_t h)
   (void)hipFree(h->d_part);
   (void)hipFree(h->d_out);
   (void)hipFree(h->d_u);
+  for (dcx *p : {h->d_chirp, h->d_kspec, h->d_btw, h->d_ba, h->d_bb})
+    if (p) (void)hipFree(p);
   if (h->d_stage) (void)hipFree(h->d_stage);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -314,6 +426,20 @@ int blah2hip_spectrum_process_dev(blah2hip_spectrum_t h, int fmt, const void *d_
   }
   SHIP(hipGetLastError());
   hipLaunchKernelGGL(spectrum_reduce_kernel, dim3((h->nS + 255) / 256, n_cpi), dim3(256), 0, st, a);
+  if (h->nS > DIRECT_MAX) {
+    BluArgs g;
+    g.u = h->d_u; g.chirp = h->d_chirp; g.kspec = h->d_kspec; g.tw = h->d_btw; g.a = h->d_ba; g.b = h->d_bb;
+    g.out = reinterpret_cast<dcx *>(d_out); g.nS = h->nS; g.M = h->M; g.hq = h->hq;
+    const dim3 gm(std::min<uint32_t>((h->M + 255) / 256, 4096), n_cpi);
+    hipLaunchKernelGGL(blu_load_kernel, gm, dim3(256), 0, st, g);
+    dcx *f = blu_transform<false>(h, h->d_ba, h->d_bb, n_cpi, st);
+    dcx *other = f == h->d_ba ? h->d_bb : h->d_ba;
+    hipLaunchKernelGGL(blu_mul_kernel, gm, dim3(256), 0, st, f, h->d_kspec, h->M);
+    dcx *conv = blu_transform<true>(h, f, other, n_cpi, st);
+    hipLaunchKernelGGL(blu_store_kernel, gm, dim3(256), 0, st, g, (const dcx *)conv);
+    SHIP(hipGetLastError());
+    return BLAH2HIP_OK;
+  }
   const dim3 dgrid((h->nS + DFT_BINS - 1) / DFT_BINS, n_cpi);
   if (h->nS <= 4096) hipLaunchKernelGGL(spectrum_dft_kernel<true>, dgrid, dim3(DFT_SLICES * DFT_BINS), 2 * (size_t)h->nS * sizeof(dcx), st, a);
   else hipLaunchKernelGGL(spectrum_dft_kernel<false>, dgrid, dim3(DFT_SLICES * DFT_BINS), 0, st, a);

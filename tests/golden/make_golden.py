@@ -49,6 +49,9 @@ CASES = {
     # path 58 dB above it (0.8 x 1000), one target 40 dB under the direct path.  After WienerHopf::process the channel is
     # 800 x smaller than what the filter subtracted: the case where fp32 `y - w*x` is nearest the 1e-4 gate
     "deep_cancel": (1_000_000, 100_000, -10, 100, -100, 100, True, 26, ((37, -63.0, 0.008),), (-10, 100)),
+    # round 6: 9011 delay bins -- more than blah2hip_cfar1d_map's fp64 row used to fit (8192); delays beyond nCorr = 6000 read the
+    # reference's aliased lags (Ambiguity.cpp:132-146), no Hamming rounding as in `aliased_lags`
+    "wide_delay": (30_000, 30_000, -10, 9000, -2, 2, False, 28, ((5000, 1.0, 0.05), (23, -1.0, 0.05)), (-3, 20)),
 }
 # name -> synth_iq keyword overrides (amplitudes); everything else uses the generator's defaults
 SYNTH_KW = {"deep_cancel": dict(ref_amp=1000.0, noise_amp=1.0, direct=0.8)}
@@ -59,8 +62,11 @@ SPECTRUM_CASES = {
     "even_decimation_odd_bins": (45_122, 2000.0, 23), # D = 22, nS = 2051: bins congruent to D/2+1 mod D
     "small": (5_000, 400.0, 24),                       # D = 12, nS = 416
     "wide": (70_000, 20_000.0, 25),                    # D = 3, nS = 23333 (round 3: more bins than the on-chip tables hold)
+    "beyond_direct_dft": (140_001, 70_000.0, 27),      # D = 2, nS = 70000 > 65536 (round 6: the chirp-z path; nfft = 140000)
 }
-DET = dict(pfa=1e-5, n_guard=2, n_train=6, min_delay=5, min_doppler=15.0, n_centroid=6)
+DET0 = dict(pfa=1e-5, n_guard=2, n_train=6, min_delay=5, min_doppler=15.0, n_centroid=6)
+# name -> detector overrides (recorded in the fixture's det_params): `wide_delay` has five Doppler rows within +-2 Hz
+DET_KW = {"wide_delay": dict(pfa=1e-3, min_doppler=0.5)}
 
 
 def main():
@@ -70,6 +76,7 @@ def main():
     for name, (fs, n, dmin, dmax, fmin, fmax, rh, seed, targets, clut) in CASES.items():
         if only and name not in only:
             continue
+        DET = dict(DET0, **DET_KW.get(name, {}))
         x, y = O.synth_iq(n, seed=seed, fs=fs, targets=targets, **SYNTH_KW.get(name, {}))
         iq = np.empty((n, 4), dtype=np.int16)
         iq[:, 0], iq[:, 1], iq[:, 2], iq[:, 3] = x.real, x.imag, y.real, y.imag
@@ -113,7 +120,7 @@ def main():
         if only and name not in only:
             continue
         x, _ = O.synth_iq(n, seed=seed, fs=2_000_000)
-        spec, n_freq = R.spectrum(x, n, bw)
+        spec, n_freq = R.spectrum(x, n, bw, cap=1 << 18)
         iq = np.empty((n, 2), dtype=np.int16)
         iq[:, 0], iq[:, 1] = x.real, x.imag
         out = os.path.join(HERE, "spectrum", name + ".npz")

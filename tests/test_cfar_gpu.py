@@ -230,3 +230,37 @@ def test_python_detector_follows_the_map_it_is_given(b2):
     assert not m2.device_copy_is_current()
     d2 = det.process(m2)
     assert (float(m2.delay[j]), float(m2.doppler[i])) in set(zip(d2.get_delay(), d2.get_doppler()))
+
+
+def test_host_map_with_more_than_8192_delay_bins(b2):
+    """blah2hip_cfar1d_map on a caller-held map of 9011 delay bins (round 6: it refused above 8192; CfarDetector1D.cpp:23-100
+    has no such bound).  `wide_delay`: the reference's own list on its own map; the same map changed by the caller and
+    handed back goes through the host-map entry, and so does a 20 000-bin row, which no longer fits the LDS as fp64 and is
+    evaluated straight from memory -- against the oracle."""
+    g = load_golden("wide_delay")
+    fs, n, dmin, dmax, fmin, fmax, rh = (int(v) for v in g["params"])
+    pfa, ng, nt, md, mdop = g["det_params"][:5]
+    det = b2.CfarDetector1D(pfa, int(ng), int(nt), int(md), mdop)
+    amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, bool(rh))
+    m = amb.process(g["x"], g["y"])
+    assert m.data.shape == (5, 9011)
+    d_dev = det.process(m)                       # the engine's device copy
+    check_detections(amb, d_dev, g["map"], g["metrics"][0], pfa, int(ng), int(nt), int(md), mdop, m)
+    assert np.array_equal(d_dev.get_delay(), g["cfar"][0]) and np.array_equal(d_dev.get_doppler(), g["cfar"][1])
+    m.data[0, 0] *= 2                            # touched by the caller (column 0 never trains, delay -10 is below minDelay: the
+    assert not m.device_copy_is_current()        # list cannot change): evaluated as given, through blah2hip_cfar1d_map
+    d_host = det.process(m)
+    assert np.array_equal(d_host.get_delay(), d_dev.get_delay()) and np.array_equal(d_host.get_doppler(), d_dev.get_doppler())
+    # a row beyond the LDS: 20 000 bins, synthetic cells, the unstaged kernel
+    rng = np.random.default_rng(8)
+    nD, nC = 3, 20_000
+    cells = (rng.standard_normal((nD, nC)) + 1j * rng.standard_normal((nD, nC))).astype(np.complex64)
+    cells[1, 12_345] = 40.0
+    delay = np.arange(-5, nC - 5)
+    doppler = np.array([-1.0, 0.0, 1.0])
+    noise, _ = O.map_metrics(cells.astype(np.complex128))
+    big = b2.Map(None, cells, delay, doppler, noise, 0.0, 0)
+    d_big = b2.CfarDetector1D(1e-4, 2, 8, 0, 0.5).process(big)
+    dl, dp, _ = O.cfar1d_fast(cells.astype(np.complex128), delay, doppler, noise, 1e-4, 2, 8, 0, 0.5)
+    assert set(zip(d_big.get_delay(), d_big.get_doppler())) == set(zip(dl, dp)) and (12_340.0, 1.0) not in set(zip(dl, dp))
+    assert (float(delay[12_345]), 0.0) not in set(zip(dl, dp))  # the zero-Doppler row is below minDoppler

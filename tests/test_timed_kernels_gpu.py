@@ -369,16 +369,28 @@ def test_four_column_kernel_finishes_the_metrics_itself_launch_after_launch(b2):
 @pytest.mark.parametrize("geom,fmt,B", [(CFG2, "c32", 1), (CFG2, "i16", 2),
                                         ((-10, 89, -100, 100, 1_000_000, 603_000), "c32", 2),    # 4 segments of 750: every x load, 7 outputs
                                         ((-7, 492, -50, 50, 155_540, 155_540), "c32", 1),         # 500 lags: all 16 outputs
-                                        ((1, 299, -100, 100, 1_000_000, 777_001), "i16", 3)])     # ragged pulse, first lag positive
+                                        ((1, 299, -100, 100, 1_000_000, 777_001), "i16", 3),      # ragged pulse, first lag positive
+                                        ((-10, 400, -50, 50, 800_000, 100_000), "c32", 1)])       # 13 segments: more than three per wave
 def test_pulse_per_workgroup_range_kernel(b2, geom, fmt, B):
-    """rangeps_kernel (F = 1024, small launches): a workgroup per pulse, a wave per segment, the products summed and
-    inverted by the eighth wave -- forced, on the cfg 2 shape (seven segments of 576, pruned x', seven outputs), with
-    fewer and longer segments, with more than 448 lags, on a ragged geometry and on the int16 wire format; every CPI
-    against the oracle.  A lone CPI at cfg 2 is 513 pulses on 512 resident workgroups: one workgroup takes two."""
+    """rangeps_kernel (F = 1024, small launches): a workgroup of FOUR waves per pulse, wave q walking segments q, q + 4, ...
+    with its partial sum in registers; the four sums meet in LDS and the last wave inverts -- forced, on the cfg 2 shape
+    (seven segments of 557, pruned x', seven outputs), with fewer and longer segments, with more than 448 lags, on a ragged
+    geometry, on the int16 wire format, and with thirteen segments (four passes of the walk: the automatic choice stops at
+    eight, use_ps_range in csrc/capi.hip); every CPI against the oracle."""
     from blah2_amd import _lib
     amb = run_batch(b2, geom, B, "auto", seeds=range(400, 400 + B), fmt=fmt, fft_len=1024, range_kernel=_lib.RANGE_PS,
                     expect=None if B > 3 else _expected_small(geom, B), targets=((37, -13.0, 0.05),))
-    assert amb.dims.fft_len == 1024 and amb.dims.n_seg <= 7 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_PS
+    assert amb.dims.fft_len == 1024 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_PS
+    assert amb.dims.n_seg == 13 if geom[5] == 100_000 else amb.dims.n_seg <= 7
+
+
+def test_automatic_choice_leaves_long_walks_to_the_eight_point_kernel(b2):
+    """Thirteen segments per pulse on a lone CPI: use_ps_range's automatic branch stops at two segments per wave (the shape
+    its timings and the planner's cost factor cover), so the launch runs range8_kernel."""
+    from blah2_amd import _lib
+    geom = (-10, 400, -50, 50, 800_000, 100_000)
+    amb = run_batch(b2, geom, 1, "auto", seeds=(431,), fft_len=1024, expect=_expected_small(geom, 1), targets=((37, -13.0, 0.05),))
+    assert amb.dims.n_seg == 13 and amb.info(_lib.INFO_LAST_RANGE_KERNEL) == _lib.RANGE_E8
 
 
 def _expected_small(geom, B):

@@ -9,7 +9,11 @@ which the 256 MB Infinity Cache holds, read 32 times; the filtered plane written
 barriers and instruction streams are identical -- only the DRAM traffic is gone.  Per-kernel HIP-event times beside the
 normal run on the same box.
 
-    gpurun -- 'python tools/gpu_cfg3_bytes.py --json gpurun_out/cfg3_bytes.json'
+The product library rejects a CPI stride of 0 (blah2hip_amb_process_dev: "cpi_stride < samples used per CPI"); the
+check is compiled out only under -DB2_EXPERIMENT_ALIASED_CPIS.  Build that variant beside the product library and select it:
+
+    bash tools/build_variant.sh aliased -DB2_EXPERIMENT_ALIASED_CPIS
+    gpurun -- 'BLAH2HIP_LIBRARY=$PWD/tools/ab/libblah2hip_aliased.so python tools/gpu_cfg3_bytes.py --json gpurun_out/cfg3_bytes.json'
 """
 import argparse
 import json
@@ -29,6 +33,10 @@ def main():
     import torch
 
     import blah2_amd as b2
+    if "aliased" not in os.path.basename(os.environ.get("BLAH2HIP_LIBRARY", "")):
+        raise SystemExit("tools/gpu_cfg3_bytes.py needs the -DB2_EXPERIMENT_ALIASED_CPIS build of the library: "
+                         "bash tools/build_variant.sh aliased -DB2_EXPERIMENT_ALIASED_CPIS, then "
+                         "BLAH2HIP_LIBRARY=$PWD/tools/ab/libblah2hip_aliased.so (the product library refuses a CPI stride of 0)")
     dmin, dmax, fmin, fmax, fs, n = (-24, 2023, -512, 512, 10_000_000, 10_000_000)
     B = a.batch
     dev = torch.device("cuda", 0)
