@@ -598,13 +598,14 @@ def _measure(a, env, handles):
                   "oracle": "oracle/blah2_oracle.py (fp64 NumPy restatement of Ambiguity.cpp:92-172, Map.cpp:187-206"
                             + (", WienerHopf.cpp:58-163, CfarDetector1D.cpp:23-100)" if a.chain == "full" else ")")
                             + "; gates: oracle/gates.py",
-                  "gates": {"peak_rel": GATE_PEAK_REL if a.chain != "full" else G.CELL_TOL, "cell_rel_above_mean": G.CELL_TOL,
+                  "gates": {"peak_rel": GATE_PEAK_REL if a.chain != "full" else G.CELL_TOL,
+                            ("cell_rel_above_mean" if a.chain != "full" else "cell_rel_above_mean_outside_notch"): G.CELL_TOL,
                             "db_max": GATE_DB_MAP, "db_floor_below_mean_level": DB_FLOOR,
                             "metrics_db": GATE_METRICS_DB, "chain_err_over_direct_path": GATE_CHAIN_DIRECT,
                             "detections": f"identical up to cells whose threshold margin is within {G.MARGIN_K:g} x the measured map error of 1",
                             "notch_abs_err_over_mean_level": G.NOTCH_ABS}}
-        for key in ("peak_rel", "cell_rel_above_mean", "db_max", "metrics_db", "chain_err_over_direct_path",
-                    "notch_db_max", "notch_abs_err_over_mean_level"):
+        for key in ("peak_rel", "cell_rel_above_mean", "cell_rel_above_mean_outside_notch", "db_max", "metrics_db",
+                    "chain_err_over_direct_path", "notch_db_max", "notch_abs_err_over_mean_level"):
             vals = [c_[key] for c_ in checks if c_.get(key) is not None]
             if vals:
                 parity[key] = max(vals)
@@ -717,7 +718,7 @@ def config_legs(a, env):
                         "chain_frac": rl["chain_frac"],  # B_amb over the time of the whole chain, against 8 TB/s
                         "dominant_kernel": dom, "kernels": ks,
                         "parity": None if par is None else {k: par[k] for k in (
-                            "pass", "peak_rel", "cell_rel_above_mean", "db_max", "metrics_db", "chain_err_over_direct_path",
+                            "pass", "peak_rel", "cell_rel_above_mean", "cell_rel_above_mean_outside_notch", "db_max", "metrics_db", "chain_err_over_direct_path",
                             "detections_ok", "filter_ok", "detections", "notch_db_max", "notch_abs_err_over_mean_level") if k in par},
                         "leg_wall_s": time.perf_counter() - t0})
         except Exception as e:

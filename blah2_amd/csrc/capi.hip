@@ -119,6 +119,11 @@ struct blah2hip_amb_s {
 
   KernelTimer<BLAH2HIP_K_COUNT> timer;
 
+  // the clutter filter's FIR fused into the range correlation (blah2hip_amb_set_fir): the filter handle's taps
+  const cf *firW = nullptr; // [max_batch][firBins]; nullptr: the plain range kernels
+  int firBins = 0, firDmin = 0;
+  cf *d_H = nullptr;        // [max_batch][16][256]: the taps' spectrum in the transform's register layout (taps_spectrum_kernel)
+
   // Fixed-pattern leak compensation (see leak_calibrate): per (range kernel, Doppler kernel) the lags of the zero-Doppler row
   // into which the fp32 transform chain leaks a fixed fraction g of the lag-0 cell, measured once on a synthetic CPI
   struct LeakCal { int nLags = 0; double maxAbs = 0.0; bool active = false; int32_t *d_lag = nullptr; cf *d_g = nullptr; };
@@ -1005,7 +1010,7 @@ int blah2hip_amb_destroy(blah2hip_amb_t h)
                   (void *)h->d_partSum, (void *)h->d_partMax, (void *)h->d_tickets, (void *)h->d_metrics,
                   (void *)h->d_doppler, h->d_in, (void *)h->d_rot,
                   (void *)h->d_hits, (void *)h->d_count, (void *)h->d_sat, (void *)h->d_dtw, (void *)h->d_chirp,
-                  (void *)h->d_bf, (void *)h->d_bfn})
+                  (void *)h->d_bf, (void *)h->d_bfn, (void *)h->d_H})
     if (p) (void)hipFree(p);
   for (auto &t : h->alphaTables)
     if (t.d) (void)hipFree(t.d);
@@ -1097,6 +1102,16 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
   }
 }
 
+int blah2hip_amb_set_fir(blah2hip_amb_t h, const float *d_w, uint32_t n_bins, int32_t clutter_delay_min)
+{
+  if (!h) return fail(BLAH2HIP_ERR_INVALID, "NULL handle");
+  if (d_w && n_bins == 0) return fail(BLAH2HIP_ERR_INVALID, "no taps");
+  h->firW = reinterpret_cast<const cf *>(d_w);
+  h->firBins = (int)n_bins;
+  h->firDmin = clutter_delay_min;
+  return BLAH2HIP_OK;
+}
+
 int blah2hip_amb_get_info(blah2hip_amb_t h, int key, int64_t *value)
 {
   if (!h || !value) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
@@ -1132,9 +1147,24 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   cf *map = d_map ? (cf *)d_map : h->d_map;
   double *met = d_metrics ? d_metrics : h->d_metrics;
 
+  // FIR fused into the range kernel: what one 4096-point transform covers (include/blah2hip.h)
+  const bool fused = h->firW != nullptr && !h->inLeakCal;
+  if (fused) {
+    const int L = 2048;
+    if (h->dims.fft_len != 4096) return fail(BLAH2HIP_ERR_UNSUPPORTED, "fused FIR: the handle's transform length must be 4096 (BLAH2HIP_OPT_FFT_LEN)");
+    if (fmt != BLAH2HIP_FMT_C32 && fmt != BLAH2HIP_FMT_I16) return fail(BLAH2HIP_ERR_UNSUPPORTED, "fused FIR: fp32 planes or int16 words");
+    if (h->chunks.size() != 1 || h->dopplerMin + h->dopplerMax != 0) return fail(BLAH2HIP_ERR_UNSUPPORTED, "fused FIR: one lag chunk, symmetric Doppler limits");
+    if (h->firBins > L + 1 || (int)nDelay > L + 1) return fail(BLAH2HIP_ERR_UNSUPPORTED, "fused FIR: at most 2049 taps and 2049 delay bins");
+    if (h->firDmin != h->delayMin || h->delayMin > 0) return fail(BLAH2HIP_ERR_UNSUPPORTED, "fused FIR: the filter's first lag must equal the map's and be <= 0");
+    if ((int)h->dims.n_corr < L - h->delayMin) return fail(BLAH2HIP_ERR_UNSUPPORTED, "fused FIR: pulses shorter than 2048 - delayMin samples");
+    if ((uint64_t)h->dims.n_used + (uint64_t)(-h->delayMin) > h->dims.n_samples)
+      return fail(BLAH2HIP_ERR_UNSUPPORTED, "fused FIR: the filter's look-ahead past the last pulse wraps around the CPI");
+    if (n_cpi > 1 && cpi_stride < h->dims.n_samples) return fail(BLAH2HIP_ERR_INVALID, "fused FIR: cpi_stride < nSamples");
+    if (!h->d_H) HIPCHK(hipMalloc(&h->d_H, (size_t)h->dims.max_batch * 16 * 256 * sizeof(cf)));
+  }
   // the fixed-pattern leak of the kernel pair this launch will run (calibrated at the pair's first launch)
   const blah2hip_amb_s::LeakCal *leak = nullptr;
-  if (h->leakMode != 0 && !h->inLeakCal) {
+  if (h->leakMode != 0 && !h->inLeakCal && !fused) { // (behind the filter the lag-0 column holds no peak to leak)
     const int rid = predict_range(h, (int)(n_cpi * nD)), did = pick_doppler(h, n_cpi);
     auto it = h->leak.find(rid * 64 + did);
     if (it == h->leak.end()) {
@@ -1193,6 +1223,30 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
       ra.plan.delayMin = ck.lag0; ra.plan.nDelay = ck.count; ra.plan.colOff = ck.col0;
       if ((rc = launch_range(h, ra, in2, st))) return rc;
     }
+    if ((rc = toc(h, BLAH2HIP_K_RANGE, st))) return rc;
+  } else if (fused) {
+    if ((rc = tic(h, BLAH2HIP_K_RANGE, st))) return rc;
+    using W = WgFft<16>;
+    const size_t lds = (size_t)(W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
+    LDSCFG(taps_spectrum_kernel, lds);
+    hipLaunchKernelGGL(taps_spectrum_kernel, dim3(n_cpi), dim3(256), lds, st, h->firW, h->firBins, h->d_tw, h->d_H);
+    RangeFirArgs fa;
+    fa.plan = h->plan;
+    fa.plan.delayMin = h->chunks[0].lag0; fa.plan.nDelay = h->chunks[0].count; fa.plan.colOff = h->chunks[0].col0;
+    fa.tw = h->d_tw; fa.out = h->d_R; fa.cpiStride = (int64_t)cpi_stride; fa.nPulses = (int32_t)(n_cpi * nD);
+    fa.H = h->d_H; fa.N = h->dims.n_samples;
+    const int grid = std::min<int>(fa.nPulses, range_grid_cap(h, lds, 4, 8));
+    if (fmt == BLAH2HIP_FMT_C32) {
+      InC32 in{(const cf *)d_x, (const cf *)d_y};
+      LDSCFG(range_fir_kernel<InC32>, lds);
+      hipLaunchKernelGGL(range_fir_kernel<InC32>, dim3(grid), dim3(256), lds, st, fa, in);
+    } else {
+      InI16 in{(const int16_t *)d_x};
+      LDSCFG(range_fir_kernel<InI16>, lds);
+      hipLaunchKernelGGL(range_fir_kernel<InI16>, dim3(grid), dim3(256), lds, st, fa, in);
+    }
+    HIPCHK(hipGetLastError());
+    h->lastRange = BLAH2HIP_RANGE_FIR;
     if ((rc = toc(h, BLAH2HIP_K_RANGE, st))) return rc;
   } else {
     if ((rc = tic(h, BLAH2HIP_K_RANGE, st))) return rc;

@@ -1036,10 +1036,12 @@ template <int R3, class In> int launch_clutter(blah2hip_clutter_s *h, const void
   fa.nBins = h->nBins; fa.segLen = h->segLen; fa.nSeg = h->nSeg; fa.w = h->d_w; fa.ok = ok; fa.tw = h->d_tw;
   fa.scale = 1.0f / (float)h->F;
   fa.carry = h->firCarry ? 1 : 0;
-  CHIP(h->timer.tic(BLAH2HIP_CK_FIR, st));
-  hipLaunchKernelGGL((clutter_fir_kernel<R3, In>), dim3(firGrid, nCpi), dim3(W::T), lds, st, fa);
-  CHIP(hipGetLastError());
-  CHIP(h->timer.toc(BLAH2HIP_CK_FIR, st));
+  if (yout) { // nullptr: the taps only (blah2hip_clutter_estimate_dev_fmt: the FIR runs fused into the range kernel)
+    CHIP(h->timer.tic(BLAH2HIP_CK_FIR, st));
+    hipLaunchKernelGGL((clutter_fir_kernel<R3, In>), dim3(firGrid, nCpi), dim3(W::T), lds, st, fa);
+    CHIP(hipGetLastError());
+    CHIP(h->timer.toc(BLAH2HIP_CK_FIR, st));
+  }
   h->lastOk = ok;
   h->lastStream = st;
   return BLAH2HIP_OK;
@@ -1298,6 +1300,41 @@ int blah2hip_clutter_process_dev_fmt(blah2hip_clutter_t h, int fmt, const void *
   case 8: return launch_clutter<8, InC32>(h, d_x, d_y, n_cpi, cs, yo, os, ok, st);
   default: return launch_clutter<16, InC32>(h, d_x, d_y, n_cpi, cs, yo, os, ok, st);
   }
+}
+
+int blah2hip_clutter_estimate_dev_fmt(blah2hip_clutter_t h, int fmt, const void *d_x, const void *d_y, uint32_t n_cpi,
+                                      uint64_t cpi_stride, int32_t *d_ok, void *stream)
+{
+  if (!h || !d_x) CFAIL(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (fmt != BLAH2HIP_FMT_C32 && fmt != BLAH2HIP_FMT_I16) CFAIL(BLAH2HIP_ERR_INVALID, "clutter filter input: BLAH2HIP_FMT_C32 or BLAH2HIP_FMT_I16");
+  if (fmt == BLAH2HIP_FMT_C32 && !d_y) CFAIL(BLAH2HIP_ERR_INVALID, "NULL argument");
+  if (n_cpi == 0 || n_cpi > h->maxBatch) CFAIL(BLAH2HIP_ERR_INVALID, "n_cpi outside [1, max_batch]");
+  if (n_cpi > 1 && cpi_stride < h->N) CFAIL(BLAH2HIP_ERR_INVALID, "cpi_stride < nSamples");
+  CHIP(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  int32_t *ok = d_ok ? d_ok : h->d_ok;
+  const int64_t cs = (int64_t)cpi_stride;
+  if (fmt == BLAH2HIP_FMT_I16) {
+    switch (h->r3) {
+    case 4: return launch_clutter<4, InI16>(h, d_x, nullptr, n_cpi, cs, nullptr, 0, ok, st);
+    case 8: return launch_clutter<8, InI16>(h, d_x, nullptr, n_cpi, cs, nullptr, 0, ok, st);
+    default: return launch_clutter<16, InI16>(h, d_x, nullptr, n_cpi, cs, nullptr, 0, ok, st);
+    }
+  }
+  switch (h->r3) {
+  case 4: return launch_clutter<4, InC32>(h, d_x, d_y, n_cpi, cs, nullptr, 0, ok, st);
+  case 8: return launch_clutter<8, InC32>(h, d_x, d_y, n_cpi, cs, nullptr, 0, ok, st);
+  default: return launch_clutter<16, InC32>(h, d_x, d_y, n_cpi, cs, nullptr, 0, ok, st);
+  }
+}
+
+int blah2hip_clutter_taps_dev(blah2hip_clutter_t h, const float **d_w, uint32_t *n_bins, int32_t *delay_min)
+{
+  if (!h) CFAIL(BLAH2HIP_ERR_INVALID, "NULL handle");
+  if (d_w) *d_w = reinterpret_cast<const float *>(h->d_w);
+  if (n_bins) *n_bins = (uint32_t)h->nBins;
+  if (delay_min) *delay_min = h->delayMin;
+  return BLAH2HIP_OK;
 }
 
 int blah2hip_clutter_process_dev(blah2hip_clutter_t h, const void *d_x, const void *d_y, uint32_t n_cpi,

@@ -163,6 +163,200 @@ __global__ __launch_bounds__(16 * R3, 2) void range_kernel(RangeArgs a, In in)
 }
 
 // --------------------------------------------------------------------------
+// FUSED clutter FIR + range correlation at F = 4096 (round 6; WienerHopf.cpp:124-160 feeding Ambiguity.cpp:106-149 without
+// the filtered channel ever crossing HBM).  tools/proto/fir_range_fusion_model.py is this kernel's transform sequence in
+// NumPy, exact against the two-stage path.  A pulse is cut into segments of L = F/2 reference samples on the PULSE's own
+// grid; with X_g the transform of the zero-padded segment g and H the taps' spectrum,
+//     the window [segment g-1 | segment g]  has the spectrum  X_(g-1) + (-1)^m X_g                 (a shift by F/2 is a sign)
+//     (w * xs) on the L samples that start at  g L + delayMin  = the last L outputs of IFFT(H (X_(g-1) + (-1)^m X_g))
+// (xs[i] = x[i - delayMin]: the filter's own shift moves its OUTPUT grid, not the segments), and with the clutter window's
+// first lag equal to the map's (config.yml; the launcher checks) the correlation's y' window of segment g is exactly the
+// filter's output blocks g and g + 1: register for register, no exchange.  So ONE forward transform per segment serves the
+// filter's window spectrum AND the correlation's x': per pulse 1 (history block) + S + S (filter inverses) + S (y' forward)
+// + 1 (correlation inverse) + 1 (the ragged last segment twice: masked to the pulse for the correlation, with the filter's
+// |delayMin| samples of look-ahead for the filter) = 3 S + 3 transforms -- 18 at configs[2] where clutter_fir_kernel +
+// range_kernel run 20.5 -- and x, y are read once: 177 instead of 417 MB per CPI.  Registers: previous and current
+// segment spectrum, accumulator, one work array, the previous output block (4 x 32 + 16) + the twiddles (62).
+// Requirements (launcher): F = 4096, nBins <= L + 1, nDelay <= L + 1, clutter delayMin == map delayMin <= 0,
+// nCorr >= L - delayMin, the CPI's last used sample + |delayMin| inside the CPI (no circular wrap of xs in reach).
+struct RangeFirArgs {
+  RangePlan plan;
+  const cf *tw;       // exp(-2 pi i k / F)
+  cf *out;            // tiled range map
+  int64_t cpiStride;
+  int32_t nPulses;
+  const cf *H;        // [nCpi][16][256]: the taps' spectrum / F in the transform's register layout (taps_spectrum_kernel)
+  uint32_t N;         // samples per CPI
+};
+
+// grid nCpi x 256: H[cpi][e][t] = register e of thread t of FFT_4096(w zero-padded) / F
+__global__ __launch_bounds__(256) void taps_spectrum_kernel(const cf *w, int nBins, const cf *tw, cf *H)
+{
+  using W = WgFft<16>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf *P = reinterpret_cast<cf *>(smem);
+  cf *Q = P + W::A_ELEMS;
+  const int t = threadIdx.x, cpi = blockIdx.x;
+  cf tw1[15], tw3[16];
+  W::load_twiddles(t, tw, tw1, tw3);
+  cf v[16];
+  const float sc = 1.0f / (float)W::F;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int m = t + 256 * k;
+    const cf x = w[(size_t)cpi * nBins + min(m, nBins - 1)];
+    v[k] = m < nBins ? cmake(x.x * sc, x.y * sc) : cmake(0.f, 0.f);
+  }
+  W::fwd_s1(t, v, tw1, P);
+  __syncthreads();
+  W::fwd_s2(t, v, P, Q);
+  __syncthreads();
+  W::fwd_s3(t, v, tw3, Q);
+#pragma unroll
+  for (int e = 0; e < 16; e++) H[((size_t)cpi * 16 + e) * 256 + t] = v[e];
+}
+
+template <class In>
+__global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in)
+{
+  using W = WgFft<16>;
+  using CX = typename BufLoad<In>::X;
+  using CY = typename BufLoad<In>::Y;
+  using RX = RawBuiltin<CX>;
+  using RY = RawBuiltin<CY>;
+  constexpr int T = 256, L = 2048;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf *P = reinterpret_cast<cf *>(smem);
+  cf *Q = P + W::A_ELEMS;
+  const int t = threadIdx.x;
+  cf tw1[15], tw3[16];
+  W::load_twiddles(t, a.tw, tw1, tw3);
+  const float sgn = ((t >> 4) & 1) ? -1.f : 1.f; // (-1)^m of this thread's spectrum registers (m = q + 16 r + 256 s, q = t >> 4)
+  const RangePlan p = a.plan;
+  const int dmin = p.delayMin; // = the clutter window's first lag (launcher), <= 0
+  const int S = (p.nCorr + L - 1) / L;
+  auto fwd = [&](cf *v) {
+    W::fwd_s1(t, v, tw1, P);
+    __syncthreads();
+    W::fwd_s2(t, v, P, Q);
+    __syncthreads();
+    W::fwd_s3(t, v, tw3, Q);
+    __syncthreads();
+  };
+  auto fwd_half = [&](cf *v) { // inputs v[8..15] are zero
+    W::fwd_s1_nz9(t, v, tw1, P);
+    __syncthreads();
+    W::fwd_s2(t, v, P, Q);
+    __syncthreads();
+    W::fwd_s3(t, v, tw3, Q);
+    __syncthreads();
+  };
+  for (int pulse = blockIdx.x; pulse < a.nPulses; pulse += gridDim.x) {
+    const int cpi = pulse / p.nDoppler;
+    const int i = pulse - cpi * p.nDoppler;
+    const int p0 = i * p.nCorr;
+    // x of the whole CPI: sample u of the stream at offset u (beyond the CPI: zeros -- out of reach by the launcher's check)
+    const __amdgpu_buffer_rsrc_t xd = make_rsrc_b(BufLoad<In>::xp(in, (int64_t)cpi * a.cpiStride), (int)a.N * CX::STRIDE);
+    // y of this pulse: outside it the range check returns the zeros the correlation's mask wants
+    const __amdgpu_buffer_rsrc_t yd = make_rsrc_b(BufLoad<In>::yp(in, (int64_t)cpi * a.cpiStride + p0), p.nCorr * CY::STRIDE);
+    const cf *Hc = a.H + (size_t)cpi * 16 * 256 + t;
+    cf Xp[16], Xg[16], acc[16], wk[16], yfp[8];
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = cmake(0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; k++) yfp[k] = cmake(0.f, 0.f);
+    // segment u in [u0, u0 + L) of the filter's reference stream: x[u], zero below -delayMin (xs[m < 0] = 0, WienerHopf.cpp:125-160)
+    auto load_seg = [&](cf *v, int u0) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int u = u0 + t + T * k;
+        const cf x = RX::cvt(RX::ld(xd, u * CX::STRIDE, 0));
+        v[k] = u >= -dmin ? x : cmake(0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 8; k < 16; k++) v[k] = cmake(0.f, 0.f);
+    };
+    if (i > 0) { // the history block in front of the pulse (pulse 0: the stream is zero there)
+      load_seg(Xp, p0 - L);
+      fwd_half(Xp);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; e++) Xp[e] = cmake(0.f, 0.f);
+    }
+    // the segment's spectrum as the CORRELATION wants it: x masked to the pulse, the CPI's first samples included.  It is the
+    // filter's variant except for a pulse's ragged last segment (the filter looks |delayMin| samples past the pulse's end)
+    // and pulse 0's first (the filter's stream is zero below -delayMin)
+    auto dual = [&](int g) { return (g + 1) * L > p.nCorr || (i == 0 && g == 0 && dmin < 0); };
+    for (int g = 0; g <= S; g++) {
+      // g < S: segment g -> the filter's spectrum X_g and output block g;  g >= 1: the correlation of segment g - 1, whose
+      // y' window is [block g - 1 | block g] (zeros behind the last block)
+      if (g < S) {
+        typename RY::raw yr[8];
+        load_seg(Xg, p0 + g * L);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          int vo = (g * L + dmin + t + T * k) * CY::STRIDE; // may be negative: the whole offset in the VGPR (bufload.hpp)
+          asm volatile("" : "+v"(vo));
+          yr[k] = RY::ld(yd, vo, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e++) wk[e] = Hc[e * 256];
+        fwd_half(Xg);
+#pragma unroll
+        for (int e = 0; e < 16; e++) wk[e] = cmul(wk[e], cmake(Xp[e].x + sgn * Xg[e].x, Xp[e].y + sgn * Xg[e].y));
+        W::inv_s1(t, wk, tw3, Q);
+        __syncthreads();
+        W::inv_s2(t, wk, Q, P);
+        __syncthreads();
+        W::inv_s3(t, wk, tw1, P);
+        __syncthreads();
+        // the block's L valid outputs are wk[8..15]: sample  g L + delayMin + t + T k  of the pulse
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int nr = g * L + dmin + t + T * k;
+          const cf yv = RY::cvt(yr[k]);
+          wk[8 + k] = (nr >= 0 && nr < p.nCorr) ? csub(yv, wk[8 + k]) : cmake(0.f, 0.f);
+        }
+      } else {
+#pragma unroll
+        for (int k = 8; k < 16; k++) wk[k] = cmake(0.f, 0.f);
+      }
+      if (g >= 1) {
+        if (dual(g - 1)) { // X_(g-1) has served the filter's window: replace it by the correlation's variant
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const int m = (g - 1) * L + t + T * k;
+            const cf x = RX::cvt(RX::ld(xd, (p0 + m) * CX::STRIDE, 0));
+            Xp[k] = m < p.nCorr ? x : cmake(0.f, 0.f);
+          }
+#pragma unroll
+          for (int k = 8; k < 16; k++) Xp[k] = cmake(0.f, 0.f);
+          fwd_half(Xp);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const cf o = yfp[k]; yfp[k] = wk[8 + k]; wk[k] = o; }
+        if (g < S) fwd(wk);
+        else fwd_half(wk);
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[e] = cmacc(acc[e], wk[e], Xp[e]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) yfp[k] = wk[8 + k];
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) Xp[e] = Xg[e];
+    }
+    W::inv_s1(t, acc, tw3, P);
+    __syncthreads();
+    W::inv_s2(t, acc, P, Q);
+    __syncthreads();
+    W::inv_s3(t, acc, tw1, Q);
+    store_lags<16>(a.out, p, cpi, i, t, acc);
+    __syncthreads(); // P, Q are rewritten by the next pulse
+  }
+}
+
+// --------------------------------------------------------------------------
 // Range kernel on the 8-points-per-thread transform (fft_wg8.hpp): identical mathematics and
 // interface, T = F/8 threads per pulse, half the registers per thread (3 waves per SIMD, see RANGE8_WAVES_PER_SIMD).  Stage 4 of
 // the transform runs across lanes (fwd_s3_lanes / inv_s4_lanes), so a transform has two LDS exchanges

@@ -220,6 +220,15 @@ class Ambiguity:
             which = {"auto": _lib.CFAR2D_AUTO, "tile": _lib.CFAR2D_TILE, "sat": _lib.CFAR2D_SAT, "stream": _lib.CFAR2D_STREAM}[which]
         check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_CFAR2D_KERNEL, int(which)))
 
+    def set_fir(self, wiener_hopf):
+        """Run the clutter filter's FIR fused into the range kernel with the taps of ``wiener_hopf`` (a WienerHopf whose
+        ``estimate_dev_fmt`` precedes each ``process_dev`` on the same stream); None: back to the plain range kernels."""
+        if wiener_hopf is None:
+            check(self._L.blah2hip_amb_set_fir(self._h, None, 0, 0))
+        else:
+            p, nb, dm = wiener_hopf.taps_dev()
+            check(self._L.blah2hip_amb_set_fir(self._h, p, nb, dm))
+
     def set_leak_compensation(self, mode):
         """BLAH2HIP_OPT_LEAK_COMPENSATION: "off", "auto" (default) or "always" (include/blah2hip.h)."""
         mode = {"off": _lib.LEAK_OFF, "auto": _lib.LEAK_AUTO, "always": _lib.LEAK_ALWAYS}.get(mode, mode)
@@ -439,6 +448,17 @@ class WienerHopf:
         .rspduo buffer); the filtered channel is written as a complex64 plane with ``out_stride`` samples per CPI."""
         check(self._L.blah2hip_clutter_process_dev_fmt(self._h, fmt, d_x, d_y, n_cpi, cpi_stride, d_y_out, out_stride,
                                                        d_ok, stream))
+
+    def estimate_dev_fmt(self, fmt, d_x, d_y, n_cpi, cpi_stride, d_ok=None, stream=0):
+        """The filter's correlations, reduction and Toeplitz solve only: the taps stay in the handle (``taps_dev``) for an
+        Ambiguity handle that runs the FIR fused into its range kernel (``Ambiguity.set_fir``)."""
+        check(self._L.blah2hip_clutter_estimate_dev_fmt(self._h, fmt, d_x, d_y, n_cpi, cpi_stride, d_ok, stream))
+
+    def taps_dev(self):
+        """(device pointer of the taps [max_batch][nBins] complex64, nBins, the filter's first lag)."""
+        p, nb, dm = C.c_void_p(), C.c_uint32(), C.c_int32()
+        check(self._L.blah2hip_clutter_taps_dev(self._h, C.byref(p), C.byref(nb), C.byref(dm)))
+        return p.value, nb.value, dm.value
 
     def _refresh_dims(self):
         nb, fl, sl = C.c_uint32(), C.c_uint32(), C.c_uint32()

@@ -170,6 +170,7 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
 #define BLAH2HIP_RANGE_WAVE 3  /* one wave per pulse, 32 points per lane, no barriers (F = 2048) */
 /* 4: was BLAH2HIP_RANGE_WAVE2 (a pair of waves per pulse at F = 4096; measured 5 % slower than _E16 and removed in round 4) */
 #define BLAH2HIP_RANGE_WAVE1K 5 /* one wave per pulse, 16 points per lane, four waves per SIMD (F = 1024) */
+#define BLAH2HIP_RANGE_FIR 7      /* INFO_LAST_RANGE_KERNEL only: range_fir_kernel (blah2hip_amb_set_fir) */
 #define BLAH2HIP_RANGE_PS 6     /* small launches (a lone CPI) at F = 1024: one workgroup of four waves per pulse, its segments dealt round-robin to the waves */
 /* BLAH2HIP_ERR_UNSUPPORTED when the kernel does not cover the handle's Doppler length */
 int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value);
@@ -381,6 +382,21 @@ int blah2hip_spectrum_process_c32(blah2hip_spectrum_t h, const float *x, uint32_
  * Enqueues only. */
 int blah2hip_spectrum_process_dev(blah2hip_spectrum_t h, int fmt, const void *d_x, uint32_t n_cpi,
                                   uint64_t cpi_stride, double *d_out, void *stream);
+
+/* ---- the clutter filter's FIR fused into the range correlation (round 6; WienerHopf.cpp:124-160 feeding Ambiguity.cpp:106-149)
+ * The filtered surveillance channel never crosses HBM: blah2hip_clutter_estimate_dev_fmt runs the filter's correlations,
+ * reduction and Toeplitz solve only (the taps stay in the handle, ok flags as in _process_dev); blah2hip_amb_set_fir hands them
+ * to an ambiguity handle, whose next blah2hip_amb_process_dev calls (with the UNFILTERED x, y) filter on the fly inside the range
+ * kernel (csrc/kernels.hpp range_fir_kernel).  The result is the two-stage result (same linear operations; fp32 rounding in a
+ * different order).  Supported where one 4096-point transform covers it -- the handle's transform length is 4096
+ * (BLAH2HIP_OPT_FFT_LEN), n_bins <= 2049, at most 2049 delay bins in one chunk, the filter's first lag equal to the map's and
+ * <= 0, symmetric Doppler limits, pulses of at least 2048 - delayMin samples, fp32 or int16 samples -- else
+ * BLAH2HIP_ERR_UNSUPPORTED at the process call.  d_w = NULL switches back to the plain range kernels. */
+int blah2hip_clutter_estimate_dev_fmt(blah2hip_clutter_t h, int fmt, const void *d_x, const void *d_y, uint32_t n_cpi,
+                                      uint64_t cpi_stride, int32_t *d_ok, void *stream);
+/* the handle's taps on the device ([max_batch][n_bins] complex fp32; zero where ok = 0), their count and the filter's first lag */
+int blah2hip_clutter_taps_dev(blah2hip_clutter_t h, const float **d_w, uint32_t *n_bins, int32_t *delay_min);
+int blah2hip_amb_set_fir(blah2hip_amb_t h, const float *d_w, uint32_t n_bins, int32_t clutter_delay_min);
 
 /* ---- device context for host bindings ------------------------------------
  * What a host-language binding needs of the HIP runtime to keep a CPI resident on the device across the calls

@@ -13,12 +13,14 @@ Tolerances and where they come from (measured values in DESIGN.md section 5):
   Toeplitz solve runs in fp64, so the residual stays at the level of those input errors
   (measured 1e-8 .. 4e-8): <= 1e-5 for the white reference, <= 1e-6 for the coloured ones.
 * map after cancellation (`check_chain_map`, the gates of oracle/gates.py = SURVEY.md 8d):
-  (i) element-wise relative error <= 1e-4 on EVERY cell above the cancelled map's own mean level
-  (the level Map::set_metrics calls noisePower) and max error <= 1e-4 of the map's peak;
-  (ii) the JSON-map gate (0.005 dB) on every cell, with the zero-Doppler cells inside the filter's
-  lag window -- which the least-squares taps cancel exactly in the reference, so that a tap error dw
-  shows up there COHERENTLY (dw[d] times sum|x|^2) -- reported on their own and held to an absolute
-  bound (1 % of the mean level);
+  (i) element-wise relative error <= 1e-4 on every cell above the cancelled map's own mean level
+  (the level Map::set_metrics calls noisePower) OUTSIDE the filter's notch, and max error <= 1e-4 of
+  the map's peak; the figure over all cells is printed beside it;
+  (ii) the JSON-map gate (0.005 dB) on every cell outside the notch;
+  the notch = the zero-Doppler cells inside the filter's lag window, which the least-squares taps
+  cancel exactly in the reference, so that the dominant tap's 1e-7 error shows up there COHERENTLY
+  (dw times sum|x|^2: 0.1-0.6 % of the mean level whatever the cell holds) -- reported on their own
+  and held to an absolute bound (1 % of the mean level);
   (iii) second line, kept from earlier rounds: the largest error over the UNCANCELLED direct-path
   level max|b| (= max|w| sum|x|^2) <= 1e-4.
 * detections: identical up to cells whose threshold margin |z|^2 / threshold is within
@@ -136,11 +138,11 @@ def margin_mismatches(ref_set, got_set, margin, amb):
     return bad
 
 
-def check_chain_map(tag, got, got_noise, ref, ref_noise, direct_level, doppler, delay, cmin, cmax, all_cells_tol=1e-4, db_gate=0.005):
+def check_chain_map(tag, got, got_noise, ref, ref_noise, direct_level, doppler, delay, cmin, cmax, db_gate=0.005):
     """The three map gates of the module docstring on a map behind the clutter filter; returns the cell measurement
     (what the detection margin is sized from)."""
     nm = notch_mask(ref.shape, doppler, delay, cmin, cmax)
-    cell = map_cell_gate(got, ref, ref_noise, tol=all_cells_tol, notch=nm)
+    cell = map_cell_gate(got, ref, ref_noise, notch=nm)
     dbg = db_map_gate(got, got_noise, ref, ref_noise, notch=nm, db_gate=db_gate)
     err_direct = float(np.abs(np.asarray(got, dtype=np.complex128) - ref).max() / direct_level)
     print(f"\n[{tag}] cell-rel above the map's mean level ({cell['cells_above_mean']} cells) {cell['cell_rel_above_mean']:.2e}  "
@@ -150,9 +152,8 @@ def check_chain_map(tag, got, got_noise, ref, ref_noise, direct_level, doppler, 
           f"notch ({dbg.get('notch_cells', 0)} cells, <= {dbg.get('notch_level_db_max', float('nan')):.1f} dB) "
           f"{dbg.get('notch_db_max', 0.0):.4f} dB, abs err / mean level {dbg.get('notch_abs_err_over_mean_level', 0.0):.2e}\n"
           f"[{tag}] err / uncancelled direct-path level {err_direct:.2e}")
-    assert cell["ok"], cell
-    assert cell["cell_rel_above_mean_outside_notch"] <= 1e-4, cell
-    assert dbg["ok"], dbg
+    assert cell["ok"] and cell["cell_rel_above_mean_outside_notch"] <= 1e-4, cell   # every cell above the mean level outside the notch
+    assert dbg["ok"], dbg                                                           # incl. the notch cells' absolute bound
     assert err_direct <= 1e-4
     return cell
 
@@ -333,7 +334,7 @@ def test_full_chain_matches_compiled_reference(b2, name):
     # which sit 8 dB above the mean level there (the target's Doppler sidelobes): 8.7e-4 of such a cell; every other cell
     # above the mean level keeps 1e-4, asserted below.  And the incoherent rounding of `y - w*x`, 100 x amplified by the
     # cancellation, puts ONE cell 19 dB under the mean level at 0.0063 dB (DESIGN.md section 5 says what would fix both)
-    loose = dict(all_cells_tol=2e-3, db_gate=0.01) if name == "deep_cancel" else {}
+    loose = dict(db_gate=0.01) if name == "deep_cancel" else {}
     cell = check_chain_map(f"{name} chain", m.data, m.noisePower, np.asarray(ref, dtype=np.complex128), float(g["chain_metrics"][0]),
                            direct_level, d.doppler, d.delay, cmin, cmax, **loose)
     assert abs(m.noisePower - g["chain_metrics"][0]) <= 1e-3 and abs(m.maxPower - g["chain_metrics"][1]) <= 1e-3

@@ -97,3 +97,30 @@ def test_looped_capture(tmp_path):
     seen = [r["s"] for r in out]
     assert seen == [int(iq[c % k, 0, 0]) for c in range(18)]
     cap.close()
+
+
+def test_cell_gate_with_a_notch():
+    """Behind a clutter filter the element-wise gate runs over the cells OUTSIDE the filter's notch; a coherent residue on
+    a notch cell that stands above the mean level is reported (cell_rel_above_mean) and bounded by db_map_gate's absolute
+    notch bound, not by 1e-4 of itself."""
+    ref = noise_map((21, 111), seed=3)
+    dop = np.arange(-10, 11) * 10.0
+    dly = np.arange(-10, 101)
+    nm = notch_mask(ref.shape, dop, dly, -10, 100)
+    noise, _ = O.map_metrics(ref)
+    lvl = mean_level(noise)
+    ref[2, 30] = 200.0 * lvl                      # the map's peak: a target
+    ref[10, 47] = 8.0 * lvl                       # its Doppler sidelobe inside the notch, above the mean level
+    got = ref.copy()
+    got[10, 47] += 4e-3 * lvl                     # the dominant tap's residue: 0.4 % of the mean level = 5e-4 of the cell
+    plain, gated = map_cell_gate(got, ref, noise), map_cell_gate(got, ref, noise, notch=nm)
+    assert not plain["ok"] and abs(plain["cell_rel_above_mean"] - 5e-4) < 1e-6
+    assert gated["ok"] and gated["cell_rel_above_mean"] == plain["cell_rel_above_mean"] and gated["cell_rel_above_mean_outside_notch"] == 0.0
+    assert gated["notch_cells_above_mean"] >= 1
+    assert db_map_gate(got, noise, ref, noise, notch=nm)["ok"]            # 0.4 % <= NOTCH_ABS
+    got[10, 47] += 2e-2 * lvl
+    assert not db_map_gate(got, noise, ref, noise, notch=nm)["ok"]        # 2.4 %: the absolute bound catches it
+    got = ref.copy()
+    got[3, 20] *= 1 + 3e-4                        # the same size of error on an ordinary cell above the mean: caught by the cell gate
+    if abs(ref[3, 20]) > lvl:
+        assert not map_cell_gate(got, ref, noise, notch=nm)["ok"]
