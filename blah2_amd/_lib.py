@@ -23,6 +23,7 @@ CLUTTER_KERNEL_NAMES = {CK_CORR: "clutter_corr", CK_REDUCE: "clutter_reduce", CK
                         CK_FIR: "clutter_fir"}
 OPT_DOPPLER_KERNEL, OPT_RANGE_GRID, OPT_RANGE_KERNEL, OPT_DOPPLER_GRID, OPT_FFT_LEN, OPT_CFAR2D_KERNEL = 1, 2, 3, 4, 5, 6
 OPT_LEAK_COMPENSATION = 7
+OPT_HOT_COLUMNS = 8
 LEAK_OFF, LEAK_AUTO, LEAK_ALWAYS = 0, 1, 2
 CFAR2D_AUTO, CFAR2D_TILE, CFAR2D_SAT, CFAR2D_STREAM = 0, 1, 2, 3
 CLUTTER_OPT_SOLVE_K, CLUTTER_OPT_FFT_LEN, CLUTTER_OPT_CORR, CLUTTER_OPT_SOLVE_FORM, CLUTTER_OPT_SOLVE_E, CLUTTER_OPT_FIR_CARRY = 1, 2, 3, 4, 5, 6
@@ -38,6 +39,7 @@ RANGE_E16, RANGE_E8, RANGE_WAVE, RANGE_WAVE1K, RANGE_PS, RANGE_FIR = 1, 2, 3, 5,
 INFO_LAST_DOPPLER_KERNEL, INFO_LAST_RANGE_KERNEL, INFO_DOPPLER_FFT_LEN, INFO_RANGE_GRID, INFO_NUM_CU = 1, 2, 3, 4, 5
 INFO_DOPPLER_GRID, INFO_DOPPLER_TILES = 6, 7
 INFO_LEAK_LAGS, INFO_LEAK_MAX_E12 = 8, 9
+INFO_HOT_COLUMNS = 10
 
 
 class Blah2HipError(RuntimeError):

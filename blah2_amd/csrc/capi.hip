@@ -82,6 +82,8 @@ struct blah2hip_amb_s {
 
   cf *d_tw = nullptr;
   cf *d_dopW = nullptr;
+  double2 *d_dopW64 = nullptr;   // hot_columns_kernel: exp(-2 pi i k / nD) in fp64
+  uint32_t *d_hotCount = nullptr; // [max_batch] columns the last call's hot_columns_kernel rewrote
   cf *d_R = nullptr;
   cf *d_map = nullptr;
   double *d_partSum = nullptr;
@@ -130,6 +132,8 @@ struct blah2hip_amb_s {
   std::map<int, LeakCal> leak;      // key = range kernel id * 64 + Doppler kernel id
   int leakMode = 1;                 // BLAH2HIP_OPT_LEAK_COMPENSATION: 0 off, 1 auto (applied where it can reach 3e-5 of the mean level), 2 always
   bool inLeakCal = false;
+  int hotMode = 1;                  // BLAH2HIP_OPT_HOT_COLUMNS: 0 off, 1 auto (CPIs long enough for a peak HOT_RATIO above the mean level), 2 always
+  bool lastHot = false;             // the last process call launched hot_columns_kernel
   int lastLeakLags = 0;             // BLAH2HIP_INFO_LEAK_LAGS: lags corrected by the last process call (0 = not applied)
   double lastLeakMax = 0.0;         // BLAH2HIP_INFO_LEAK_MAX_E12: the largest |g| of the calibration the last call ran under
 };
@@ -743,6 +747,147 @@ __global__ __launch_bounds__(64) void leak_fix_kernel(cf *map, size_t cells, siz
   }
 }
 
+// ------------------------------------------------------------------ hot columns
+// A delay column that holds a tone -- the direct path at lag 0, a strong target, the cancelled map's tallest echo -- comes
+// out of the fp32 Doppler transform with an error of ~4e-8 ... 1.2e-7 of ITS PEAK in every other row of that column (the
+// last radix step alone rounds two half-sums of the peak's size; measured: tools/gpu_chain_split_diag.py, configs[2] behind
+// the filter: 1.65e-4 of a mean-level cell in the column of a peak 1430x the mean level, the map's largest error by 5x and
+// the only one beyond north_star's 1e-4).  The reference computes in fp64 and has no such floor.  So the few columns whose
+// peak can stand more than HOT_RATIO above the map's mean level are transformed again in fp64, straight from the fp32
+// range map (direct DFT, nD^2 complex fp64 MACs a column -- 1e6 at nD = 1025, spread over nD/32 workgroups), and written
+// over the fp32 result.  Which columns: those whose mean power over four pulses of the range map, taken as a coherent tone
+// (x nD), would reach HOT_RATIO x the mean level of the Map::set_metrics partials -- noise columns sit sqrt(nD)/0.75 below
+// that test, so a launch with nothing hot costs one read of 4 x nDelay cells per workgroup.  At most HOT_MAX columns a CPI
+// (the strongest; ties to the lower lag), every workgroup of the CPI deriving the same list.  The Map::set_metrics partials
+// were taken before: rewriting 1e-7 of a peak moves noisePower by < 1e-8 dB.
+constexpr int HOT_ROWS = 32, HOT_MAX = 16, HOT_CAND = 256, HOT_SAMPLES = 4, HOT_ND_MAX = 4096;
+constexpr double HOT_RATIO = 250.0; // 1.2e-7 x 250 = 3e-5 of a mean-level cell: a third of the 1e-4 gate, as LEAK_REACH
+
+struct HotArgs {
+  const cf *R;             // tiled range map (rmap_index)
+  cf *map;                 // [nCpi][nD][nDelay]
+  const double2 *W;        // exp(-2 pi i k / nD), fp64
+  const double *partSum;   // [nCpi][nParts] (nParts > 0) ...
+  const double *metrics;   // ... or the finished [nCpi][2] (nParts == 0: doppler_sub1k_kernel)
+  uint32_t *count;         // [nCpi]: columns rewritten
+  int32_t nParts, partStride, nD, nDelay, nTiles;
+  float ratioDb;           // 10 log10(HOT_RATIO)
+};
+
+__global__ __launch_bounds__(256) void hot_columns_kernel(HotArgs a)
+{
+  extern __shared__ double2 hs[]; // W[nD], column[nD]
+  __shared__ double sred[256];
+  __shared__ int candLag[HOT_CAND];
+  __shared__ float candDb[HOT_CAND];
+  __shared__ int waveCnt[4], hot[HOT_MAX], nHot;
+  __shared__ double2 red[8][HOT_ROWS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int cpi = blockIdx.y, nD = a.nD, nDelay = a.nDelay;
+  // mean level (dB) of the map, from the partials in index order (every workgroup of the CPI: the same bits)
+  double levelDb;
+  if (a.nParts > 0) {
+    double s = 0.0;
+    for (int i = t; i < a.nParts; i += 256) s += a.partSum[(size_t)cpi * a.partStride + i];
+    sred[t] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (t < off) sred[t] += sred[t + off];
+      __syncthreads();
+    }
+    levelDb = sred[0] / ((double)nD * (double)nDelay);
+  } else {
+    levelDb = a.metrics[2 * cpi];
+  }
+  const float thr = (float)levelDb + a.ratioDb - 10.f * log10f((float)nD);
+  // candidates in lag order: wave w scans its quarter of the lags
+  const int per = ((nDelay + 3) / 4 + 63) & ~63;
+  int mine = 0;
+  for (int j0 = wave * per; j0 < min(nDelay, (wave + 1) * per); j0 += 64) {
+    const int j = j0 + lane;
+    float db = -1e30f;
+    if (j < nDelay) {
+      float pw = 0.f;
+#pragma unroll
+      for (int s = 0; s < HOT_SAMPLES; s++) {
+        const cf r = a.R[rmap_index(nD, a.nTiles, cpi, (int)(((int64_t)(2 * s + 1) * nD) / (2 * HOT_SAMPLES)), j)];
+        pw += r.x * r.x + r.y * r.y;
+      }
+      db = 5.f * log10f(pw * (1.f / HOT_SAMPLES)); // 10 log10 of the amplitude
+    }
+    const uint64_t m = __ballot(db > thr);
+    if (db > thr) {
+      const int slot = mine + __popcll(m & ((1ull << lane) - 1ull));
+      if (slot < HOT_CAND / 4) { candLag[wave * (HOT_CAND / 4) + slot] = j; candDb[wave * (HOT_CAND / 4) + slot] = db; }
+    }
+    mine += __popcll(m);
+  }
+  if (lane == 0) waveCnt[wave] = min(mine, HOT_CAND / 4);
+  __syncthreads();
+  if (t == 0) { // the HOT_MAX strongest, ties to the lower lag
+    int n = 0;
+    for (; n < HOT_MAX; n++) {
+      int best = -1;
+      float bestDb = -1e30f; // (a picked candidate is marked with this value)
+      for (int w = 0; w < 4; w++)
+        for (int i = 0; i < waveCnt[w]; i++) {
+          const int c = w * (HOT_CAND / 4) + i;
+          if (candDb[c] > bestDb) { best = c; bestDb = candDb[c]; }
+        }
+      if (best < 0) break;
+      candDb[best] = -1e30f;
+      hot[n] = candLag[best];
+    }
+    nHot = n;
+    if (blockIdx.x == 0) a.count[cpi] = (uint32_t)n;
+  }
+  __syncthreads();
+  const int nh = nHot;
+  if (nh == 0) return;
+  double2 *W = hs, *col = hs + nD;
+  for (int i = t; i < nD; i += 256) W[i] = a.W[i];
+  const int r = t & (HOT_ROWS - 1), part = t / HOT_ROWS; // 8 parts of the pulse axis
+  const int o = blockIdx.x * HOT_ROWS + r;
+  const int src = ((o < nD ? o : nD - 1) + nD / 2 + 1) % nD; // Ambiguity.cpp:165
+  const int chunk = (nD + 7) / 8;
+  const int i0 = part * chunk, i1 = min(nD, i0 + chunk);
+  for (int h = 0; h < nh; h++) {
+    const int j = hot[h];
+    __syncthreads();
+    for (int i = t; i < nD; i += 256) {
+      const cf v = a.R[rmap_index(nD, a.nTiles, cpi, i, j)];
+      col[i] = make_double2((double)v.x, (double)v.y);
+    }
+    __syncthreads();
+    int idx = (int)(((int64_t)src * i0) % nD);
+    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+    int i = i0;
+    for (; i + 1 < i1; i += 2) {
+      const double2 w0 = W[idx], v0 = col[i];
+      idx += src; if (idx >= nD) idx -= nD;
+      const double2 w1 = W[idx], v1 = col[i + 1];
+      idx += src; if (idx >= nD) idx -= nD;
+      ar = fma(v0.x, w0.x, ar); ar = fma(-v0.y, w0.y, ar);
+      ai = fma(v0.x, w0.y, ai); ai = fma(v0.y, w0.x, ai);
+      br = fma(v1.x, w1.x, br); br = fma(-v1.y, w1.y, br);
+      bi = fma(v1.x, w1.y, bi); bi = fma(v1.y, w1.x, bi);
+    }
+    if (i < i1) {
+      const double2 w0 = W[idx], v0 = col[i];
+      ar = fma(v0.x, w0.x, ar); ar = fma(-v0.y, w0.y, ar);
+      ai = fma(v0.x, w0.y, ai); ai = fma(v0.y, w0.x, ai);
+    }
+    red[part][r] = make_double2(ar + br, ai + bi);
+    __syncthreads();
+    if (t < HOT_ROWS && o < nD) {
+      double2 s = red[0][t];
+#pragma unroll
+      for (int p = 1; p < 8; p++) { s.x += red[p][t].x; s.y += red[p][t].y; }
+      a.map[((size_t)cpi * nD + o) * nDelay + j] = cmake((float)s.x, (float)s.y);
+    }
+  }
+}
+
 int predict_range(const blah2hip_amb_s *h, int nPulses)
 {
   if (use_wave_range(h, nPulses)) return BLAH2HIP_RANGE_WAVE;
@@ -975,6 +1120,17 @@ int blah2hip_amb_create_ex(int32_t delay_min, int32_t delay_max, int32_t doppler
   HIPCHK(hipMalloc(&h->d_count, max_batch * sizeof(uint32_t)));
   HIPCHK(hipMemset(h->d_R, 0, rcells * max_batch * sizeof(cf))); // padding columns stay finite
   HIPCHK(hipMemcpy(h->d_dopW, dw.data(), nD * sizeof(cf), hipMemcpyHostToDevice));
+  if (nD <= (uint32_t)HOT_ND_MAX) {
+    std::vector<double2> dw64(nD);
+    for (uint32_t k = 0; k < nD; k++) {
+      const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)nD;
+      dw64[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    HIPCHK(hipMalloc(&h->d_dopW64, nD * sizeof(double2)));
+    HIPCHK(hipMemcpy(h->d_dopW64, dw64.data(), nD * sizeof(double2), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&h->d_hotCount, max_batch * sizeof(uint32_t)));
+    HIPCHK(hipMemset(h->d_hotCount, 0, max_batch * sizeof(uint32_t)));
+  }
   HIPCHK(hipMemcpy(h->d_doppler, h->dopplerAxis.data(), nD * sizeof(double), hipMemcpyHostToDevice));
   if (h->dopR3) {
     std::vector<cf> dtw, chirp, bf;
@@ -1010,7 +1166,7 @@ int blah2hip_amb_destroy(blah2hip_amb_t h)
                   (void *)h->d_partSum, (void *)h->d_partMax, (void *)h->d_tickets, (void *)h->d_metrics,
                   (void *)h->d_doppler, h->d_in, (void *)h->d_rot,
                   (void *)h->d_hits, (void *)h->d_count, (void *)h->d_sat, (void *)h->d_dtw, (void *)h->d_chirp,
-                  (void *)h->d_bf, (void *)h->d_bfn, (void *)h->d_H})
+                  (void *)h->d_bf, (void *)h->d_bfn, (void *)h->d_H, (void *)h->d_dopW64, (void *)h->d_hotCount})
     if (p) (void)hipFree(p);
   for (auto &t : h->alphaTables)
     if (t.d) (void)hipFree(t.d);
@@ -1098,6 +1254,10 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value)
     }
     h->leakMode = (int)value;
     return BLAH2HIP_OK;
+  case BLAH2HIP_OPT_HOT_COLUMNS:
+    if (value < 0 || value > 2) return fail(BLAH2HIP_ERR_INVALID, "hot columns: 0 (off), 1 (auto) or 2 (always)");
+    h->hotMode = (int)value;
+    return BLAH2HIP_OK;
   default: return fail(BLAH2HIP_ERR_INVALID, "unknown option");
   }
 }
@@ -1125,6 +1285,16 @@ int blah2hip_amb_get_info(blah2hip_amb_t h, int key, int64_t *value)
   case BLAH2HIP_INFO_DOPPLER_TILES: *value = h->dopTilesLast; return BLAH2HIP_OK;
   case BLAH2HIP_INFO_LEAK_LAGS: *value = h->lastLeakLags; return BLAH2HIP_OK;
   case BLAH2HIP_INFO_LEAK_MAX_E12: *value = (int64_t)std::llround(h->lastLeakMax * 1e12); return BLAH2HIP_OK;
+  case BLAH2HIP_INFO_HOT_COLUMNS: { // of the last call's first CPI; waits for the device
+    *value = 0;
+    if (!h->lastHot) return BLAH2HIP_OK;
+    uint32_t n = 0;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(&n, h->d_hotCount, sizeof(n), hipMemcpyDeviceToHost));
+    *value = n;
+    return BLAH2HIP_OK;
+  }
   default: return fail(BLAH2HIP_ERR_INVALID, "unknown info key");
   }
 }
@@ -1402,6 +1572,21 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   h->lastDoppler = which;
   h->dopGridLast = dopGrid;
   h->dopTilesLast = dopTiles;
+  // fp64 columns under the tallest peaks (hot_columns_kernel), inside the Doppler bracket like the leak fix below
+  h->lastHot = false;
+  if (h->hotMode != 0 && !h->inLeakCal && h->d_dopW64 &&
+      (h->hotMode == 2 || 1.34 * std::sqrt((double)h->dims.n_used) >= HOT_RATIO)) { // |peak| <= sqrt(N) sx sy, mean level ~ 0.75 sqrt(N) sx sy
+    HotArgs ha;
+    ha.R = h->d_R; ha.map = map; ha.W = h->d_dopW64;
+    ha.partSum = h->d_partSum; ha.metrics = met; ha.count = h->d_hotCount;
+    ha.nParts = nPartsUsed; ha.partStride = nPartsUsed; ha.nD = (int32_t)nD; ha.nDelay = (int32_t)nDelay; ha.nTiles = h->nTiles;
+    ha.ratioDb = (float)(10.0 * std::log10(HOT_RATIO));
+    const size_t lds = 2 * (size_t)nD * sizeof(double2);
+    LDSCFG(hot_columns_kernel, (size_t)2 * HOT_ND_MAX * sizeof(double2));
+    hipLaunchKernelGGL(hot_columns_kernel, dim3((nD + HOT_ROWS - 1) / HOT_ROWS, n_cpi), dim3(256), lds, st, ha);
+    HIPCHK(hipGetLastError());
+    h->lastHot = true;
+  }
   if (leak) { // inside the Doppler bracket: one 64-thread workgroup per CPI on a few dozen cells of the zero-Doppler row
     leak_fix_kernel<<<dim3(n_cpi), dim3(64), 0, st>>>(map, (size_t)nD * nDelay, (size_t)leak_row0(h) * nDelay, leak_col0(h),
                                                       leak->nLags, leak->d_lag, leak->d_g);

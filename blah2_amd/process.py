@@ -229,6 +229,16 @@ class Ambiguity:
             p, nb, dm = wiener_hopf.taps_dev()
             check(self._L.blah2hip_amb_set_fir(self._h, p, nb, dm))
 
+    def set_hot_columns(self, mode):
+        """BLAH2HIP_OPT_HOT_COLUMNS: "off", "auto" (default) or "always" -- the fp64 Doppler transform of the delay columns
+        under the map's tallest peaks (include/blah2hip.h)."""
+        mode = {"off": 0, "auto": 1, "always": 2}.get(mode, mode)
+        check(self._L.blah2hip_amb_set_option(self._h, _lib.OPT_HOT_COLUMNS, int(mode)))
+
+    def hot_columns(self):
+        """Columns of the last call's first CPI that were transformed again in fp64 (waits for the device)."""
+        return self.info(_lib.INFO_HOT_COLUMNS)
+
     def set_leak_compensation(self, mode):
         """BLAH2HIP_OPT_LEAK_COMPENSATION: "off", "auto" (default) or "always" (include/blah2hip.h)."""
         mode = {"off": _lib.LEAK_OFF, "auto": _lib.LEAK_AUTO, "always": _lib.LEAK_ALWAYS}.get(mode, mode)

@@ -143,12 +143,18 @@ int blah2hip_amb_get_axes(blah2hip_amb_t h, int32_t *delay, double *doppler);
                                        * summed-area table), _STREAM / _TILE (BLAH2HIP_ERR_UNSUPPORTED at the call for other windows) or _SAT */
 #define BLAH2HIP_OPT_LEAK_COMPENSATION 7 /* Fixed-pattern leak of the fp32 transform chain (csrc/capi.hip, "leak compensation"): the butterfly
                                        * and twiddle constants are each off by up to 3e-8 of themselves, the same way in every transform, and
-                                       * what that adds up to over a CPI is a FIXED fraction g[d] (<= 1.5e-8) of the lag-0 column appearing at a
+                                       * what that adds up to over a CPI is a FIXED fraction g[d] (<= 2e-8) of the lag-0 column appearing at a
                                        * few dozen lags d -- in the zero-Doppler row, where the direct-path peak stands sqrt(N) above the floor,
                                        * up to 1e-4 of a floor cell at 4e7 samples per CPI.  g is measured once per (range kernel, Doppler
-                                       * kernel) on a synthetic CPI of sparse impulses (exact answer: zero) and subtracted from that row.
+                                       * kernel) on a synthetic white CPI against its exact fp64 direct sum and subtracted from that row.
                                        * 1 (default): where max|g| sqrt(N) >= 3e-5 (not at 2 MS/s x 1 s); 2: wherever a pattern was measured;
                                        * 0: never.  No reference counterpart (the reference computes in fp64). */
+#define BLAH2HIP_OPT_HOT_COLUMNS 8    /* fp64 Doppler transform of the delay columns that hold a peak more than 250x (24 dB) above the map's
+                                       * mean level (csrc/capi.hip, "hot columns"): the fp32 transform leaves up to 1.2e-7 of a column's peak
+                                       * in that column's other rows, which behind the clutter filter (the floor 8x down, a target 1400x above
+                                       * it at 10 MS/s) is 1.7e-4 of a mean-level cell.  At most 16 columns a CPI, found from four pulses of
+                                       * the range map.  1 (default): CPIs of >= 35 000 samples (a shorter one cannot hold such a peak);
+                                       * 2: every call; 0: never.  No reference counterpart (the reference computes in fp64). */
 #define BLAH2HIP_CFAR2D_AUTO 0
 #define BLAH2HIP_CFAR2D_TILE 1
 #define BLAH2HIP_CFAR2D_SAT 2
@@ -183,6 +189,7 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value);
 #define BLAH2HIP_INFO_LEAK_LAGS 8            /* cells of the zero-Doppler row the last process call corrected (0 = compensation not applied) */
 #define BLAH2HIP_INFO_LEAK_MAX_E12 9         /* 1e12 x the largest |g| measured for the kernel pair the last call ran (0 = not measurable: no
                                               * zero-Doppler row / lag-0 column, rotated reference channel, chunked lag window) */
+#define BLAH2HIP_INFO_HOT_COLUMNS 10          /* columns of the last call's first CPI rewritten in fp64 (BLAH2HIP_OPT_HOT_COLUMNS); waits for the device */
 #define BLAH2HIP_INFO_DOPPLER_TILES 7       /* tiles (units of work the persistent workgroups walk) of the last Doppler launch; 0 for the
                                              * non-persistent kernels */
 int blah2hip_amb_get_info(blah2hip_amb_t h, int key, int64_t *value);
