@@ -34,7 +34,6 @@ CLUTTER_CORR_AUTO, CLUTTER_CORR_HALF, CLUTTER_CORR_WINDOW = 0, 1, 2
 DOP_AUTO, DOP_TILE8, DOP_TILE16, DOP_TILEM, DOP_COLUMN, DOP_DIRECT, DOP_TILEW, DOP_TILEW2, DOP_TILE16WG, DOP_SUB4, DOP_TILE8K, DOP_TILEW4 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 DOPPLER_KERNEL_NAMES = {DOP_AUTO: "auto", DOP_TILE8: "tile8", DOP_TILE16: "tile16", DOP_TILEM: "tilem",
                         DOP_COLUMN: "column", DOP_DIRECT: "direct", DOP_TILEW: "tilew", DOP_TILEW2: "tilew2", DOP_TILE16WG: "tile16wg", DOP_SUB4: "sub4", DOP_TILE8K: "tile8k", DOP_TILEW4: "tilew4"}
-RANGE_FIR = 7
 RANGE_E16, RANGE_E8, RANGE_WAVE, RANGE_WAVE1K, RANGE_PS, RANGE_FIR = 1, 2, 3, 5, 6, 7
 INFO_LAST_DOPPLER_KERNEL, INFO_LAST_RANGE_KERNEL, INFO_DOPPLER_FFT_LEN, INFO_RANGE_GRID, INFO_NUM_CU = 1, 2, 3, 4, 5
 INFO_DOPPLER_GRID, INFO_DOPPLER_TILES = 6, 7
@@ -126,6 +125,7 @@ SYMBOLS = {
     "blah2hip_clutter_estimate_dev_fmt": (C.c_int, [_vp, C.c_int, _vp, _vp, _u32, C.c_uint64, _vp, _vp]),
     "blah2hip_clutter_taps_dev": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_i32)]),
     "blah2hip_amb_set_fir": (C.c_int, [_vp, _vp, _u32, _i32]),
+    "blah2hip_amb_fir_fusable": (C.c_int, [_vp, C.c_int, _u32, _i32]),
     "blah2hip_amb_result_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "blah2hip_amb_set_timing": (C.c_int, [_vp, C.c_int]),
     "blah2hip_amb_get_timing": (C.c_int, [_vp, _vp, _vp]),

@@ -1002,6 +1002,23 @@ int leak_calibrate(blah2hip_amb_s *h, int rangeId, int dopId, hipStream_t st, bl
   return BLAH2HIP_OK;
 }
 
+// nullptr if range_fir_kernel covers the handle's geometry with a filter of nBins taps from lag firDmin, else the reason
+const char *fir_unfusable(const blah2hip_amb_s *h, int fmt, int nBins, int firDmin)
+{
+  const int L = 2048;
+  const int nDelay = (int)h->dims.n_delay_bins;
+  if (h->dims.fft_len != 4096) return "fused FIR: the handle's transform length must be 4096 (BLAH2HIP_OPT_FFT_LEN)";
+  if (fmt != BLAH2HIP_FMT_C32 && fmt != BLAH2HIP_FMT_I16) return "fused FIR: fp32 planes or int16 words";
+  if (h->chunks.size() != 1 || h->dopplerMin + h->dopplerMax != 0) return "fused FIR: one lag chunk, symmetric Doppler limits";
+  if (nBins < 1 || nBins > L + 1 || nDelay > L + 1) return "fused FIR: at most 2049 taps and 2049 delay bins";
+  if (firDmin != h->delayMin || h->delayMin > 0) return "fused FIR: the filter's first lag must equal the map's and be <= 0";
+  if (nBins < -firDmin) return "fused FIR: the filter's window must reach lag 0";
+  if ((int)h->dims.n_corr < L - h->delayMin) return "fused FIR: pulses shorter than 2048 - delayMin samples";
+  if ((uint64_t)h->dims.n_used + (uint64_t)(-h->delayMin) > h->dims.n_samples)
+    return "fused FIR: the filter's look-ahead past the last pulse wraps around the CPI";
+  return nullptr;
+}
+
 int ensure_sat(blah2hip_amb_s *h)
 {
   if (h->d_sat) return BLAH2HIP_OK;
@@ -1272,6 +1289,13 @@ int blah2hip_amb_set_fir(blah2hip_amb_t h, const float *d_w, uint32_t n_bins, in
   return BLAH2HIP_OK;
 }
 
+int blah2hip_amb_fir_fusable(blah2hip_amb_t h, int fmt, uint32_t n_bins, int32_t clutter_delay_min)
+{
+  if (!h) return fail(BLAH2HIP_ERR_INVALID, "NULL handle");
+  const char *why = fir_unfusable(h, fmt, (int)n_bins, clutter_delay_min);
+  return why ? fail(BLAH2HIP_ERR_UNSUPPORTED, why) : BLAH2HIP_OK;
+}
+
 int blah2hip_amb_get_info(blah2hip_amb_t h, int key, int64_t *value)
 {
   if (!h || !value) return fail(BLAH2HIP_ERR_INVALID, "NULL argument");
@@ -1320,15 +1344,8 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
   // FIR fused into the range kernel: what one 4096-point transform covers (include/blah2hip.h)
   const bool fused = h->firW != nullptr && !h->inLeakCal;
   if (fused) {
-    const int L = 2048;
-    if (h->dims.fft_len != 4096) return fail(BLAH2HIP_ERR_UNSUPPORTED, "fused FIR: the handle's transform length must be 4096 (BLAH2HIP_OPT_FFT_LEN)");
-    if (fmt != BLAH2HIP_FMT_C32 && fmt != BLAH2HIP_FMT_I16) return fail(BLAH2HIP_ERR_UNSUPPORTED, "fused FIR: fp32 planes or int16 words");
-    if (h->chunks.size() != 1 || h->dopplerMin + h->dopplerMax != 0) return fail(BLAH2HIP_ERR_UNSUPPORTED, "fused FIR: one lag chunk, symmetric Doppler limits");
-    if (h->firBins > L + 1 || (int)nDelay > L + 1) return fail(BLAH2HIP_ERR_UNSUPPORTED, "fused FIR: at most 2049 taps and 2049 delay bins");
-    if (h->firDmin != h->delayMin || h->delayMin > 0) return fail(BLAH2HIP_ERR_UNSUPPORTED, "fused FIR: the filter's first lag must equal the map's and be <= 0");
-    if ((int)h->dims.n_corr < L - h->delayMin) return fail(BLAH2HIP_ERR_UNSUPPORTED, "fused FIR: pulses shorter than 2048 - delayMin samples");
-    if ((uint64_t)h->dims.n_used + (uint64_t)(-h->delayMin) > h->dims.n_samples)
-      return fail(BLAH2HIP_ERR_UNSUPPORTED, "fused FIR: the filter's look-ahead past the last pulse wraps around the CPI");
+    const char *why = fir_unfusable(h, fmt, h->firBins, h->firDmin);
+    if (why) return fail(BLAH2HIP_ERR_UNSUPPORTED, why);
     if (n_cpi > 1 && cpi_stride < h->dims.n_samples) return fail(BLAH2HIP_ERR_INVALID, "fused FIR: cpi_stride < nSamples");
     if (!h->d_H) HIPCHK(hipMalloc(&h->d_H, (size_t)h->dims.max_batch * 16 * 256 * sizeof(cf)));
   }
@@ -1404,16 +1421,17 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     fa.plan = h->plan;
     fa.plan.delayMin = h->chunks[0].lag0; fa.plan.nDelay = h->chunks[0].count; fa.plan.colOff = h->chunks[0].col0;
     fa.tw = h->d_tw; fa.out = h->d_R; fa.cpiStride = (int64_t)cpi_stride; fa.nPulses = (int32_t)(n_cpi * nD);
-    fa.H = h->d_H; fa.N = h->dims.n_samples;
-    const int grid = std::min<int>(fa.nPulses, range_grid_cap(h, lds, 4, 8));
+    fa.H = h->d_H; fa.N = h->dims.n_samples; fa.w = h->firW; fa.nBins = h->firBins;
+    const size_t ldsf = lds;
+    const int grid = std::min<int>(fa.nPulses, range_grid_cap(h, ldsf, 4, 8));
     if (fmt == BLAH2HIP_FMT_C32) {
       InC32 in{(const cf *)d_x, (const cf *)d_y};
-      LDSCFG(range_fir_kernel<InC32>, lds);
-      hipLaunchKernelGGL(range_fir_kernel<InC32>, dim3(grid), dim3(256), lds, st, fa, in);
+      LDSCFG(range_fir_kernel<InC32>, ldsf);
+      hipLaunchKernelGGL(range_fir_kernel<InC32>, dim3(grid), dim3(256), ldsf, st, fa, in);
     } else {
       InI16 in{(const int16_t *)d_x};
-      LDSCFG(range_fir_kernel<InI16>, lds);
-      hipLaunchKernelGGL(range_fir_kernel<InI16>, dim3(grid), dim3(256), lds, st, fa, in);
+      LDSCFG(range_fir_kernel<InI16>, ldsf);
+      hipLaunchKernelGGL(range_fir_kernel<InI16>, dim3(grid), dim3(256), ldsf, st, fa, in);
     }
     HIPCHK(hipGetLastError());
     h->lastRange = BLAH2HIP_RANGE_FIR;

@@ -186,6 +186,8 @@ struct RangeFirArgs {
   int64_t cpiStride;
   int32_t nPulses;
   const cf *H;        // [nCpi][16][256]: the taps' spectrum / F in the transform's register layout (taps_spectrum_kernel)
+  const cf *w;        // [nCpi][nBins]: the taps themselves (the few direct products at a pulse's edges)
+  int32_t nBins;
   uint32_t N;         // samples per CPI
 };
 
@@ -234,15 +236,7 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
   const float sgn = ((t >> 4) & 1) ? -1.f : 1.f; // (-1)^m of this thread's spectrum registers (m = q + 16 r + 256 s, q = t >> 4)
   const RangePlan p = a.plan;
   const int dmin = p.delayMin; // = the clutter window's first lag (launcher), <= 0
-  const int S = (p.nCorr + L - 1) / L;
-  auto fwd = [&](cf *v) {
-    W::fwd_s1(t, v, tw1, P);
-    __syncthreads();
-    W::fwd_s2(t, v, P, Q);
-    __syncthreads();
-    W::fwd_s3(t, v, tw3, Q);
-    __syncthreads();
-  };
+  const int SB = (p.nCorr - dmin + L - 1) / L;  // blocks of filter output that reach into the pulse (segments: S = SB or SB - 1)
   auto fwd_half = [&](cf *v) { // inputs v[8..15] are zero
     W::fwd_s1_nz9(t, v, tw1, P);
     __syncthreads();
@@ -260,91 +254,117 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
     // y of this pulse: outside it the range check returns the zeros the correlation's mask wants
     const __amdgpu_buffer_rsrc_t yd = make_rsrc_b(BufLoad<In>::yp(in, (int64_t)cpi * a.cpiStride + p0), p.nCorr * CY::STRIDE);
     const cf *Hc = a.H + (size_t)cpi * 16 * 256 + t;
-    cf Xp[16], Xg[16], acc[16], wk[16], yfp[8];
-#pragma unroll
-    for (int e = 0; e < 16; e++) acc[e] = cmake(0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 8; k++) yfp[k] = cmake(0.f, 0.f);
-    // segment u in [u0, u0 + L) of the filter's reference stream: x[u], zero below -delayMin (xs[m < 0] = 0, WienerHopf.cpp:125-160)
-    auto load_seg = [&](cf *v, int u0) {
+    const cf *wc = a.w + (size_t)cpi * a.nBins;
+    // Three arrays (+ the twiddles): what range_kernel holds.  V = the spectrum of the filter's WINDOW
+    // [segment g-1 | segment g] of x masked to the pulse, wk = the work array, acc = the correlation's accumulator.
+    // Where the filter's stream differs from the masked x -- it looks |delayMin| samples past the pulse's end, and it is zero
+    // on the CPI's first |delayMin| samples (xs[m < 0] = 0, WienerHopf.cpp:125-160) -- the <= |delayMin| products a sample is
+    // off by are added directly (`edges`): a few hundred MACs a pulse instead of a second transform.
+    cf V[16], wk[16], acc[16];
+    // the filter's output block g from wk = IFFT(H V_g): samples n = g L + delayMin + [0, L) of the pulse are wk[8..15];
+    // leaves y' = y - (w * xs) of the block, masked to the pulse, in wk[0..7] and zeros in wk[8..15]
+    auto block_out = [&](int g) {
+      W::inv_s1(t, wk, tw3, Q);
+      __syncthreads();
+      typename RY::raw yr[8]; // y of the block: requested here, used after the last stage
 #pragma unroll
       for (int k = 0; k < 8; k++) {
-        const int u = u0 + t + T * k;
-        const cf x = RX::cvt(RX::ld(xd, u * CX::STRIDE, 0));
-        v[k] = u >= -dmin ? x : cmake(0.f, 0.f);
+        int vo = (g * L + dmin + t + T * k) * CY::STRIDE; // may be negative: the whole offset in the VGPR (bufload.hpp)
+        asm volatile("" : "+v"(vo));
+        yr[k] = RY::ld(yd, vo, 0);
+      }
+      W::inv_s2(t, wk, Q, P);
+      __syncthreads();
+      W::inv_s3(t, wk, tw1, P);
+      __syncthreads();
+      const bool tail = (g + 1) * L > p.nCorr;                      // the block holds the pulse's last |delayMin| samples
+      const bool head = i == 0 && g * L + dmin < a.nBins + (-dmin); // pulse 0: samples the CPI's first |delayMin| reach
+      if (tail || head) { // (workgroup-uniform) the edges, through LDS so that the register arrays keep static indices
+        cf *E = P + t;    // P is free: its last readers passed the barrier above
+#pragma unroll
+        for (int k = 0; k < 8; k++) E[k * T] = wk[8 + k];
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) {
+          const int n = g * L + dmin + t + T * k; // sample of the pulse
+          cf c = E[k * T];
+          if (tail) // past the pulse's end: the taps kk <= n - delayMin - nCorr reach x[p0 + nCorr ...], masked out of the window
+            for (int kk = 0; kk <= min(n - dmin - p.nCorr, a.nBins - 1) && n < p.nCorr; kk++) {
+              const cf x = RX::cvt(RX::ld(xd, (p0 + n - dmin - kk) * CX::STRIDE, 0));
+              c = cadd(c, cmul(wc[kk], x));
+            }
+          if (head && n >= 0) // the CPI's first |delayMin| samples: in the window of pulse 0, zero in the filter's stream
+            for (int kk = max(n + 1, 0); kk <= n - dmin && kk < a.nBins; kk++) {
+              const cf x = RX::cvt(RX::ld(xd, (n - dmin - kk) * CX::STRIDE, 0));
+              c = csub(c, cmul(wc[kk], x));
+            }
+          E[k * T] = c;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) wk[8 + k] = E[k * T];
+        __syncthreads(); // P is written again by the next transform
       }
 #pragma unroll
-      for (int k = 8; k < 16; k++) v[k] = cmake(0.f, 0.f);
+      for (int k = 0; k < 8; k++) {
+        const int n = g * L + dmin + t + T * k;
+        const cf yv = RY::cvt(yr[k]);
+        wk[k] = (n >= 0 && n < p.nCorr) ? csub(yv, wk[8 + k]) : cmake(0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 8; k < 16; k++) wk[k] = cmake(0.f, 0.f);
     };
-    if (i > 0) { // the history block in front of the pulse (pulse 0: the stream is zero there)
-      load_seg(Xp, p0 - L);
-      fwd_half(Xp);
+    // ---- block 0: the history block X_(-1) and segment 0 separately (the history is not a segment of the correlation);
+    //      X_0 sits in the accumulator's registers, which have nothing to hold yet
+#pragma unroll
+    for (int e = 0; e < 16; e++) wk[e] = Hc[e * 256];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int m = t + T * k;
+      const cf x = RX::cvt(RX::ld(xd, (p0 + m) * CX::STRIDE, 0));
+      acc[k] = m < p.nCorr ? x : cmake(0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 8; k < 16; k++) acc[k] = cmake(0.f, 0.f);
+    if (i > 0) { // (pulse 0: the stream is zero in front of the CPI)
+#pragma unroll
+      for (int k = 0; k < 8; k++) V[k] = RX::cvt(RX::ld(xd, (p0 - L + t + T * k) * CX::STRIDE, 0));
+#pragma unroll
+      for (int k = 8; k < 16; k++) V[k] = cmake(0.f, 0.f);
+      fwd_half(V);
     } else {
 #pragma unroll
-      for (int e = 0; e < 16; e++) Xp[e] = cmake(0.f, 0.f);
+      for (int e = 0; e < 16; e++) V[e] = cmake(0.f, 0.f);
     }
-    // the segment's spectrum as the CORRELATION wants it: x masked to the pulse, the CPI's first samples included.  It is the
-    // filter's variant except for a pulse's ragged last segment (the filter looks |delayMin| samples past the pulse's end)
-    // and pulse 0's first (the filter's stream is zero below -delayMin)
-    auto dual = [&](int g) { return (g + 1) * L > p.nCorr || (i == 0 && g == 0 && dmin < 0); };
-    for (int g = 0; g <= S; g++) {
-      // g < S: segment g -> the filter's spectrum X_g and output block g;  g >= 1: the correlation of segment g - 1, whose
-      // y' window is [block g - 1 | block g] (zeros behind the last block)
-      if (g < S) {
-        typename RY::raw yr[8];
-        load_seg(Xg, p0 + g * L);
+    fwd_half(acc);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          int vo = (g * L + dmin + t + T * k) * CY::STRIDE; // may be negative: the whole offset in the VGPR (bufload.hpp)
-          asm volatile("" : "+v"(vo));
-          yr[k] = RY::ld(yd, vo, 0);
-        }
+    for (int e = 0; e < 16; e++) wk[e] = cmul(wk[e], cmake(V[e].x + sgn * acc[e].x, V[e].y + sgn * acc[e].y));
+    block_out(0);
+    // Z_g = FFT([block g | 0]); the y' window of segment g is [block g | block g + 1] = Z_g + (-1)^m Z_(g+1), so
+    //   sum_g Y'_g conj(X_g) = Z_0 conj(X_0) + sum_(g >= 1) Z_g conj(X_g + (-1)^m X_(g-1)) = ... + sum Z_g conj((-1)^m V_g)
+    fwd_half(wk);
 #pragma unroll
-        for (int e = 0; e < 16; e++) wk[e] = Hc[e * 256];
-        fwd_half(Xg);
+    for (int e = 0; e < 16; e++) acc[e] = cmulc(wk[e], acc[e]);
+    for (int g = 1; g < SB; g++) {
+      // (H into the work array, which is free until the product below: its L2 latency hides behind the window's transform)
 #pragma unroll
-        for (int e = 0; e < 16; e++) wk[e] = cmul(wk[e], cmake(Xp[e].x + sgn * Xg[e].x, Xp[e].y + sgn * Xg[e].y));
-        W::inv_s1(t, wk, tw3, Q);
-        __syncthreads();
-        W::inv_s2(t, wk, Q, P);
-        __syncthreads();
-        W::inv_s3(t, wk, tw1, P);
-        __syncthreads();
-        // the block's L valid outputs are wk[8..15]: sample  g L + delayMin + t + T k  of the pulse
+      for (int e = 0; e < 16; e++) wk[e] = Hc[e * 256];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const int nr = g * L + dmin + t + T * k;
-          const cf yv = RY::cvt(yr[k]);
-          wk[8 + k] = (nr >= 0 && nr < p.nCorr) ? csub(yv, wk[8 + k]) : cmake(0.f, 0.f);
-        }
-      } else {
-#pragma unroll
-        for (int k = 8; k < 16; k++) wk[k] = cmake(0.f, 0.f);
+      for (int k = 0; k < 16; k++) {
+        const int m = (g - 1) * L + t + T * k;
+        const cf x = RX::cvt(RX::ld(xd, (p0 + m) * CX::STRIDE, 0));
+        V[k] = m < p.nCorr ? x : cmake(0.f, 0.f);
       }
-      if (g >= 1) {
-        if (dual(g - 1)) { // X_(g-1) has served the filter's window: replace it by the correlation's variant
+      W::fwd_s1(t, V, tw1, P);
+      __syncthreads();
+      W::fwd_s2(t, V, P, Q);
+      __syncthreads();
+      W::fwd_s3(t, V, tw3, Q);
+      __syncthreads();
 #pragma unroll
-          for (int k = 0; k < 8; k++) {
-            const int m = (g - 1) * L + t + T * k;
-            const cf x = RX::cvt(RX::ld(xd, (p0 + m) * CX::STRIDE, 0));
-            Xp[k] = m < p.nCorr ? x : cmake(0.f, 0.f);
-          }
+      for (int e = 0; e < 16; e++) wk[e] = cmul(wk[e], V[e]);
+      block_out(g);
+      fwd_half(wk);
 #pragma unroll
-          for (int k = 8; k < 16; k++) Xp[k] = cmake(0.f, 0.f);
-          fwd_half(Xp);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) { const cf o = yfp[k]; yfp[k] = wk[8 + k]; wk[k] = o; }
-        if (g < S) fwd(wk);
-        else fwd_half(wk);
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[e] = cmacc(acc[e], wk[e], Xp[e]);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 8; k++) yfp[k] = wk[8 + k];
-      }
-#pragma unroll
-      for (int e = 0; e < 16; e++) Xp[e] = Xg[e];
+      for (int e = 0; e < 16; e++) acc[e] = cmacc(acc[e], wk[e], cmake(sgn * V[e].x, sgn * V[e].y));
     }
     W::inv_s1(t, acc, tw3, P);
     __syncthreads();

@@ -229,6 +229,16 @@ class Ambiguity:
             p, nb, dm = wiener_hopf.taps_dev()
             check(self._L.blah2hip_amb_set_fir(self._h, p, nb, dm))
 
+    def fir_fusable(self, wiener_hopf, fmt):
+        """None if ``set_fir(wiener_hopf)`` is covered for samples in format ``fmt`` (FMT_C32 / FMT_I16), else the reason."""
+        _, nb, dm = wiener_hopf.taps_dev()
+        rc = self._L.blah2hip_amb_fir_fusable(self._h, int(fmt), nb, dm)
+        if rc == _lib.OK:
+            return None
+        if rc == _lib.ERR_UNSUPPORTED:
+            return self._L.blah2hip_last_error().decode()
+        check(rc)
+
     def set_hot_columns(self, mode):
         """BLAH2HIP_OPT_HOT_COLUMNS: "off", "auto" (default) or "always" -- the fp64 Doppler transform of the delay columns
         under the map's tallest peaks (include/blah2hip.h)."""

@@ -404,6 +404,9 @@ int blah2hip_clutter_estimate_dev_fmt(blah2hip_clutter_t h, int fmt, const void 
 /* the handle's taps on the device ([max_batch][n_bins] complex fp32; zero where ok = 0), their count and the filter's first lag */
 int blah2hip_clutter_taps_dev(blah2hip_clutter_t h, const float **d_w, uint32_t *n_bins, int32_t *delay_min);
 int blah2hip_amb_set_fir(blah2hip_amb_t h, const float *d_w, uint32_t n_bins, int32_t clutter_delay_min);
+/* BLAH2HIP_OK if the fused kernel covers this handle with such a filter and sample format, else BLAH2HIP_ERR_UNSUPPORTED (the reason
+ * in blah2hip_last_error): lets a caller choose between the fused and the two-stage chain before it enqueues anything */
+int blah2hip_amb_fir_fusable(blah2hip_amb_t h, int fmt, uint32_t n_bins, int32_t clutter_delay_min);
 
 /* ---- device context for host bindings ------------------------------------
  * What a host-language binding needs of the HIP runtime to keep a CPI resident on the device across the calls

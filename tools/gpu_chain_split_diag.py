@@ -1,3 +1,5 @@
+"""Where the full chain's map error comes from: the filter's share (the engine's filtered channel through the ORACLE's map
+stage) and the map stage's share, with the five worst cells of each."""
 import os, sys
 import numpy as np
 ROOT = "/root/repo"
@@ -7,12 +9,13 @@ import bench
 import blah2_amd as b2
 from oracle import blah2_oracle as O
 from oracle import gates as G
-cfg, _ = bench.CONFIGS["cfg3"]
+# python tools/gpu_chain_split_diag.py [config [seed [cpi]]]   (tools/gpu_chain_gate_stats.py: seed = 5000 + 8 * (cpi // 8), cpi % 8)
+cfg, _ = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg3"]
 dmin, dmax, fmin, fmax, fs, n = cfg
 dev = torch.device("cuda", 0)
 B = 8
-x, y = bench.synth_batch(torch, B, n, 5000 + 8, fs, dev)
-c = 4
+x, y = bench.synth_batch(torch, B, n, int(sys.argv[2]) if len(sys.argv) > 2 else 5008, fs, dev)
+c = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 amb = b2.Ambiguity(dmin, dmax, fmin, fmax, fs, n, True, max_batch=1)
 wh = b2.WienerHopf(dmin, dmax, n, max_batch=1)
 xc, yc = x[c:c+1].contiguous(), y[c:c+1].contiguous()
