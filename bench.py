@@ -335,6 +335,7 @@ def _measure(a, env, handles):
             iq = torch.stack([x.real, x.imag, y.real, y.imag], dim=-1).to(torch.int16).contiguous()
             iqs.append(iq)
     wh = None
+    fused_fir = False
     CAP = 65536
     if a.chain == "full":
         if a.fmt not in ("c32", "i16"):
@@ -353,6 +354,15 @@ def _measure(a, env, handles):
         yfilt, okflag, hits, hitcnt = yfilts[0], okflags[0], hitss[0], hitcnts[0]
         det_params = (1e-5, 2, 6, 1, 3, 5, 15.0) if a.cfar == "2d" else (1e-5, 2, 6, 5, 15.0)  # config.yml:36-40 (+ Doppler guard 1, train 3)
         det = blah2_amd.CfarDetector2D(*det_params) if a.cfar == "2d" else blah2_amd.CfarDetector1D(*det_params)
+        # the filter's FIR inside the range kernel (range_fir_kernel) where one 4096-point transform covers the geometry
+        fmt_id = blah2_amd.FMT_I16 if a.fmt == "i16" else blah2_amd.FMT_C32
+        why_not = next((w for w in (ambs[q].fir_fusable(whs[q], fmt_id) for q in range(NS)) if w), None)
+        if a.fir == "fused" and why_not:
+            raise SystemExit(f"--fir fused: {why_not}")
+        fused_fir = a.fir != "two-stage" and why_not is None
+        if fused_fir:
+            for q in range(NS):
+                ambs[q].set_fir(whs[q])
     outs = [torch.zeros((B, nD, nC), dtype=torch.complex64, device=dev) for _ in range(NS)]
     mets = [torch.zeros((B, 2), dtype=torch.float64, device=dev) for _ in range(NS)]
     out, met = outs[0], mets[0]
@@ -366,7 +376,14 @@ def _measure(a, env, handles):
         if wh is not None:
             q = i % NS
             w_, a_, s_, yf_, ok_, o_, m_, h_, c_ = whs[q], ambs[q], sts[q], yfilts[q], okflags[q], outs[q], mets[q], hitss[q], hitcnts[q]
-            if a.fmt == "i16":  # the replay format: the filter and the range kernel read the .rspduo words
+            if fused_fir:  # the filter's taps only; the range kernel filters the unfiltered channels on the fly
+                if a.fmt == "i16":
+                    w_.estimate_dev_fmt(blah2_amd.FMT_I16, iqs[r].data_ptr(), None, B, n, ok_.data_ptr(), s_)
+                    a_.process_dev(blah2_amd.FMT_I16, iqs[r].data_ptr(), None, B, n, o_.data_ptr(), m_.data_ptr(), s_)
+                else:
+                    w_.estimate_dev_fmt(blah2_amd.FMT_C32, xs[r].data_ptr(), ys[r].data_ptr(), B, n, ok_.data_ptr(), s_)
+                    a_.process_dev(blah2_amd.FMT_C32, xs[r].data_ptr(), ys[r].data_ptr(), B, n, o_.data_ptr(), m_.data_ptr(), s_)
+            elif a.fmt == "i16":  # the replay format: the filter and the range kernel read the .rspduo words
                 w_.process_dev_fmt(blah2_amd.FMT_I16, iqs[r].data_ptr(), None, B, n, yf_.data_ptr(), n, ok_.data_ptr(), s_)
                 a_.process_dev(blah2_amd.FMT_I16X_C32Y, iqs[r].data_ptr(), yf_.data_ptr(), B, n, o_.data_ptr(), m_.data_ptr(), s_)
             else:
@@ -513,7 +530,7 @@ def _measure(a, env, handles):
     # passes of this same command (tools/summarize_prof.py -> profiles/*_traffic.json)
     traffic, traffic_src = None, None
     import glob
-    ran_range = {1: "range_kernel", 2: "range8_kernel", 3: "rangew_kernel", 5: "rangew1k_kernel", 6: "rangeps_kernel"}.get(
+    ran_range = {1: "range_kernel", 2: "range8_kernel", 3: "rangew_kernel", 5: "rangew1k_kernel", 6: "rangeps_kernel", 7: "range_fir_kernel"}.get(
         amb.info(blah2_amd._lib.INFO_LAST_RANGE_KERNEL), "range_kernel")
     prof_names = {"range": (ran_range,), "doppler": ("doppler_",),  # the range kernel this run launched, no other
                   "metrics": ("metrics_kernel",), "cfar": ("cfar2d_stream_kernel", "cfar2d_tile_kernel", "cfar2d_kernel", "cfar1d_kernel"),
@@ -630,7 +647,8 @@ def _measure(a, env, handles):
                        "fft_len": amb.dims.fft_len, "n_seg": amb.dims.n_seg, "seg_len": amb.dims.seg_len,
                        "doppler_kernel": amb.last_doppler_kernel(),
                        "prewarm_s": a.prewarm_s, "prewarm_steps": n_pre,
-                       "range_kernel": {1: "e16", 2: "e8", 3: "wave", 5: "wave1k", 6: "ps"}.get(amb.info(blah2_amd._lib.INFO_LAST_RANGE_KERNEL)),
+                       "range_kernel": {1: "e16", 2: "e8", 3: "wave", 5: "wave1k", 6: "ps", 7: "fir+e16"}.get(amb.info(blah2_amd._lib.INFO_LAST_RANGE_KERNEL)),
+                       "fir": ("fused into the range kernel (range_fir_kernel)" if fused_fir else "two-stage (clutter_fir_kernel)") if wh is not None else None,
                        "ring_batches": ring, "streams_per_gpu": NS, "sharding": f"{world} independent CPI streams, one per GPU",
                        "ranks_seen_by_rccl": ranks_seen if dist is not None else None},
             "cells_per_s": total_cpis * cells / elapsed,
@@ -638,7 +656,7 @@ def _measure(a, env, handles):
             "per_gpu_cpis_per_s": total_cpis / elapsed / world,
             "parity": parity,
             "headline_long": long_res,
-            "roofline": {"bound": "hbm", "kernel": {1: "range_kernel", 2: "range8_kernel", 3: "rangew_kernel", 5: "rangew1k_kernel", 6: "rangeps_kernel"}.get(
+            "roofline": {"bound": "hbm", "kernel": {1: "range_kernel", 2: "range8_kernel", 3: "rangew_kernel", 5: "rangew1k_kernel", 6: "rangeps_kernel", 7: "range_fir_kernel"}.get(
                              amb.info(blah2_amd._lib.INFO_LAST_RANGE_KERNEL), "range_kernel"), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes,
@@ -715,6 +733,7 @@ def config_legs(a, env):
                         "cpis_per_s": r["value"], "us_per_cpi": r["us_per_cpi"], "cells_per_s": r["cells_per_s"],
                         "n_doppler_bins": r["config"]["n_doppler_bins"], "n_delay_bins": r["config"]["n_delay_bins"],
                         "range_kernel": r["config"]["range_kernel"], "doppler_kernel": r["config"]["doppler_kernel"],
+                        "fir": r["config"].get("fir"),
                         "chain_frac": rl["chain_frac"],  # B_amb over the time of the whole chain, against 8 TB/s
                         "dominant_kernel": dom, "kernels": ks,
                         "parity": None if par is None else {k: par[k] for k in (
@@ -908,6 +927,8 @@ def main(argv=None):
                     help="force the range transform length (0 = the planner's choice); diagnostics")
     ap.add_argument("--range-grid", type=int, default=0,
                     help="cap the range kernel's grid (workgroups; 0 = its residency): e.g. the CU count for ONE workgroup per CU; diagnostics")
+    ap.add_argument("--fir", default="auto", choices=["auto", "fused", "two-stage"],
+                    help="--chain full: the clutter filter's FIR fused into the range kernel where it is covered (auto), required (fused) or never")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent CPI streams per GPU (engine handles on their own HIP streams); successive "
                          "steps alternate between them so one batch's Doppler stage overlaps the next batch's range stage")

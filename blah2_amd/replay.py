@@ -418,8 +418,14 @@ class GpuChain:
                                        self.fs, n, True, device=device, max_batch=B)
         nD, nC = self.amb.get_n_doppler_bins(), self.amb.get_n_delay_bins()
         self.wh = None
+        self.fused_fir = False
         if clu_c.get("enable", False):
             self.wh = blah2_amd.WienerHopf(clu_c["delayMin"], clu_c["delayMax"], n, device=device, max_batch=B)
+            # the filter's FIR inside the range kernel where one 4096-point transform covers the geometry (range_fir_kernel):
+            # the filtered channel never crosses HBM.  clutter: {fused: false} keeps the two-stage chain.
+            self.fused_fir = bool(clu_c.get("fused", True)) and self.amb.fir_fusable(self.wh, blah2_amd.FMT_I16) is None
+            if self.fused_fir:
+                self.amb.set_fir(self.wh)
         self.cfar = self.centroid = self.interp = None
         if det_c.get("enable", False):
             self.cfar = blah2_amd.CfarDetector1D(det_c["pfa"], det_c["nGuard"], det_c["nTrain"], det_c["minDelay"],
@@ -454,7 +460,7 @@ class GpuChain:
         if read_mode == "mapped" and self._hip is None:
             self.read_mode = "memmove"
         # the filtered surveillance channel (one buffer: the compute stream is in order)
-        self.yf = torch.empty((B, n), dtype=torch.complex64, device=dev) if self.wh is not None else None
+        self.yf = torch.empty((B, n), dtype=torch.complex64, device=dev) if self.wh is not None and not self.fused_fir else None
         self.busy_ms, self.batches_done = 0.0, 0  # kernels' time on the compute stream / batches collected, since construction
         self.slots = []
         for _ in range(self.depth):
@@ -540,6 +546,9 @@ class GpuChain:
             iq = slot["d_iq"].data_ptr()
             if self.wh is None:
                 amb.process_dev(b2.FMT_I16, iq, 0, cnt, n, slot["d_map"].data_ptr(), slot["d_met"].data_ptr(), st)
+            elif self.fused_fir:
+                self.wh.estimate_dev_fmt(b2.FMT_I16, iq, None, cnt, n, slot["d_ok"].data_ptr(), st)
+                amb.process_dev(b2.FMT_I16, iq, None, cnt, n, slot["d_map"].data_ptr(), slot["d_met"].data_ptr(), st)
             else:
                 self.wh.process_dev_fmt(b2.FMT_I16, iq, None, cnt, n, self.yf.data_ptr(), n, slot["d_ok"].data_ptr(), st)
                 amb.process_dev(b2.FMT_I16X_C32Y, iq, self.yf.data_ptr(), cnt, n, slot["d_map"].data_ptr(),

@@ -169,15 +169,15 @@ def test_refusals(b2):
     torch.cuda.synchronize()
     for h in (a, w_ok, w_shift):
         h.close()
-    b = b2.Ambiguity(-8, 1200, -100, 100, 200_000, 200_000, True)  # 201 pulses of 995 samples
+    b = b2.Ambiguity(-8, 300, -100, 100, 200_000, 200_000, True)  # 201 pulses of 995 samples
     b.set_fft_len(4096)
-    w = b2.WienerHopf(-8, 1200, 200_000)
+    w = b2.WienerHopf(-8, 300, 200_000)
     assert "shorter" in b.fir_fusable(w, b2.FMT_C32)
     b.close()
     w.close()
-    c = b2.Ambiguity(2, 1200, -10, 10, 200_000, 200_000, True)
+    c = b2.Ambiguity(1, 1200, -10, 10, 200_000, 200_000, True)
     c.set_fft_len(4096)
-    w = b2.WienerHopf(2, 1200, 200_000)
+    w = b2.WienerHopf(1, 1200, 200_000)
     assert "<= 0" in c.fir_fusable(w, b2.FMT_C32)
     c.close()
     w.close()

@@ -134,3 +134,38 @@ def test_replay_json_frames(built_lib, tmp_path, capsys):
         assert len(d["delay"]) == len(km)
         assert np.allclose(d["delay"], km, atol=0.011) and np.allclose(d["doppler"], g["interp"][1], atol=0.011)
         assert np.allclose(d["snr"], g["interp"][2], atol=0.011)
+
+
+def test_replay_runs_the_fused_fir_where_it_is_covered(built_lib, tmp_path):
+    """A geometry one 4096-point transform covers (31 pulses of 6149 samples, 2047 taps): GpuChain hands the filter's taps to
+    the range kernel (range_fir_kernel) instead of writing the filtered channel; clutter: {fused: false} keeps the two-stage
+    chain.  Same detections, metrics to 1e-4 dB; a dead reference channel is skipped either way."""
+    import blah2_amd
+    from blah2_amd import replay as R
+    from test_fused_fir_gpu import synth
+    n = 190_647
+    x, y = synth(n, n, 77)
+    iq = np.stack([x.real, x.imag, y.real, y.imag], axis=-1).astype(np.int16)
+    dead = iq.copy()
+    dead[:, 0:2] = 0
+    path = str(tmp_path / "cap.rspduo")
+    np.concatenate([iq, dead, iq]).tofile(path)
+    cfg = {"fs": n, "n_samples": n,
+           "ambiguity": {"delayMin": -24, "delayMax": 2023, "dopplerMin": -15, "dopplerMax": 15},
+           "detection": {"enable": True, "pfa": 1e-5, "nGuard": 2, "nTrain": 6, "minDelay": 5, "minDoppler": 1.0},
+           "clutter": {"enable": True, "delayMin": -24, "delayMax": 2023}}
+    out = {}
+    for fused in (True, False):
+        cfg["clutter"]["fused"] = fused
+        chain = R.gpu_processor(cfg, 0, batch=2)
+        assert chain.fused_fir == fused
+        res = R.replay(R.RspduoFile(path, n), chain, batch=2)
+        out[fused] = res
+        assert [bool(r.get("skipped")) for r in res] == [False, True, False]
+        assert chain.amb.info(blah2_amd._lib.INFO_LAST_RANGE_KERNEL) == (blah2_amd._lib.RANGE_FIR if fused else blah2_amd._lib.RANGE_E16)
+    for a, b in zip(out[True], out[False]):
+        if a.get("skipped"):
+            continue
+        assert abs(a["noisePower"] - b["noisePower"]) < 1e-4 and abs(a["maxPower"] - b["maxPower"]) < 1e-4
+        assert list(zip(a["delay"], a["doppler"])) == list(zip(b["delay"], b["doppler"])) and len(a["delay"]) >= 1
+        assert np.allclose(a["snr"], b["snr"], rtol=0, atol=1e-3)
