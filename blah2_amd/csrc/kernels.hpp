@@ -263,18 +263,27 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
     cf V[16], wk[16], acc[16];
     // the filter's output block g from wk = IFFT(H V_g): samples n = g L + delayMin + [0, L) of the pulse are wk[8..15];
     // leaves y' = y - (w * xs) of the block, masked to the pulse, in wk[0..7] and zeros in wk[8..15]
-    auto block_out = [&](int g) {
-      W::inv_s1(t, wk, tw3, Q);
-      __syncthreads();
-      typename RY::raw yr[8]; // y of the block: requested here, used after the last stage
+    // B2_FIR_YPOS (experiments, tools/prof_fused_ab.sh): where the block's y is requested -- 1 (default) behind the inverse's
+    // first exchange; 2 behind its second; 0 before the window's transform (see profiles/r06_ab_experiments.json)
+#ifndef B2_FIR_YPOS
+#define B2_FIR_YPOS 1
+#endif
+    typename RY::raw yr[8];
+    auto y_request = [&](int g) {
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         int vo = (g * L + dmin + t + T * k) * CY::STRIDE; // may be negative: the whole offset in the VGPR (bufload.hpp)
         asm volatile("" : "+v"(vo));
         yr[k] = RY::ld(yd, vo, 0);
       }
+    };
+    auto block_out = [&](int g) {
+      W::inv_s1(t, wk, tw3, Q);
+      __syncthreads();
+      if (B2_FIR_YPOS == 1) y_request(g); // y of the block: requested here, used after the last stage
       W::inv_s2(t, wk, Q, P);
       __syncthreads();
+      if (B2_FIR_YPOS == 2) y_request(g);
       W::inv_s3(t, wk, tw1, P);
       __syncthreads();
       const bool tail = (g + 1) * L > p.nCorr;                      // the block holds the pulse's last |delayMin| samples
@@ -314,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
     };
     // ---- block 0: the history block X_(-1) and segment 0 separately (the history is not a segment of the correlation);
     //      X_0 sits in the accumulator's registers, which have nothing to hold yet
+    if (B2_FIR_YPOS == 0) y_request(0);
 #pragma unroll
     for (int e = 0; e < 16; e++) wk[e] = Hc[e * 256];
 #pragma unroll
@@ -345,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
     for (int e = 0; e < 16; e++) acc[e] = cmulc(wk[e], acc[e]);
     for (int g = 1; g < SB; g++) {
       // (H into the work array, which is free until the product below: its L2 latency hides behind the window's transform)
+      if (B2_FIR_YPOS == 0) y_request(g);
 #pragma unroll
       for (int e = 0; e < 16; e++) wk[e] = Hc[e * 256];
 #pragma unroll
