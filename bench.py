@@ -304,6 +304,8 @@ def _measure(a, env, handles):
         handles.append(ambs[-1])
     for h_ in ambs:
         h_.set_doppler_kernel(a.doppler_kernel)
+        if a.hot_columns != "auto":
+            h_.set_hot_columns(a.hot_columns)
         if a.fft_len:
             h_.set_fft_len(a.fft_len)
         if a.range_grid:
@@ -927,6 +929,8 @@ def main(argv=None):
                     help="force the range transform length (0 = the planner's choice); diagnostics")
     ap.add_argument("--range-grid", type=int, default=0,
                     help="cap the range kernel's grid (workgroups; 0 = its residency): e.g. the CU count for ONE workgroup per CU; diagnostics")
+    ap.add_argument("--hot-columns", default="auto", choices=["auto", "off", "always"],
+                    help="BLAH2HIP_OPT_HOT_COLUMNS: the fp64 Doppler transform of the columns under the tallest peaks (an A/B switch; auto is the engine's default)")
     ap.add_argument("--fir", default="auto", choices=["auto", "fused", "two-stage"],
                     help="--chain full: the clutter filter's FIR fused into the range kernel where it is covered (auto), required (fused) or never")
     ap.add_argument("--streams", type=int, default=1,

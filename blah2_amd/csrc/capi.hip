@@ -755,7 +755,8 @@ __global__ __launch_bounds__(64) void leak_fix_kernel(cf *map, size_t cells, siz
 // the only one beyond north_star's 1e-4).  The reference computes in fp64 and has no such floor.  So the few columns whose
 // peak can stand more than HOT_RATIO above the map's mean level are transformed again in fp64, straight from the fp32
 // range map (direct DFT, nD^2 complex fp64 MACs a column -- 1e6 at nD = 1025, spread over nD/32 workgroups), and written
-// over the fp32 result.  Which columns: those whose mean power over four pulses of the range map, taken as a coherent tone
+// over the fp32 result.  Which columns: those whose mean power over four pulses of the range map (less the first pulse's
+// value: the Doppler kernels remove the column's zero-Doppler content exactly before they transform it), taken as a coherent tone
 // (x nD), would reach HOT_RATIO x the mean level of the Map::set_metrics partials -- noise columns sit sqrt(nD)/0.75 below
 // that test, so a launch with nothing hot costs one read of 4 x nDelay cells per workgroup.  At most HOT_MAX columns a CPI
 // (the strongest; ties to the lower lag), every workgroup of the CPI deriving the same list.  The Map::set_metrics partials
@@ -807,11 +808,14 @@ __global__ __launch_bounds__(256) void hot_columns_kernel(HotArgs a)
     const int j = j0 + lane;
     float db = -1e30f;
     if (j < nDelay) {
+      // (less the first pulse's value, as the Doppler kernels transform the column: what stands at zero Doppler -- the direct
+      // path's column -- is exact there already and is no reason to transform it again)
+      const cf r0 = a.R[rmap_index(nD, a.nTiles, cpi, 0, j)];
       float pw = 0.f;
 #pragma unroll
       for (int s = 0; s < HOT_SAMPLES; s++) {
         const cf r = a.R[rmap_index(nD, a.nTiles, cpi, (int)(((int64_t)(2 * s + 1) * nD) / (2 * HOT_SAMPLES)), j)];
-        pw += r.x * r.x + r.y * r.y;
+        pw += (r.x - r0.x) * (r.x - r0.x) + (r.y - r0.y) * (r.y - r0.y);
       }
       db = 5.f * log10f(pw * (1.f / HOT_SAMPLES)); // 10 log10 of the amplitude
     }
