@@ -16,6 +16,7 @@ from oracle import blah2_oracle as O  # noqa: E402
 from oracle import gates as G  # noqa: E402
 
 config, n_cpi, cfar = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+fir = sys.argv[4] if len(sys.argv) > 4 else "auto"  # auto: fused into the range kernel where covered (what bench.py and the replay run)
 cfg, _ = bench.CONFIGS[config]
 dmin, dmax, fmin, fmax, fs, n = cfg
 dev = torch.device("cuda", 0)
@@ -25,6 +26,10 @@ wh = b2.WienerHopf(dmin, dmax, n, max_batch=B)
 det_params = (1e-5, 2, 6, 1, 3, 5, 15.0) if cfar == "2d" else (1e-5, 2, 6, 5, 15.0)
 det = b2.CfarDetector2D(*det_params) if cfar == "2d" else b2.CfarDetector1D(*det_params)
 nD, nC = amb.get_n_doppler_bins(), amb.get_n_delay_bins()
+fused = fir != "two-stage" and amb.fir_fusable(wh, b2.FMT_C32) is None
+if fused:
+    amb.set_fir(wh)
+print(f"{config}: FIR {'fused into the range kernel' if fused else 'two-stage'}")
 CAP = 65536
 st = torch.cuda.current_stream().cuda_stream
 worst = {}
@@ -36,8 +41,12 @@ for b0 in range(0, n_cpi, B):
     met = torch.zeros((B, 2), dtype=torch.float64, device=dev)
     hits = torch.zeros((B, CAP, 2), dtype=torch.float64, device=dev)
     cnt = torch.zeros(B, dtype=torch.int32, device=dev)
-    wh.process_dev(x.data_ptr(), y.data_ptr(), B, n, yf.data_ptr(), ok.data_ptr(), st)
-    amb.process_dev(b2.FMT_C32, x.data_ptr(), yf.data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
+    if fused:
+        wh.estimate_dev_fmt(b2.FMT_C32, x.data_ptr(), y.data_ptr(), B, n, ok.data_ptr(), st)
+        amb.process_dev(b2.FMT_C32, x.data_ptr(), y.data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
+    else:
+        wh.process_dev(x.data_ptr(), y.data_ptr(), B, n, yf.data_ptr(), ok.data_ptr(), st)
+        amb.process_dev(b2.FMT_C32, x.data_ptr(), yf.data_ptr(), B, n, out.data_ptr(), met.data_ptr(), st)
     det.process_dev(amb, B, hits.data_ptr(), CAP, cnt.data_ptr(), out.data_ptr(), met.data_ptr(), st)
     torch.cuda.synchronize()
     o, m, okh, ch = out.cpu().numpy(), met.cpu().numpy(), ok.cpu().numpy(), cnt.cpu().numpy()

@@ -31,7 +31,8 @@ profile() { # tag, json description, bench args...
 PMC_EXTRA=1 profile amb '{"config": "cfg2", "batch": 256, "fmt": "c32", "chain": "amb"}' --steps 12 --warmup 3
 PMC_EXTRA= profile full '{"config": "cfg2", "batch": 256, "fmt": "c32", "chain": "full"}' --chain full --steps 6 --warmup 2
 PMC_EXTRA= profile cfg3 '{"config": "cfg3", "batch": 32, "fmt": "c32", "chain": "amb"}' --config cfg3 --steps 10 --warmup 2 --prewarm-s 0.3
-PMC_EXTRA= profile cfg3_full '{"config": "cfg3", "batch": 256, "fmt": "c32", "chain": "full"}' --config cfg3 --chain full --steps 2 --warmup 1 --prewarm-s 0.3
+PMC_EXTRA= profile cfg3_full '{"config": "cfg3", "batch": 32, "fmt": "c32", "chain": "full", "fir": "fused"}' --config cfg3 --chain full --cfar 2d --batch 32 --streams 2 --steps 10 --warmup 2 --prewarm-s 0.3
+PMC_EXTRA= profile cfg3_full_twostage '{"config": "cfg3", "batch": 32, "fmt": "c32", "chain": "full-two-stage", "fir": "two-stage"}' --config cfg3 --chain full --cfar 2d --batch 32 --streams 2 --fir two-stage --steps 10 --warmup 2 --prewarm-s 0.3
 PMC_EXTRA= profile cfg5 '{"config": "cfg5", "batch": 8, "fmt": "f16", "chain": "amb"}' --config cfg5 --fmt f16 --steps 10 --warmup 2
 mkdir -p $OUT/cal
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/cal/fetch -o cal --output-format csv -- $REPO/tools/membench/pmccal > $OUT/cal/fetch.log 2>&1
@@ -40,14 +41,15 @@ prune $OUT/cal
 cd $REPO
 rm -f $OUT/bench_r6*.log
 python bench.py > $OUT/bench_r6.log 2>&1                      # the default line: headline + configs[] legs + cpu_baseline + e2e_host
-python bench.py --fmt i16 --no-cpu-baseline --no-configs > $OUT/bench_r6_i16.log 2>&1
-python bench.py --chain full --steps 20 --no-cpu-baseline --no-configs > $OUT/bench_r6_full.log 2>&1
-python bench.py --config cfg3 --steps 20 --warmup 3 --no-cpu-baseline --no-configs > $OUT/bench_r6_cfg3.log 2>&1
-python bench.py --config cfg3 --chain full --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $OUT/bench_r6_cfg3_full.log 2>&1
-python bench.py --config cfg5 --fmt f16 --steps 10 --warmup 2 --no-cpu-baseline --no-configs > $OUT/bench_r6_cfg5.log 2>&1
-python bench.py --batch 1 --steps 2000 --warmup 50 --no-cpu-baseline --no-configs > $OUT/bench_r6_b1.log 2>&1
-python bench.py --chain full --cfar 1d --batch 1 --steps 500 --warmup 20 --no-cpu-baseline --no-configs > $OUT/bench_r6_full_b1.log 2>&1
-python bench.py --config small --steps 40 --warmup 3 --no-cpu-baseline --no-configs > $OUT/bench_r6_small.log 2>&1
+python bench.py --fmt i16 --no-cpu-baseline --no-configs --no-replay > $OUT/bench_r6_i16.log 2>&1
+python bench.py --chain full --steps 20 --no-cpu-baseline --no-configs --no-replay > $OUT/bench_r6_full.log 2>&1
+python bench.py --config cfg3 --steps 20 --warmup 3 --no-cpu-baseline --no-configs --no-replay > $OUT/bench_r6_cfg3.log 2>&1
+python bench.py --config cfg3 --chain full --cfar 2d --batch 32 --streams 2 --steps 20 --warmup 3 --no-cpu-baseline --no-configs --no-replay > $OUT/bench_r6_cfg3_full.log 2>&1
+python bench.py --config cfg3 --chain full --cfar 2d --batch 32 --streams 2 --fir two-stage --steps 20 --warmup 3 --no-cpu-baseline --no-configs --no-replay > $OUT/bench_r6_cfg3_full_twostage.log 2>&1
+python bench.py --config cfg5 --fmt f16 --steps 10 --warmup 2 --no-cpu-baseline --no-configs --no-replay > $OUT/bench_r6_cfg5.log 2>&1
+python bench.py --batch 1 --steps 2000 --warmup 50 --no-cpu-baseline --no-configs --no-replay > $OUT/bench_r6_b1.log 2>&1
+python bench.py --chain full --cfar 1d --batch 1 --steps 500 --warmup 20 --no-cpu-baseline --no-configs --no-replay > $OUT/bench_r6_full_b1.log 2>&1
+python bench.py --config small --steps 40 --warmup 3 --no-cpu-baseline --no-configs --no-replay > $OUT/bench_r6_small.log 2>&1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_r6_torchrun.log 2>&1
 # the Toeplitz solve on its own: HIP-event time per launch by taps / batch / form, and rocprofv3's kernel durations of the same
 python tools/gpu_solve.py --json $OUT/solve_timing.json > $OUT/solve_timing.log 2>&1
@@ -57,5 +59,9 @@ mkdir -p $OUT/prof/solve
 mkdir -p $OUT/prof/b1
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof/b1/trace -o bench --output-format csv -- python $REPO/bench.py --batch 1 --steps 500 --warmup 20 --no-cpu-baseline --no-parity --no-configs > $OUT/prof/b1/trace.log 2>&1)
 prune $OUT/prof/solve; prune $OUT/prof/b1
+# the fused FIR + range kernel beside the two kernels it replaces (configs[2], 16 CPIs per launch)
+bash $REPO/tools/prof_fused_ab.sh 16 10 > $OUT/fused_fir_ab.txt 2>&1
+# the spread of the full chain's gates over 16 CPIs of configs[2] and configs[1]
+(python $REPO/tools/gpu_chain_gate_stats.py cfg3 16 2d; python $REPO/tools/gpu_chain_gate_stats.py cfg2 16 1d) 2>&1 | grep -v amdgpu > $OUT/chain_gate_stats.txt
 du -sh $OUT
 tail -qn 1 $OUT/bench_r6*.log | cut -c1-200

@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 
-KERNELS = ("rangeps_kernel", "rangew1k_kernel", "rangew_kernel", "range8_kernel", "range_kernel", "doppler_tilew2_kernel", "doppler_tilew_kernel", "doppler_tilem_kernel", "doppler_tile1k_kernel", "doppler_sub1k_kernel", "doppler_tile_kernel", "doppler_fft_kernel",
+KERNELS = ("range_fir_kernel", "taps_spectrum_kernel", "hot_columns_kernel", "leak_fix_kernel", "rangeps_kernel", "rangew1k_kernel", "rangew_kernel", "range8_kernel", "range_kernel", "doppler_tilew2_kernel", "doppler_tilew_kernel", "doppler_tilem_kernel", "doppler_tile1k_kernel", "doppler_sub1k_kernel", "doppler_tile_kernel", "doppler_fft_kernel",
            "doppler_dft_kernel", "metrics_kernel", "cfar1d_kernel", "cfar2d_stream_kernel", "cfar2d_tile_kernel", "cfar2d_kernel", "sat_rows_kernel", "sat_cols_kernel",
            "rotate_kernel", "clutter_corr_half_kernel", "clutter_corr_kernel", "clutter_fir_kernel", "clutter_solve_la_kernel", "clutter_solve_kernel", "solve_epoch_kernel", "clutter_reduce_kernel",
            "db_map_kernel", "cal_")
