@@ -510,14 +510,16 @@ struct SolveScal {
   double pad;
 };
 
-template <int K>
+// SINGLE: ONE buffer of n + 1 entries and a second barrier per order (operands read | barrier | written | barrier): 8192 taps
+// fit the LDS that the double-buffered form fills at 5054.  The long filters' solve (blah2hip_clutter_create); ~1 us an order.
+template <int K, bool SINGLE = false>
 __global__ __launch_bounds__(1024) void clutter_solve_kernel(SolveArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n = a.nBins;
   // two buffers of n + 1 entries (entry n stays zero: "F[m]" as seen by index 0), then the scalars
   dcx *cur = reinterpret_cast<dcx *>(smem);
-  dcx *nxt = cur + (n + 1);
+  dcx *nxt = SINGLE ? cur : cur + (n + 1);
   SolveScal *scal = reinterpret_cast<SolveScal *>(nxt + (n + 1)); // [parity]
   const int cpi = blockIdx.x;
   const int t = threadIdx.x, NT = blockDim.x;
@@ -573,6 +575,7 @@ __global__ __launch_bounds__(1024) void clutter_solve_kernel(SolveArgs a)
     const double rsn = q.rs * fast_rcp(D); // 1 / s_{m+1}
     const dcx dt = {q.d.x * rsn, q.d.y * rsn};
     const dcx efc = {q.ef.x, -q.ef.y};
+    if (SINGLE) __syncthreads(); // every operand of this order has been read
 #pragma unroll
     for (int k = 0; k < K; k++) {
       const int j = t + NT * k;
@@ -803,6 +806,12 @@ struct blah2hip_clutter_s {
   int32_t *lastOk = nullptr; // where the last process call wrote its flags
   hipStream_t lastStream = nullptr; // ... and the stream it was enqueued on (blah2hip_clutter_get_info waits for that one only)
   KernelTimer<BLAH2HIP_CK_COUNT> timer;
+  int stages = 7;            // launch_clutter runs: 1 correlations + reduction, 2 solve, 4 FIR (the long form drives its children piecewise)
+  // LONG filters (more than F - 15 = 4081 taps, up to LONG_MAX_BINS; see long_process): two children of LONG_C taps run the
+  // correlations (first lag = this filter's) and the FIR (first lag 0, on pre-shifted planes) chunk by chunk
+  blah2hip_clutter_s *subCorr = nullptr, *subFir = nullptr;
+  int nChunks = 0;
+  cf *d_long = nullptr;      // [3][maxBatch][N]: private copies of x and y (the output is built in the y copy) + one work plane
 };
 
 namespace {
@@ -925,6 +934,11 @@ int clutter_plan(blah2hip_clutter_s *h)
 // latency-bound), 2 up to 2048, 4 above
 void launch_solve_stepwise(blah2hip_clutter_s *h, const SolveArgs &sa, uint32_t nCpi, hipStream_t st)
 {
+  if (h->nBins > 4096) { // the long filters: one buffer, eight indices per thread
+    const size_t sl1 = ((size_t)h->nBins + 1) * sizeof(dcx) + 2 * sizeof(SolveScal);
+    hipLaunchKernelGGL((clutter_solve_kernel<8, true>), dim3(nCpi), dim3(1024), sl1, st, sa);
+    return;
+  }
   const size_t sl = ((size_t)2 * (h->nBins + 1)) * sizeof(dcx) + 2 * sizeof(SolveScal);
   const int kper = h->solveK ? h->solveK : (h->nBins > 2048 ? 4 : (h->nBins > 1024 ? 2 : 1));
   const int nt = std::min(1024, 64 * ((h->nBins + 64 * kper - 1) / (64 * kper)));
@@ -941,6 +955,7 @@ int launch_solve(blah2hip_clutter_s *h, const SolveArgs &sa, uint32_t nCpi, hipS
   CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<1>, 160 * 1024 - 2048));
   CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<2>, 160 * 1024 - 2048));
   CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<4>, 160 * 1024 - 2048));
+  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<8, true>, 160 * 1024 - 2048));
   CHIP(h->timer.tic(BLAH2HIP_CK_SOLVE, st));
   if (h->solveForm != BLAH2HIP_CLUTTER_SOLVE_STEPWISE && h->d_mail) {
     // blocks of 32 orders on several workgroups per CPI (solve_la.hpp): as many CUs per CPI as the launch leaves free
@@ -1004,6 +1019,7 @@ template <int R3, class In> int launch_clutter(blah2hip_clutter_s *h, const void
   auto up8 = [](int v) { return std::max(8, (v + 7) & ~7); };
   const int nJobs = std::min(h->nJobs, up8((2 * slots + (int)nCpi - 1) / (int)nCpi));
   const int firGrid = std::min(h->firGrid, up8((2 * slots + (int)nCpi - 1) / (int)nCpi));
+  if (h->stages & 1) {
   CHIP(h->timer.tic(BLAH2HIP_CK_CORR, st));
   if (h->corrHalf) {
     CHIP(blah2hip_ensure_lds_((const void *)clutter_corr_half_kernel<R3, In>, (int)lds));
@@ -1029,17 +1045,125 @@ template <int R3, class In> int launch_clutter(blah2hip_clutter_s *h, const void
   CHIP(h->timer.tic(BLAH2HIP_CK_REDUCE, st));
   hipLaunchKernelGGL(clutter_reduce_kernel, dim3((h->nBins + 15) / 16, 2, nCpi), dim3(16 * RED_SLICES), 0, st, sa);
   CHIP(h->timer.toc(BLAH2HIP_CK_REDUCE, st));
-  { const int rc_ = launch_solve(h, sa, nCpi, st); if (rc_) return rc_; }
+  if (h->stages & 2) { const int rc_ = launch_solve(h, sa, nCpi, st); if (rc_) return rc_; }
+  }
 
   FirArgs fa;
   fa.x = px; fa.y = py; fa.yout = yout; fa.cpiStride = stride; fa.outStride = outStride; fa.N = h->N; fa.xs = xs;
   fa.nBins = h->nBins; fa.segLen = h->segLen; fa.nSeg = h->nSeg; fa.w = h->d_w; fa.ok = ok; fa.tw = h->d_tw;
   fa.scale = 1.0f / (float)h->F;
   fa.carry = h->firCarry ? 1 : 0;
-  if (yout) { // nullptr: the taps only (blah2hip_clutter_estimate_dev_fmt: the FIR runs fused into the range kernel)
+  if (yout && (h->stages & 4)) { // nullptr: the taps only (blah2hip_clutter_estimate_dev_fmt: the FIR runs fused into the range kernel)
     CHIP(h->timer.tic(BLAH2HIP_CK_FIR, st));
     hipLaunchKernelGGL((clutter_fir_kernel<R3, In>), dim3(firGrid, nCpi), dim3(W::T), lds, st, fa);
     CHIP(hipGetLastError());
+    CHIP(h->timer.toc(BLAH2HIP_CK_FIR, st));
+  }
+  h->lastOk = ok;
+  h->lastStream = st;
+  return BLAH2HIP_OK;
+}
+
+// ---- LONG filters: more taps than one transform holds --------------------------------------------------------------
+// WienerHopf.cpp takes any nBins (a dense nBins x nBins Cholesky and FFTs of the whole CPI).  The kernels above hold
+// nBins <= F - 15 = 4081.  Beyond that -- up to LONG_MAX_BINS = 8192, what the one-workgroup solve holds in LDS -- the same
+// kernels run chunk by chunk of LONG_C = 2048 lags / taps on rotated or shifted copies of the channels:
+//   b[cC + j] = sum_n y[n] conj(xs[n - cC - j]) = the child's b[j] with y rotated by cC            (circular, :100-108)
+//   r[cC + j] = the same with xs in y's place                                                       (:76-84)
+//   y - (w * xs) = y - sum_c (w[cC ...] * xs delayed by cC, zeros shifted in)                       (linear, :125-160)
+// with xs[i] = x[(uint32(i) - uint32(delayMin)) mod N] (:61-70, the reference's own unsigned arithmetic).  One child handle
+// (first lag = this filter's) does the correlations, a second (first lag 0: its xs IS its x) the FIR passes; the solve is
+// clutter_solve_kernel<8, true>.  fp32 planes only.  A rarely used form, built for coverage rather than speed: 2 nChunks - 1
+// correlation passes and nChunks FIR passes over the CPI, ~1 us per order of the solve.
+constexpr int LONG_C = 2048;
+constexpr int LONG_MAX_BINS = 8192;
+
+// planes [nCpi][N] out of planes [nCpi][N] (every index below 2^31: no overflow in uint32):
+// MODE 0: dst[m] = src[(m + off) mod N]                      (y rotated)
+// MODE 1: dst[m] = xs[(m + off) mod N]                       (xs rotated; src = x)
+// MODE 2: dst[m] = m >= off ? xs[m - off] : 0                (xs delayed, zeros shifted in; src = x)
+// xs[i] = x[(uint32(i) - uint32(delayMin)) mod N]: the reference's own unsigned arithmetic (WienerHopf.cpp:61-70)
+// (A first version with the mode as a run-time argument and a grid-stride loop faulted on gfx950 -- in a stand-alone
+// program too; this one is one sample per thread and a compile-time mode.)
+template <int MODE>
+__global__ __launch_bounds__(256) void long_plane_kernel(const cf *src, cf *dst, uint32_t N, uint32_t off, uint32_t dmin)
+{
+  const cf *s = src + (size_t)blockIdx.y * N;
+  cf *d = dst + (size_t)blockIdx.y * N;
+  const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+  if (m >= N) return;
+  cf v = cmake(0.f, 0.f);
+  if (MODE == 0) v = s[(m + off) % N];
+  if (MODE == 1) v = s[(((m + off) % N) - dmin) % N];
+  if (MODE == 2 && m >= off) v = s[((m - off) - dmin) % N];
+  d[m] = v;
+}
+
+// which 0: the child's b -> b[cC + j]; 1: the child's r -> r[cC + j] (chunk 0); 2: the child's b -> r[cC + j]
+__global__ __launch_bounds__(256) void long_gather_kernel(const dcx *sub, dcx *big, int C, int n, int c, int which)
+{
+  const int j = blockIdx.x * 256 + threadIdx.x, cpi = blockIdx.y;
+  const int k = c * C + j;
+  if (j >= C || k >= n) return;
+  const dcx v = sub[((size_t)cpi * 2 + (which == 1 ? 0 : 1)) * C + j];
+  big[((size_t)cpi * 2 + (which == 0 ? 1 : 0)) * n + k] = v;
+}
+
+// the FIR child's taps of chunk c: w[cC + j], zeros behind the filter's last tap
+__global__ __launch_bounds__(256) void long_taps_kernel(const cf *w, cf *wsub, int C, int n, int c)
+{
+  const int j = blockIdx.x * 256 + threadIdx.x, cpi = blockIdx.y;
+  if (j >= C) return;
+  const int k = c * C + j;
+  wsub[(size_t)cpi * C + j] = k < n ? w[(size_t)cpi * n + k] : cmake(0.f, 0.f);
+}
+
+int long_process(blah2hip_clutter_s *h, const cf *d_x, const cf *d_y, uint32_t nCpi, int64_t stride, cf *yout, int64_t outStride,
+                 int32_t *ok, hipStream_t st)
+{
+  const uint32_t N = h->N, dmin = (uint32_t)h->delayMin;
+  const int n = h->nBins, C = LONG_C;
+  const size_t plane = (size_t)h->maxBatch * N;
+  cf *xp = h->d_long, *yp = xp + plane, *wp = yp + plane;
+  const dim3 pg((N + 255) / 256, nCpi), gg((C + 255) / 256, nCpi);
+  blah2hip_clutter_s *sc = h->subCorr, *sf = h->subFir;
+  // private copies with the children's stride (the caller's may differ from N); the output is built in the copy of y
+  CHIP(hipMemcpy2DAsync(xp, (size_t)N * sizeof(cf), d_x, (size_t)stride * sizeof(cf), (size_t)N * sizeof(cf), nCpi, hipMemcpyDeviceToDevice, st));
+  CHIP(hipMemcpy2DAsync(yp, (size_t)N * sizeof(cf), d_y, (size_t)stride * sizeof(cf), (size_t)N * sizeof(cf), nCpi, hipMemcpyDeviceToDevice, st));
+  sc->stages = 1;
+  for (int c = 0; c < h->nChunks; c++) {
+    const cf *yin = yp;
+    if (c > 0) {
+      long_plane_kernel<0><<<pg, 256, 0, st>>>(yp, wp, N, (uint32_t)(c * C), 0u);
+      yin = wp;
+    }
+    int rc = launch_clutter<16, InC32>(sc, xp, yin, nCpi, (int64_t)N, nullptr, 0, ok, st);
+    if (rc) return rc;
+    long_gather_kernel<<<gg, 256, 0, st>>>(sc->d_rb, h->d_rb, C, n, c, 0);
+    if (c == 0) {
+      long_gather_kernel<<<gg, 256, 0, st>>>(sc->d_rb, h->d_rb, C, n, c, 1);
+    } else {
+      long_plane_kernel<1><<<pg, 256, 0, st>>>(xp, wp, N, (uint32_t)(c * C), dmin);
+      rc = launch_clutter<16, InC32>(sc, xp, wp, nCpi, (int64_t)N, nullptr, 0, ok, st);
+      if (rc) return rc;
+      long_gather_kernel<<<gg, 256, 0, st>>>(sc->d_rb, h->d_rb, C, n, c, 2);
+    }
+    CHIP(hipGetLastError());
+  }
+  SolveArgs sa;
+  sa.partial = nullptr; sa.rb = h->d_rb; sa.w = h->d_w; sa.ok = ok; sa.nBins = n; sa.nJobs = 0; sa.epoch = h->d_epoch;
+  { const int rc = launch_solve(h, sa, nCpi, st); if (rc) return rc; }
+  if (yout) {
+    sf->stages = 4;
+    CHIP(h->timer.tic(BLAH2HIP_CK_FIR, st));
+    for (int c = 0; c < h->nChunks; c++) {
+      long_taps_kernel<<<gg, 256, 0, st>>>(h->d_w, sf->d_w, C, n, c);
+      long_plane_kernel<2><<<pg, 256, 0, st>>>(xp, wp, N, (uint32_t)(c * C), dmin);
+      CHIP(hipGetLastError());
+      const int rc = launch_clutter<16, InC32>(sf, wp, yp, nCpi, (int64_t)N, yp, (int64_t)N, ok, st); // in place: y -= w_c * xs_c
+      if (rc) return rc;
+    }
+    CHIP(hipMemcpy2DAsync(yout, (size_t)outStride * sizeof(cf), yp, (size_t)N * sizeof(cf), (size_t)N * sizeof(cf), nCpi, hipMemcpyDeviceToDevice, st));
     CHIP(h->timer.toc(BLAH2HIP_CK_FIR, st));
   }
   h->lastOk = ok;
@@ -1068,9 +1192,12 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
     CFAIL(BLAH2HIP_ERR_NO_DEVICE, "no HIP device visible (the HIP path is the only path)");
   if (device < 0 || device >= ndev) CFAIL(BLAH2HIP_ERR_INVALID, "device index out of range");
   CHIP(hipSetDevice(device));
-  // the solve keeps two fp64 vectors of nBins in LDS and 4 indices per thread at most
-  if (((size_t)2 * nBins + 16) * sizeof(dcx) > 160 * 1024 - 2048 || nBins > 4096)
-    CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "nBins too large for the on-chip Toeplitz solve");
+  // beyond one transform (nBins > F - 15 = 4081): the long form, chunks of LONG_C taps on two child handles (long_process);
+  // its one-workgroup solve holds one fp64 vector of nBins in LDS, eight indices per thread
+  const bool isLong = nBins > 4096 - 15;
+  if (nBins > LONG_MAX_BINS)
+    CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "more than 8192 taps: the Toeplitz solve's vector does not fit the LDS of one workgroup");
+  if (isLong && (uint32_t)nBins > n_samples) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "a long filter (more than 4081 taps) needs nBins <= nSamples");
   auto *h = new blah2hip_clutter_s;
   // everything that can fail runs inside `build`; a partially built handle is torn down by destroy()
   auto build = [&]() -> int {
@@ -1081,10 +1208,21 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
   CHIP(hipGetDeviceProperties(&prop, device));
   h->numCU = prop.multiProcessorCount;
   CHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  { const int rc_ = clutter_plan(h); if (rc_) return rc_; }
   CHIP(hipMalloc(&h->d_rb, (size_t)max_batch * 2 * nBins * sizeof(dcx)));
   CHIP(hipMalloc(&h->d_w, (size_t)max_batch * nBins * sizeof(cf)));
   CHIP(hipMalloc(&h->d_ok, max_batch * sizeof(int32_t)));
+  if (isLong) {
+    h->nChunks = (nBins + LONG_C - 1) / LONG_C;
+    h->solveForm = BLAH2HIP_CLUTTER_SOLVE_STEPWISE;
+    { const int rc_ = blah2hip_clutter_create(delay_min, delay_min + LONG_C, n_samples, device, max_batch, &h->subCorr); if (rc_) return rc_; }
+    { const int rc_ = blah2hip_clutter_create(0, LONG_C, n_samples, device, max_batch, &h->subFir); if (rc_) return rc_; }
+    h->r3 = h->subFir->r3; h->F = h->subFir->F; h->segLen = h->subFir->segLen; h->nSeg = h->subFir->nSeg;
+    CHIP(hipMalloc(&h->d_long, (size_t)3 * max_batch * n_samples * sizeof(cf)));
+    CHIP(hipMalloc(&h->d_epoch, 4 * sizeof(uint32_t)));
+    CHIP(hipMemset(h->d_epoch, 0, 4 * sizeof(uint32_t)));
+    return BLAH2HIP_OK;
+  }
+  { const int rc_ = clutter_plan(h); if (rc_) return rc_; }
   { const int rc_ = solve_la_alloc(h); if (rc_) return rc_; }
   return BLAH2HIP_OK;
   };
@@ -1102,8 +1240,10 @@ int blah2hip_clutter_destroy(blah2hip_clutter_t h)
   if (!h) return BLAH2HIP_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->subCorr) (void)blah2hip_clutter_destroy(h->subCorr);
+  if (h->subFir) (void)blah2hip_clutter_destroy(h->subFir);
   for (void *p : {(void *)h->d_tw, (void *)h->d_partial, (void *)h->d_rb, (void *)h->d_w, (void *)h->d_ok,
-                  (void *)h->d_stage, (void *)h->d_mail, (void *)h->d_epoch})
+                  (void *)h->d_stage, (void *)h->d_mail, (void *)h->d_epoch, (void *)h->d_long})
     if (p) (void)hipFree(p);
   h->timer.destroy();
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1162,6 +1302,7 @@ int blah2hip_clutter_read_last(blah2hip_clutter_t h, uint32_t cpi, float *w, dou
 int blah2hip_clutter_set_option(blah2hip_clutter_t h, int option, int64_t value)
 {
   if (!h) CFAIL(BLAH2HIP_ERR_INVALID, "NULL handle");
+  if (h->subCorr) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "a long filter (more than 4081 taps) has one plan: no options");
   switch (option) {
   case BLAH2HIP_CLUTTER_OPT_SOLVE_K:
     if (value != 0 && value != 1 && value != 2 && value != 4) CFAIL(BLAH2HIP_ERR_INVALID, "indices per thread: 0 (auto), 1, 2 or 4");
@@ -1259,6 +1400,7 @@ int blah2hip_clutter_set_timing(blah2hip_clutter_t h, int enable)
 {
   if (!h) CFAIL(BLAH2HIP_ERR_INVALID, "NULL handle");
   h->timer.enabled = enable != 0;
+  if (h->subCorr) h->subCorr->timer.enabled = enable != 0; // the long form: correlations and reduction are the child's launches
   return BLAH2HIP_OK;
 }
 
@@ -1268,6 +1410,12 @@ int blah2hip_clutter_get_timing(blah2hip_clutter_t h, double *ms_total, uint32_t
   CHIP(hipSetDevice(h->device));
   CHIP(hipDeviceSynchronize());
   CHIP(h->timer.collect(ms_total, launches));
+  if (h->subCorr) { // correlations + reduction of the long form (its FIR passes and solve are bracketed on this handle)
+    double ms[BLAH2HIP_CK_COUNT];
+    uint32_t nl[BLAH2HIP_CK_COUNT];
+    CHIP(h->subCorr->timer.collect(ms, nl));
+    for (int k : {BLAH2HIP_CK_CORR, BLAH2HIP_CK_REDUCE}) { ms_total[k] += ms[k]; launches[k] += nl[k]; }
+  }
   return BLAH2HIP_OK;
 }
 
@@ -1288,6 +1436,10 @@ int blah2hip_clutter_process_dev_fmt(blah2hip_clutter_t h, int fmt, const void *
   // thread that writes it, and x is never written
   const int64_t cs = (int64_t)cpi_stride, os = (int64_t)out_stride;
   cf *yo = (cf *)d_y_out;
+  if (h->subCorr) {
+    if (fmt != BLAH2HIP_FMT_C32) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "a long filter (more than 4081 taps) takes fp32 planes only");
+    return long_process(h, (const cf *)d_x, (const cf *)d_y, n_cpi, cs, yo, os, ok, st);
+  }
   if (fmt == BLAH2HIP_FMT_I16) {
     switch (h->r3) {
     case 4: return launch_clutter<4, InI16>(h, d_x, nullptr, n_cpi, cs, yo, os, ok, st);
@@ -1314,6 +1466,10 @@ int blah2hip_clutter_estimate_dev_fmt(blah2hip_clutter_t h, int fmt, const void 
   hipStream_t st = (hipStream_t)stream;
   int32_t *ok = d_ok ? d_ok : h->d_ok;
   const int64_t cs = (int64_t)cpi_stride;
+  if (h->subCorr) {
+    if (fmt != BLAH2HIP_FMT_C32) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "a long filter (more than 4081 taps) takes fp32 planes only");
+    return long_process(h, (const cf *)d_x, (const cf *)d_y, n_cpi, cs, nullptr, 0, ok, st);
+  }
   if (fmt == BLAH2HIP_FMT_I16) {
     switch (h->r3) {
     case 4: return launch_clutter<4, InI16>(h, d_x, nullptr, n_cpi, cs, nullptr, 0, ok, st);

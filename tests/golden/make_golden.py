@@ -52,6 +52,9 @@ CASES = {
     # round 6: 9011 delay bins -- more than blah2hip_cfar1d_map's fp64 row used to fit (8192); delays beyond nCorr = 6000 read the
     # reference's aliased lags (Ambiguity.cpp:132-146), no Hamming rounding as in `aliased_lags`
     "wide_delay": (30_000, 30_000, -10, 9000, -2, 2, False, 28, ((5000, 1.0, 0.05), (23, -1.0, 0.05)), (-3, 20)),
+    # round 6: a clutter filter of 4610 taps -- more than one on-chip transform holds (4081): the engine runs it as three
+    # chunks of 2048 taps (csrc/clutter.hip, "LONG filters"); the reference's 4610 x 4610 Cholesky takes 45 s here
+    "long_filter": (60_000, 60_000, -10, 100, -2, 2, True, 29, ((300, 1.0, 0.05), (50, -1.0, 0.05)), (-10, 4600)),
 }
 # name -> synth_iq keyword overrides (amplitudes); everything else uses the generator's defaults
 SYNTH_KW = {"deep_cancel": dict(ref_amp=1000.0, noise_amp=1.0, direct=0.8)}

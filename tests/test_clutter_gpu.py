@@ -71,6 +71,8 @@ def test_clutter_golden_half_window_correlation(b2, name):
     g = load_golden(name)
     n = int(g["params"][1])
     dmin, dmax = (int(v) for v in g["clutter_params"])
+    if dmax - dmin > 4081:
+        pytest.skip("a long filter (chunks of 2048 taps on child handles) has one plan: tests/test_clutter_long_gpu.py")
     wh = b2.WienerHopf(dmin, dmax, n)
     wh.set_corr_form("half")
     ok, yf = wh.process(g["x"], g["y"])
