@@ -292,7 +292,12 @@ int blah2hip_interpolate(const double *delay, const double *doppler, const doubl
                          const double *doppler_axis, double noise_power, int do_delay, int do_doppler,
                          double *delay_out, double *doppler_out, double *snr_out, uint32_t *count_out);
 
-/* ---- WienerHopf clutter filter (WienerHopf.h:68-78) --------------------- */
+/* ---- WienerHopf clutter filter (WienerHopf.h:68-78) ---------------------
+ * nBins = delay_max - delay_min taps (WienerHopf.cpp:12).  Up to 4081 taps run on one on-chip transform (fp32 planes or the int16
+ * words).  4082 ... 8192 taps ("long" filters, round 6): the same kernels chunk by chunk of 2048 lags / taps on rotated and shifted
+ * copies of the channels, the Toeplitz solve in one workgroup -- fp32 planes only (BLAH2HIP_FMT_I16: ERR_UNSUPPORTED), nBins <=
+ * n_samples, no blah2hip_clutter_set_option; built for coverage, not speed (2 nChunks - 1 correlation passes, nChunks FIR passes, ~1 us
+ * per order of the solve).  More than 8192 taps: ERR_UNSUPPORTED (the reference takes any: a dense nBins x nBins Cholesky). */
 int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_samples, int device,
                             uint32_t max_batch, blah2hip_clutter_t *out);
 int blah2hip_clutter_destroy(blah2hip_clutter_t h);
