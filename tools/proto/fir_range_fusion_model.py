@@ -114,6 +114,61 @@ def fused(x, y, w, dmin_c, n_corr, n_d, lags, F):
     return R, count / n_d
 
 
+def fused_window_form(x, y, w, dmin_c, n_corr, n_d, lags, F):
+    """range_fir_kernel's sequence (csrc/kernels.hpp), transform for transform, in fp64.  Per pulse, with x masked to the pulse:
+    V_g = FFT([segment g-1 | segment g]) (block 0: the history block and segment 0 separately), the filter's output block g =
+    the last L outputs of IFFT(H V_g) at samples g L + delayMin + [0, L), y' = y - that (+ the direct products at the pulse's
+    edges), Z_g = FFT([y' block | 0]), acc += Z_g conj((-1)^m V_g) (block 0: conj X_0); one inverse at the end.
+    Returns R and the transform count per pulse."""
+    L = F // 2
+    assert lags[0] == dmin_c <= 0 and w.size <= L + 1 and lags.size <= L + 1 and n_corr >= L - dmin_c
+    n = x.size
+    H = np.fft.fft(w, F)
+    sgn = (-1.0) ** np.arange(F)
+    R = np.zeros((n_d, lags.size), dtype=np.complex128)
+    count = 0
+    SB = -(-(n_corr - dmin_c) // L)
+    for i in range(n_d):
+        p0 = i * n_corr
+        xm = np.zeros(SB * L + L, dtype=np.complex128)   # x of the pulse, zero beyond it
+        xm[:n_corr] = x[p0:p0 + n_corr]
+
+        def block_out(g, HV):
+            conv = np.fft.ifft(HV)[L:]
+            out = np.zeros(L, dtype=np.complex128)
+            for k in range(L):
+                nn = g * L + dmin_c + k
+                if not (0 <= nn < n_corr):
+                    continue
+                c = conv[k]
+                # past the pulse's end: taps kk <= nn - delayMin - nCorr reach x[p0 + nCorr ...], masked out of the window
+                for kk in range(0, min(nn - dmin_c - n_corr, w.size - 1) + 1):
+                    c += w[kk] * x[p0 + nn - dmin_c - kk]
+                # the CPI's first |delayMin| samples: in the window of pulse 0, zero in the filter's stream (xs[m < 0] = 0)
+                if i == 0:
+                    for kk in range(max(nn + 1, 0), min(nn - dmin_c, w.size - 1) + 1):
+                        c -= w[kk] * x[nn - dmin_c - kk]
+                out[k] = y[p0 + nn] - c
+            return out
+
+        hist = np.zeros(L, dtype=np.complex128)
+        if i > 0:
+            hist[:] = x[p0 - L:p0]
+        Xh, X0 = np.fft.fft(hist, F), np.fft.fft(xm[:L], F)
+        count += 2 if i > 0 else 1
+        Z = np.fft.fft(block_out(0, H * (Xh + sgn * X0)), F)
+        count += 2
+        acc = Z * np.conj(X0)
+        for g in range(1, SB):
+            V = np.fft.fft(xm[(g - 1) * L:(g + 1) * L])
+            Z = np.fft.fft(block_out(g, H * V), F)
+            count += 3
+            acc += Z * np.conj(sgn * V)
+        R[i] = np.fft.ifft(acc)[:lags.size]
+        count += 1
+    return R, count / n_d
+
+
 def geometry(n_corr, n_delay, taps, F, dmin_c):
     L = F // 2
     S = -(-n_corr // L)
