@@ -185,6 +185,12 @@ class Ambiguity:
 
     def process_dev(self, fmt, d_x, d_y, n_cpi, cpi_stride, d_map=None, d_metrics=None, stream=0):
         """Enqueue the device-resident chain on ``stream`` (raw pointers/ints)."""
+        fir = getattr(self, "_fir", None)
+        if fir is not None:
+            if fir._h is None:
+                raise Blah2HipError(_lib.ERR_INVALID, "set_fir: the WienerHopf handle has been closed")
+            if n_cpi > fir.max_batch:
+                raise Blah2HipError(_lib.ERR_INVALID, f"set_fir: {n_cpi} CPIs, the filter handle holds taps for {fir.max_batch}")
         check(self._L.blah2hip_amb_process_dev(self._h, fmt, d_x, d_y, n_cpi, cpi_stride, d_map,
                                                d_metrics, stream))
         self._gen += 1
@@ -228,6 +234,9 @@ class Ambiguity:
         else:
             p, nb, dm = wiener_hopf.taps_dev()
             check(self._L.blah2hip_amb_set_fir(self._h, p, nb, dm))
+        # the ambiguity handle reads the filter handle's device array on every call: keep it alive, and remember how many
+        # CPIs' taps it holds
+        self._fir = wiener_hopf
 
     def fir_fusable(self, wiener_hopf, fmt):
         """None if ``set_fir(wiener_hopf)`` is covered for samples in format ``fmt`` (FMT_C32 / FMT_I16), else the reason."""
@@ -427,6 +436,7 @@ class WienerHopf:
         check(L.blah2hip_clutter_create(delayMin, delayMax, nSamples, device, max_batch, C.byref(h)))
         self._h, self._L = h, L
         self.nSamples = nSamples
+        self.max_batch = max(1, int(max_batch))
         nb, fl, sl = C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(L.blah2hip_clutter_get_dims(h, C.byref(nb), C.byref(fl), C.byref(sl)))
         self.nBins, self.fft_len, self.seg_len = nb.value, fl.value, sl.value

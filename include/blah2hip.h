@@ -403,7 +403,8 @@ int blah2hip_spectrum_process_dev(blah2hip_spectrum_t h, int fmt, const void *d_
  * different order).  Supported where one 4096-point transform covers it -- the handle's transform length is 4096
  * (BLAH2HIP_OPT_FFT_LEN), n_bins <= 2049, at most 2049 delay bins in one chunk, the filter's first lag equal to the map's and
  * <= 0, symmetric Doppler limits, pulses of at least 2048 - delayMin samples, fp32 or int16 samples -- else
- * BLAH2HIP_ERR_UNSUPPORTED at the process call.  d_w = NULL switches back to the plain range kernels. */
+ * BLAH2HIP_ERR_UNSUPPORTED at the process call.  d_w = NULL switches back to the plain range kernels.  The ambiguity handle keeps
+ * the POINTER: the filter handle must outlive its use, and a process call may not ask for more CPIs than the filter handle's max_batch. */
 int blah2hip_clutter_estimate_dev_fmt(blah2hip_clutter_t h, int fmt, const void *d_x, const void *d_y, uint32_t n_cpi,
                                       uint64_t cpi_stride, int32_t *d_ok, void *stream);
 /* the handle's taps on the device ([max_batch][n_bins] complex fp32; zero where ok = 0), their count and the filter's first lag */
