@@ -772,6 +772,8 @@ struct HotArgs {
   const double *metrics;   // ... or the finished [nCpi][2] (nParts == 0: doppler_sub1k_kernel)
   uint32_t *count;         // [nCpi]: columns rewritten
   int32_t nParts, partStride, nD, nDelay, nTiles;
+  int32_t groups;          // 32-row groups a workgroup walks: 1 on small launches (latency), 4 in batches (the candidate scan,
+                           // which every workgroup repeats, is most of a launch that finds nothing)
   float ratioDb;           // 10 log10(HOT_RATIO)
 };
 
@@ -851,8 +853,6 @@ __global__ __launch_bounds__(256) void hot_columns_kernel(HotArgs a)
   double2 *W = hs, *col = hs + nD;
   for (int i = t; i < nD; i += 256) W[i] = a.W[i];
   const int r = t & (HOT_ROWS - 1), part = t / HOT_ROWS; // 8 parts of the pulse axis
-  const int o = blockIdx.x * HOT_ROWS + r;
-  const int src = ((o < nD ? o : nD - 1) + nD / 2 + 1) % nD; // Ambiguity.cpp:165
   const int chunk = (nD + 7) / 8;
   const int i0 = part * chunk, i1 = min(nD, i0 + chunk);
   for (int h = 0; h < nh; h++) {
@@ -863,31 +863,36 @@ __global__ __launch_bounds__(256) void hot_columns_kernel(HotArgs a)
       col[i] = make_double2((double)v.x, (double)v.y);
     }
     __syncthreads();
-    int idx = (int)(((int64_t)src * i0) % nD);
-    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
-    int i = i0;
-    for (; i + 1 < i1; i += 2) {
-      const double2 w0 = W[idx], v0 = col[i];
-      idx += src; if (idx >= nD) idx -= nD;
-      const double2 w1 = W[idx], v1 = col[i + 1];
-      idx += src; if (idx >= nD) idx -= nD;
-      ar = fma(v0.x, w0.x, ar); ar = fma(-v0.y, w0.y, ar);
-      ai = fma(v0.x, w0.y, ai); ai = fma(v0.y, w0.x, ai);
-      br = fma(v1.x, w1.x, br); br = fma(-v1.y, w1.y, br);
-      bi = fma(v1.x, w1.y, bi); bi = fma(v1.y, w1.x, bi);
-    }
-    if (i < i1) {
-      const double2 w0 = W[idx], v0 = col[i];
-      ar = fma(v0.x, w0.x, ar); ar = fma(-v0.y, w0.y, ar);
-      ai = fma(v0.x, w0.y, ai); ai = fma(v0.y, w0.x, ai);
-    }
-    red[part][r] = make_double2(ar + br, ai + bi);
-    __syncthreads();
-    if (t < HOT_ROWS && o < nD) {
-      double2 s = red[0][t];
+    for (int gi = 0; gi < a.groups; gi++) {
+      const int o = (blockIdx.x * a.groups + gi) * HOT_ROWS + r;
+      const int src = ((o < nD ? o : nD - 1) + nD / 2 + 1) % nD; // Ambiguity.cpp:165
+      int idx = (int)(((int64_t)src * i0) % nD);
+      double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+      int i = i0;
+      for (; i + 1 < i1; i += 2) {
+        const double2 w0 = W[idx], v0 = col[i];
+        idx += src; if (idx >= nD) idx -= nD;
+        const double2 w1 = W[idx], v1 = col[i + 1];
+        idx += src; if (idx >= nD) idx -= nD;
+        ar = fma(v0.x, w0.x, ar); ar = fma(-v0.y, w0.y, ar);
+        ai = fma(v0.x, w0.y, ai); ai = fma(v0.y, w0.x, ai);
+        br = fma(v1.x, w1.x, br); br = fma(-v1.y, w1.y, br);
+        bi = fma(v1.x, w1.y, bi); bi = fma(v1.y, w1.x, bi);
+      }
+      if (i < i1) {
+        const double2 w0 = W[idx], v0 = col[i];
+        ar = fma(v0.x, w0.x, ar); ar = fma(-v0.y, w0.y, ar);
+        ai = fma(v0.x, w0.y, ai); ai = fma(v0.y, w0.x, ai);
+      }
+      if (gi) __syncthreads(); // the previous group's sums have been read
+      red[part][r] = make_double2(ar + br, ai + bi);
+      __syncthreads();
+      if (t < HOT_ROWS && o < nD) {
+        double2 s = red[0][t];
 #pragma unroll
-      for (int p = 1; p < 8; p++) { s.x += red[p][t].x; s.y += red[p][t].y; }
-      a.map[((size_t)cpi * nD + o) * nDelay + j] = cmake((float)s.x, (float)s.y);
+        for (int p = 1; p < 8; p++) { s.x += red[p][t].x; s.y += red[p][t].y; }
+        a.map[((size_t)cpi * nD + o) * nDelay + j] = cmake((float)s.x, (float)s.y);
+      }
     }
   }
 }
@@ -1603,9 +1608,10 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     ha.partSum = h->d_partSum; ha.metrics = met; ha.count = h->d_hotCount;
     ha.nParts = nPartsUsed; ha.partStride = nPartsUsed; ha.nD = (int32_t)nD; ha.nDelay = (int32_t)nDelay; ha.nTiles = h->nTiles;
     ha.ratioDb = (float)(10.0 * std::log10(HOT_RATIO));
+    ha.groups = n_cpi >= 4 ? 4 : 1;
     const size_t lds = 2 * (size_t)nD * sizeof(double2);
     LDSCFG(hot_columns_kernel, (size_t)2 * HOT_ND_MAX * sizeof(double2));
-    hipLaunchKernelGGL(hot_columns_kernel, dim3((nD + HOT_ROWS - 1) / HOT_ROWS, n_cpi), dim3(256), lds, st, ha);
+    hipLaunchKernelGGL(hot_columns_kernel, dim3((nD + HOT_ROWS * ha.groups - 1) / (HOT_ROWS * ha.groups), n_cpi), dim3(256), lds, st, ha);
     HIPCHK(hipGetLastError());
     h->lastHot = true;
   }
