@@ -510,16 +510,14 @@ struct SolveScal {
   double pad;
 };
 
-// SINGLE: ONE buffer of n + 1 entries and a second barrier per order (operands read | barrier | written | barrier): 8192 taps
-// fit the LDS that the double-buffered form fills at 5054.  The long filters' solve (blah2hip_clutter_create); ~1 us an order.
-template <int K, bool SINGLE = false>
+template <int K>
 __global__ __launch_bounds__(1024) void clutter_solve_kernel(SolveArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n = a.nBins;
   // two buffers of n + 1 entries (entry n stays zero: "F[m]" as seen by index 0), then the scalars
   dcx *cur = reinterpret_cast<dcx *>(smem);
-  dcx *nxt = SINGLE ? cur : cur + (n + 1);
+  dcx *nxt = cur + (n + 1);
   SolveScal *scal = reinterpret_cast<SolveScal *>(nxt + (n + 1)); // [parity]
   const int cpi = blockIdx.x;
   const int t = threadIdx.x, NT = blockDim.x;
@@ -575,7 +573,6 @@ __global__ __launch_bounds__(1024) void clutter_solve_kernel(SolveArgs a)
     const double rsn = q.rs * fast_rcp(D); // 1 / s_{m+1}
     const dcx dt = {q.d.x * rsn, q.d.y * rsn};
     const dcx efc = {q.ef.x, -q.ef.y};
-    if (SINGLE) __syncthreads(); // every operand of this order has been read
 #pragma unroll
     for (int k = 0; k < K; k++) {
       const int j = t + NT * k;
@@ -598,6 +595,84 @@ __global__ __launch_bounds__(1024) void clutter_solve_kernel(SolveArgs a)
   for (int k = 0; k < K; k++) {
     const int j = t + NT * k;
     if (j < n) a.w[(size_t)cpi * n + j] = ok ? cmake((float)Acc[k].x, (float)Acc[k].y) : cmake(0.f, 0.f);
+  }
+  if (t == 0) a.ok[cpi] = ok ? 1 : 0;
+}
+
+// The same recursion for ANY n (the long filters, blah2hip_clutter_create): every vector in global memory -- per CPI cur / nxt
+// (n + 1 entries each, shared between the threads: written and read through L2, sc1, with the workgroup barrier between), U and
+// Acc (n each, touched by their owner only) -- and a loop over the indices a thread owns instead of register arrays.  A few
+// microseconds an order: built for coverage (the reference runs a dense nBins x nBins Cholesky there), not for speed.
+__device__ __forceinline__ dcx ld_l2(const dcx *p)
+{
+  return {__hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&p->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+}
+__device__ __forceinline__ void st_l2(dcx *p, dcx v)
+{
+  __hip_atomic_store(&p->x, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(1024) void clutter_solve_big_kernel(SolveArgs a, dcx *ws)
+{
+  __shared__ SolveScal scal[2];
+  const int n = a.nBins, cpi = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
+  dcx *cur = ws + (size_t)cpi * (4 * (size_t)n + 2);
+  dcx *nxt = cur + (n + 1), *U = nxt + (n + 1), *Acc = U + n;
+  const dcx *rg = a.rb + (size_t)cpi * 2 * n;
+  const double r0 = rg[0].x;
+  bool ok = (r0 > 0.0) && isfinite(r0);
+  const double inv0 = ok ? 1.0 / r0 : 0.0;
+  const dcx x0 = {rg[n].x * inv0, rg[n].y * inv0};
+  for (int j = t; j < n; j += NT) { // the first order, as clutter_solve_kernel sets it up
+    const dcx rj = rg[j], bj = rg[n + j];
+    dcx u, acc;
+    if (j == 0) {
+      u = {inv0, 0.0};
+      acc = x0;
+    } else {
+      u = {rj.x * inv0, rj.y * inv0};
+      const dcx g = dsub_mul(bj, rj, x0);
+      acc = {-g.x, -g.y};
+    }
+    st_l2(cur + j, u);
+    if (j == 1) {
+      scal[1] = SolveScal{u, {-acc.x, -acc.y}, 1.0, 0.0};
+      u = {0.0, 0.0};
+      acc = {0.0, 0.0};
+    }
+    U[j] = u;
+    Acc[j] = acc;
+  }
+  if (t == 0) { st_l2(cur + n, {0.0, 0.0}); st_l2(nxt + n, {0.0, 0.0}); }
+  __syncthreads();
+  for (int m = 1; m < n && ok; m++) {
+    const SolveScal q = scal[m & 1];
+    const double D = __builtin_fma(-q.ef.y, q.ef.y, __builtin_fma(-q.ef.x, q.ef.x, 1.0));
+    if (!(D > 0.0) || !isfinite(D)) { ok = false; break; } // uniform: every thread reads the same scalars
+    const double rsn = q.rs * fast_rcp(D);
+    const dcx dt = {q.d.x * rsn, q.d.y * rsn};
+    const dcx efc = {q.ef.x, -q.ef.y};
+    for (int j = t; j < n; j += NT) {
+      const int src = (j > m) ? j - 1 : (j == 0 ? n : m - j);
+      const dcx s = ld_l2(cur + min(src, n));
+      const dcx v = {s.x, (j > m) ? s.y : -s.y};
+      const dcx u = U[j], acc = Acc[j];
+      const dcx un = dsub_mul(u, q.ef, v);
+      const dcx vn = dsub_mul(v, efc, u);
+      const dcx an = dadd_mul(acc, dt, vn);
+      const bool hi = j > m;
+      st_l2(nxt + j, {hi ? vn.x : un.x, hi ? vn.y : un.y});
+      const bool owner = (j == m + 1);
+      if (owner) scal[(m + 1) & 1] = SolveScal{{un.x * rsn, un.y * rsn}, {-an.x, -an.y}, rsn, 0.0};
+      U[j] = {owner ? 0.0 : un.x, owner ? 0.0 : un.y};
+      Acc[j] = {owner ? 0.0 : an.x, owner ? 0.0 : an.y};
+    }
+    __syncthreads();
+    dcx *tmp = cur; cur = nxt; nxt = tmp;
+  }
+  for (int j = t; j < n; j += NT) {
+    const dcx acc = Acc[j];
+    a.w[(size_t)cpi * n + j] = ok ? cmake((float)acc.x, (float)acc.y) : cmake(0.f, 0.f);
   }
   if (t == 0) a.ok[cpi] = ok ? 1 : 0;
 }
@@ -807,11 +882,12 @@ struct blah2hip_clutter_s {
   hipStream_t lastStream = nullptr; // ... and the stream it was enqueued on (blah2hip_clutter_get_info waits for that one only)
   KernelTimer<BLAH2HIP_CK_COUNT> timer;
   int stages = 7;            // launch_clutter runs: 1 correlations + reduction, 2 solve, 4 FIR (the long form drives its children piecewise)
-  // LONG filters (more than F - 15 = 4081 taps, up to LONG_MAX_BINS; see long_process): two children of LONG_C taps run the
+  // LONG filters (more than F - 15 = 4081 taps; see long_process): two children of LONG_C taps run the
   // correlations (first lag = this filter's) and the FIR (first lag 0, on pre-shifted planes) chunk by chunk
   blah2hip_clutter_s *subCorr = nullptr, *subFir = nullptr;
   int nChunks = 0;
   cf *d_long = nullptr;      // [3][maxBatch][N]: private copies of x and y (the output is built in the y copy) + one work plane
+  dcx *d_solveWs = nullptr;  // [maxBatch][4 nBins + 2]: clutter_solve_big_kernel's vectors
 };
 
 namespace {
@@ -934,9 +1010,8 @@ int clutter_plan(blah2hip_clutter_s *h)
 // latency-bound), 2 up to 2048, 4 above
 void launch_solve_stepwise(blah2hip_clutter_s *h, const SolveArgs &sa, uint32_t nCpi, hipStream_t st)
 {
-  if (h->nBins > 4096) { // the long filters: one buffer, eight indices per thread
-    const size_t sl1 = ((size_t)h->nBins + 1) * sizeof(dcx) + 2 * sizeof(SolveScal);
-    hipLaunchKernelGGL((clutter_solve_kernel<8, true>), dim3(nCpi), dim3(1024), sl1, st, sa);
+  if (h->d_solveWs) { // the long filters: the recursion on vectors in global memory
+    hipLaunchKernelGGL(clutter_solve_big_kernel, dim3(nCpi), dim3(1024), 0, st, sa, h->d_solveWs);
     return;
   }
   const size_t sl = ((size_t)2 * (h->nBins + 1)) * sizeof(dcx) + 2 * sizeof(SolveScal);
@@ -955,7 +1030,6 @@ int launch_solve(blah2hip_clutter_s *h, const SolveArgs &sa, uint32_t nCpi, hipS
   CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<1>, 160 * 1024 - 2048));
   CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<2>, 160 * 1024 - 2048));
   CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<4>, 160 * 1024 - 2048));
-  CHIP(blah2hip_ensure_lds_((const void *)clutter_solve_kernel<8, true>, 160 * 1024 - 2048));
   CHIP(h->timer.tic(BLAH2HIP_CK_SOLVE, st));
   if (h->solveForm != BLAH2HIP_CLUTTER_SOLVE_STEPWISE && h->d_mail) {
     // blocks of 32 orders on several workgroups per CPI (solve_la.hpp): as many CUs per CPI as the launch leaves free
@@ -1066,17 +1140,16 @@ template <int R3, class In> int launch_clutter(blah2hip_clutter_s *h, const void
 
 // ---- LONG filters: more taps than one transform holds --------------------------------------------------------------
 // WienerHopf.cpp takes any nBins (a dense nBins x nBins Cholesky and FFTs of the whole CPI).  The kernels above hold
-// nBins <= F - 15 = 4081.  Beyond that -- up to LONG_MAX_BINS = 8192, what the one-workgroup solve holds in LDS -- the same
+// nBins <= F - 15 = 4081.  Beyond that -- any nBins <= nSamples -- the same
 // kernels run chunk by chunk of LONG_C = 2048 lags / taps on rotated or shifted copies of the channels:
 //   b[cC + j] = sum_n y[n] conj(xs[n - cC - j]) = the child's b[j] with y rotated by cC            (circular, :100-108)
 //   r[cC + j] = the same with xs in y's place                                                       (:76-84)
 //   y - (w * xs) = y - sum_c (w[cC ...] * xs delayed by cC, zeros shifted in)                       (linear, :125-160)
 // with xs[i] = x[(uint32(i) - uint32(delayMin)) mod N] (:61-70, the reference's own unsigned arithmetic).  One child handle
 // (first lag = this filter's) does the correlations, a second (first lag 0: its xs IS its x) the FIR passes; the solve is
-// clutter_solve_kernel<8, true>.  fp32 planes only.  A rarely used form, built for coverage rather than speed: 2 nChunks - 1
+// clutter_solve_kernel<11, true, 768>.  fp32 planes only.  A rarely used form, built for coverage rather than speed: 2 nChunks - 1
 // correlation passes and nChunks FIR passes over the CPI, ~1 us per order of the solve.
 constexpr int LONG_C = 2048;
-constexpr int LONG_MAX_BINS = 8192;
 
 // planes [nCpi][N] out of planes [nCpi][N] (every index below 2^31: no overflow in uint32):
 // MODE 0: dst[m] = src[(m + off) mod N]                      (y rotated)
@@ -1195,8 +1268,7 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
   // beyond one transform (nBins > F - 15 = 4081): the long form, chunks of LONG_C taps on two child handles (long_process);
   // its one-workgroup solve holds one fp64 vector of nBins in LDS, eight indices per thread
   const bool isLong = nBins > 4096 - 15;
-  if (nBins > LONG_MAX_BINS)
-    CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "more than 8192 taps: the Toeplitz solve's vector does not fit the LDS of one workgroup");
+  // (more taps than samples: the reference reads its nSamples correlation lags out of bounds, WienerHopf.cpp:76-108)
   if (isLong && (uint32_t)nBins > n_samples) CFAIL(BLAH2HIP_ERR_UNSUPPORTED, "a long filter (more than 4081 taps) needs nBins <= nSamples");
   auto *h = new blah2hip_clutter_s;
   // everything that can fail runs inside `build`; a partially built handle is torn down by destroy()
@@ -1218,6 +1290,7 @@ int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_sam
     { const int rc_ = blah2hip_clutter_create(0, LONG_C, n_samples, device, max_batch, &h->subFir); if (rc_) return rc_; }
     h->r3 = h->subFir->r3; h->F = h->subFir->F; h->segLen = h->subFir->segLen; h->nSeg = h->subFir->nSeg;
     CHIP(hipMalloc(&h->d_long, (size_t)3 * max_batch * n_samples * sizeof(cf)));
+    CHIP(hipMalloc(&h->d_solveWs, (size_t)max_batch * (4 * (size_t)nBins + 2) * sizeof(dcx)));
     CHIP(hipMalloc(&h->d_epoch, 4 * sizeof(uint32_t)));
     CHIP(hipMemset(h->d_epoch, 0, 4 * sizeof(uint32_t)));
     return BLAH2HIP_OK;
@@ -1243,7 +1316,7 @@ int blah2hip_clutter_destroy(blah2hip_clutter_t h)
   if (h->subCorr) (void)blah2hip_clutter_destroy(h->subCorr);
   if (h->subFir) (void)blah2hip_clutter_destroy(h->subFir);
   for (void *p : {(void *)h->d_tw, (void *)h->d_partial, (void *)h->d_rb, (void *)h->d_w, (void *)h->d_ok,
-                  (void *)h->d_stage, (void *)h->d_mail, (void *)h->d_epoch, (void *)h->d_long})
+                  (void *)h->d_stage, (void *)h->d_mail, (void *)h->d_epoch, (void *)h->d_long, (void *)h->d_solveWs})
     if (p) (void)hipFree(p);
   h->timer.destroy();
   if (h->stream) (void)hipStreamDestroy(h->stream);

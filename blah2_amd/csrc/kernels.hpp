@@ -231,8 +231,17 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
   cf *P = reinterpret_cast<cf *>(smem);
   cf *Q = P + W::A_ELEMS;
   const int t = threadIdx.x;
+#ifdef B2_FIR_TW3_LDS // experiment: the stage-3 twiddles (they depend on t % 16 only) in a 16 x 15 table behind the exchange buffers
+  cf tw1[15];
+  W::load_tw1(t, a.tw, tw1);
+  cf *T3 = Q + W::B_ELEMS;
+  if (t < 240) T3[t] = a.tw[(16 * (t / 15) * (t % 15 + 1)) & (W::F - 1)];
+  __syncthreads();
+  const cf *tw3 = T3 + (t & 15) * 15;
+#else
   cf tw1[15], tw3[16];
   W::load_twiddles(t, a.tw, tw1, tw3);
+#endif
   const float sgn = ((t >> 4) & 1) ? -1.f : 1.f; // (-1)^m of this thread's spectrum registers (m = q + 16 r + 256 s, q = t >> 4)
   const RangePlan p = a.plan;
   const int dmin = p.delayMin; // = the clutter window's first lag (launcher), <= 0

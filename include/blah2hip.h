@@ -294,10 +294,11 @@ int blah2hip_interpolate(const double *delay, const double *doppler, const doubl
 
 /* ---- WienerHopf clutter filter (WienerHopf.h:68-78) ---------------------
  * nBins = delay_max - delay_min taps (WienerHopf.cpp:12).  Up to 4081 taps run on one on-chip transform (fp32 planes or the int16
- * words).  4082 ... 8192 taps ("long" filters, round 6): the same kernels chunk by chunk of 2048 lags / taps on rotated and shifted
- * copies of the channels, the Toeplitz solve in one workgroup -- fp32 planes only (BLAH2HIP_FMT_I16: ERR_UNSUPPORTED), nBins <=
- * n_samples, no blah2hip_clutter_set_option; built for coverage, not speed (2 nChunks - 1 correlation passes, nChunks FIR passes, ~1 us
- * per order of the solve).  More than 8192 taps: ERR_UNSUPPORTED (the reference takes any: a dense nBins x nBins Cholesky). */
+ * words).  More ("long" filters, round 6): the same kernels chunk by chunk of 2048 lags / taps on rotated and shifted copies of the
+ * channels, the Toeplitz solve by one workgroup on vectors in global memory -- fp32 planes only (BLAH2HIP_FMT_I16: ERR_UNSUPPORTED),
+ * no blah2hip_clutter_set_option; built for coverage, not speed (2 nChunks - 1 correlation passes, nChunks FIR passes, a few
+ * microseconds per order of the solve).  nBins > n_samples: ERR_UNSUPPORTED (the reference reads its n_samples correlation lags out
+ * of bounds there, WienerHopf.cpp:76-108). */
 int blah2hip_clutter_create(int32_t delay_min, int32_t delay_max, uint32_t n_samples, int device,
                             uint32_t max_batch, blah2hip_clutter_t *out);
 int blah2hip_clutter_destroy(blah2hip_clutter_t h);

@@ -1,7 +1,7 @@
 """GPU: clutter filters of more than 4081 taps (csrc/clutter.hip, "LONG filters"; WienerHopf.cpp:58-163 takes any nBins).
 
-One on-chip transform holds 4081 taps.  Up to 8192 the engine runs the same kernels chunk by chunk of 2048 lags / taps on
-rotated and shifted copies of the channels and solves the normal equations in one workgroup with a single LDS buffer.
+One on-chip transform holds 4081 taps.  Beyond, the engine runs the same kernels chunk by chunk of 2048 lags / taps on
+rotated and shifted copies of the channels and solves the normal equations in one workgroup on vectors in global memory.
 Checked against the oracle's fp64 chain (taps, normal equations, filtered channel), the compiled reference's fixture
 `long_filter` (4610 taps; in tests/test_clutter_gpu.py with every other fixture), batches with a stride, a failed solve,
 a positive first lag (the reference's unsigned index arithmetic), the solve on its own against LAPACK, and the refusals.
@@ -32,7 +32,7 @@ def channels(n, seed, taps_at=((0, 0.8), (700, 0.2), (3000, 0.1), (5000, 0.05)),
     return x.astype(np.complex64), np.round(y).astype(np.complex64)
 
 
-@pytest.mark.parametrize("dmin,dmax,n", [(-10, 4600, 60_000), (0, 8192, 70_000), (-3, 4082 - 3, 50_000), (2, 6002, 64_000)])
+@pytest.mark.parametrize("dmin,dmax,n", [(-10, 4600, 60_000), (0, 9000, 40_000), (-3, 4082 - 3, 50_000), (2, 6002, 64_000)])
 def test_long_filter_against_the_oracle(b2, dmin, dmax, n):
     nb = dmax - dmin
     x, y = channels(n, seed=nb, dmin=dmin)
@@ -115,10 +115,7 @@ def test_the_solve_on_its_own_against_lapack(b2):
 
 def test_refusals(b2):
     with pytest.raises(b2.Blah2HipError) as e:
-        b2.WienerHopf(0, 8193, 100_000)
-    assert e.value.code == b2._lib.ERR_UNSUPPORTED and "8192" in str(e.value)
-    with pytest.raises(b2.Blah2HipError) as e:
-        b2.WienerHopf(0, 5000, 4000)  # more taps than samples
+        b2.WienerHopf(0, 5000, 4000)  # more taps than samples: the reference reads its correlation lags out of bounds
     assert e.value.code == b2._lib.ERR_UNSUPPORTED
     import torch
     wh = b2.WienerHopf(-10, 4600, 60_000)
