@@ -1431,11 +1431,7 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     fa.plan.delayMin = h->chunks[0].lag0; fa.plan.nDelay = h->chunks[0].count; fa.plan.colOff = h->chunks[0].col0;
     fa.tw = h->d_tw; fa.out = h->d_R; fa.cpiStride = (int64_t)cpi_stride; fa.nPulses = (int32_t)(n_cpi * nD);
     fa.H = h->d_H; fa.N = h->dims.n_samples; fa.w = h->firW; fa.nBins = h->firBins;
-#ifdef B2_FIR_TW3_LDS
-    const size_t ldsf = lds + 240 * sizeof(cf);
-#else
-    const size_t ldsf = lds;
-#endif
+    const size_t ldsf = lds + 240 * sizeof(cf); // + the stage-3 twiddle table
     const int grid = std::min<int>(fa.nPulses, range_grid_cap(h, ldsf, 4, 8));
     if (fmt == BLAH2HIP_FMT_C32) {
       InC32 in{(const cf *)d_x, (const cf *)d_y};

@@ -231,17 +231,15 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
   cf *P = reinterpret_cast<cf *>(smem);
   cf *Q = P + W::A_ELEMS;
   const int t = threadIdx.x;
-#ifdef B2_FIR_TW3_LDS // experiment: the stage-3 twiddles (they depend on t % 16 only) in a 16 x 15 table behind the exchange buffers
+  // the stage-3 twiddles depend on t % 16 only: a 16 x 15 table behind the exchange buffers (2 KB) instead of 30 registers --
+  // the kernel's time does not move (1601-1646 against 1623-1649 us per 16 CPIs, same box), its spilled registers go from 28 to 8
+  // (fp32 planes; none with the int16 words), saved once per kernel and read back five times a pulse
   cf tw1[15];
   W::load_tw1(t, a.tw, tw1);
   cf *T3 = Q + W::B_ELEMS;
   if (t < 240) T3[t] = a.tw[(16 * (t / 15) * (t % 15 + 1)) & (W::F - 1)];
   __syncthreads();
   const cf *tw3 = T3 + (t & 15) * 15;
-#else
-  cf tw1[15], tw3[16];
-  W::load_twiddles(t, a.tw, tw1, tw3);
-#endif
   const float sgn = ((t >> 4) & 1) ? -1.f : 1.f; // (-1)^m of this thread's spectrum registers (m = q + 16 r + 256 s, q = t >> 4)
   const RangePlan p = a.plan;
   const int dmin = p.delayMin; // = the clutter window's first lag (launcher), <= 0
@@ -278,9 +276,9 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
 #define B2_FIR_YPOS 1
 #endif
     typename RY::raw yr[8];
-    auto y_request = [&](int g) {
+    auto y_request = [&](int g, int k0 = 0, int k1 = 8) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
+      for (int k = k0; k < k1; k++) {
         int vo = (g * L + dmin + t + T * k) * CY::STRIDE; // may be negative: the whole offset in the VGPR (bufload.hpp)
         asm volatile("" : "+v"(vo));
         yr[k] = RY::ld(yd, vo, 0);
@@ -290,9 +288,11 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
       W::inv_s1(t, wk, tw3, Q);
       __syncthreads();
       if (B2_FIR_YPOS == 1) y_request(g); // y of the block: requested here, used after the last stage
+      if (B2_FIR_YPOS == 3) y_request(g, 0, 4);
       W::inv_s2(t, wk, Q, P);
       __syncthreads();
       if (B2_FIR_YPOS == 2) y_request(g);
+      if (B2_FIR_YPOS == 3) y_request(g, 4, 8);
       W::inv_s3(t, wk, tw1, P);
       __syncthreads();
       const bool tail = (g + 1) * L > p.nCorr;                      // the block holds the pulse's last |delayMin| samples
