@@ -134,6 +134,7 @@ struct blah2hip_amb_s {
   bool inLeakCal = false;
   int hotMode = 1;                  // BLAH2HIP_OPT_HOT_COLUMNS: 0 off, 1 auto (CPIs long enough for a peak HOT_RATIO above the mean level), 2 always
   bool lastHot = false;             // the last process call launched hot_columns_kernel
+  hipStream_t lastHotStream = nullptr; // ... on this stream (BLAH2HIP_INFO_HOT_COLUMNS waits for that one only)
   int lastLeakLags = 0;             // BLAH2HIP_INFO_LEAK_LAGS: lags corrected by the last process call (0 = not applied)
   double lastLeakMax = 0.0;         // BLAH2HIP_INFO_LEAK_MAX_E12: the largest |g| of the calibration the last call ran under
 };
@@ -1323,8 +1324,9 @@ int blah2hip_amb_get_info(blah2hip_amb_t h, int key, int64_t *value)
     if (!h->lastHot) return BLAH2HIP_OK;
     uint32_t n = 0;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(&n, h->d_hotCount, sizeof(n), hipMemcpyDeviceToHost));
+    // the stream of the call, not the device: a poll in a pipeline must not stall other streams and handles
+    HIPCHK(hipMemcpyAsync(&n, h->d_hotCount, sizeof(n), hipMemcpyDeviceToHost, h->lastHotStream));
+    HIPCHK(hipStreamSynchronize(h->lastHotStream));
     *value = n;
     return BLAH2HIP_OK;
   }
@@ -1614,6 +1616,7 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     hipLaunchKernelGGL(hot_columns_kernel, dim3((nD + HOT_ROWS * ha.groups - 1) / (HOT_ROWS * ha.groups), n_cpi), dim3(256), lds, st, ha);
     HIPCHK(hipGetLastError());
     h->lastHot = true;
+    h->lastHotStream = st;
   }
   if (leak) { // inside the Doppler bracket: one 64-thread workgroup per CPI on a few dozen cells of the zero-Doppler row
     leak_fix_kernel<<<dim3(n_cpi), dim3(64), 0, st>>>(map, (size_t)nD * nDelay, (size_t)leak_row0(h) * nDelay, leak_col0(h),

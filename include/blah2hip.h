@@ -189,7 +189,7 @@ int blah2hip_amb_set_option(blah2hip_amb_t h, int option, int64_t value);
 #define BLAH2HIP_INFO_LEAK_LAGS 8            /* cells of the zero-Doppler row the last process call corrected (0 = compensation not applied) */
 #define BLAH2HIP_INFO_LEAK_MAX_E12 9         /* 1e12 x the largest |g| measured for the kernel pair the last call ran (0 = not measurable: no
                                               * zero-Doppler row / lag-0 column, rotated reference channel, chunked lag window) */
-#define BLAH2HIP_INFO_HOT_COLUMNS 10          /* columns of the last call's first CPI rewritten in fp64 (BLAH2HIP_OPT_HOT_COLUMNS); waits for the device */
+#define BLAH2HIP_INFO_HOT_COLUMNS 10          /* columns of the last call's first CPI rewritten in fp64 (BLAH2HIP_OPT_HOT_COLUMNS); waits for that call's stream */
 #define BLAH2HIP_INFO_DOPPLER_TILES 7       /* tiles (units of work the persistent workgroups walk) of the last Doppler launch; 0 for the
                                              * non-persistent kernels */
 int blah2hip_amb_get_info(blah2hip_amb_t h, int key, int64_t *value);
