@@ -343,6 +343,11 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
     }
 #pragma unroll
     for (int k = 8; k < 16; k++) acc[k] = cmake(0.f, 0.f);
+#ifdef B2_FIR_CARRY // experiment: the upper half of a block's window is the lower half of the next block's -- carried in 16 registers
+    cf keep[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) keep[k] = acc[k];
+#endif
     if (i > 0) { // (pulse 0: the stream is zero in front of the CPI)
 #pragma unroll
       for (int k = 0; k < 8; k++) V[k] = RX::cvt(RX::ld(xd, (p0 - L + t + T * k) * CX::STRIDE, 0));
@@ -367,12 +372,23 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
       if (B2_FIR_YPOS == 0) y_request(g);
 #pragma unroll
       for (int e = 0; e < 16; e++) wk[e] = Hc[e * 256];
+#ifdef B2_FIR_CARRY
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int m = g * L + t + T * k;
+        const cf x = RX::cvt(RX::ld(xd, (p0 + m) * CX::STRIDE, 0));
+        V[k] = keep[k];
+        V[8 + k] = m < p.nCorr ? x : cmake(0.f, 0.f);
+        keep[k] = V[8 + k];
+      }
+#else
 #pragma unroll
       for (int k = 0; k < 16; k++) {
         const int m = (g - 1) * L + t + T * k;
         const cf x = RX::cvt(RX::ld(xd, (p0 + m) * CX::STRIDE, 0));
         V[k] = m < p.nCorr ? x : cmake(0.f, 0.f);
       }
+#endif
       W::fwd_s1(t, V, tw1, P);
       __syncthreads();
       W::fwd_s2(t, V, P, Q);
