@@ -260,6 +260,8 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
     const __amdgpu_buffer_rsrc_t xd = make_rsrc_b(BufLoad<In>::xp(in, (int64_t)cpi * a.cpiStride), (int)a.N * CX::STRIDE);
     // y of this pulse: outside it the range check returns the zeros the correlation's mask wants
     const __amdgpu_buffer_rsrc_t yd = make_rsrc_b(BufLoad<In>::yp(in, (int64_t)cpi * a.cpiStride + p0), p.nCorr * CY::STRIDE);
+    // ... and x of this pulse for the windows: beyond the pulse's end the range check IS the mask (no fetch, no select)
+    const __amdgpu_buffer_rsrc_t xpd = make_rsrc_b(BufLoad<In>::xp(in, (int64_t)cpi * a.cpiStride + p0), p.nCorr * CX::STRIDE);
     const cf *Hc = a.H + (size_t)cpi * 16 * 256 + t;
     const cf *wc = a.w + (size_t)cpi * a.nBins;
     // Three arrays (+ the twiddles): what range_kernel holds.  V = the spectrum of the filter's WINDOW
@@ -336,11 +338,7 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
 #pragma unroll
     for (int e = 0; e < 16; e++) wk[e] = Hc[e * 256];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int m = t + T * k;
-      const cf x = RX::cvt(RX::ld(xd, (p0 + m) * CX::STRIDE, 0));
-      acc[k] = m < p.nCorr ? x : cmake(0.f, 0.f);
-    }
+    for (int k = 0; k < 8; k++) acc[k] = RX::cvt(RX::ld(xpd, (t + T * k) * CX::STRIDE, 0));
 #pragma unroll
     for (int k = 8; k < 16; k++) acc[k] = cmake(0.f, 0.f);
 #ifdef B2_FIR_CARRY // experiment: the upper half of a block's window is the lower half of the next block's -- carried in 16 registers
@@ -375,19 +373,13 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
 #ifdef B2_FIR_CARRY
 #pragma unroll
       for (int k = 0; k < 8; k++) {
-        const int m = g * L + t + T * k;
-        const cf x = RX::cvt(RX::ld(xd, (p0 + m) * CX::STRIDE, 0));
         V[k] = keep[k];
-        V[8 + k] = m < p.nCorr ? x : cmake(0.f, 0.f);
+        V[8 + k] = RX::cvt(RX::ld(xpd, (g * L + t + T * k) * CX::STRIDE, 0));
         keep[k] = V[8 + k];
       }
 #else
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
-        const int m = (g - 1) * L + t + T * k;
-        const cf x = RX::cvt(RX::ld(xd, (p0 + m) * CX::STRIDE, 0));
-        V[k] = m < p.nCorr ? x : cmake(0.f, 0.f);
-      }
+      for (int k = 0; k < 16; k++) V[k] = RX::cvt(RX::ld(xpd, ((g - 1) * L + t + T * k) * CX::STRIDE, 0));
 #endif
       W::fwd_s1(t, V, tw1, P);
       __syncthreads();
