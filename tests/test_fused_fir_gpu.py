@@ -181,3 +181,22 @@ def test_refusals(b2):
     assert "<= 0" in c.fir_fusable(w, b2.FMT_C32)
     c.close()
     w.close()
+
+
+def test_fused_chain_is_deterministic_and_blind_to_the_batch_position(b2):
+    """The same CPI alone, twice: bit-identical maps (fixed-order reductions in the filter's estimate, no atomics in the fused
+    kernel, the hot-column rewrite included: the echo below is one).  The same CPI as CPI 0 and CPI 2 of a batch of three:
+    bit-identical to each other; against the lone run only to rounding -- the estimate cuts a CPI into a number of partial
+    sums that depends on how many CPIs share the launch (csrc/clutter.hip launch_clutter), so the fp32 partials group
+    differently."""
+    args = GEOMETRIES["pulse ends 5 samples past a boundary (nCorr 6149)"]
+    n, fs = args[5], args[4]
+    x, y = synth(n, fs, 51, echo=(37, -3.0, 0.2), noise=3.0)
+    xo, yo = synth(n, fs, 52)
+    _, a1, _, _ = run_chains(b2, args, x[None], y[None])
+    _, a2, _, _ = run_chains(b2, args, x[None], y[None])
+    assert np.array_equal(a1, a2)
+    _, b3, _, ok3 = run_chains(b2, args, np.stack([x, xo, x]), np.stack([y, yo, y]))
+    assert list(ok3) == [1, 1, 1]
+    assert np.array_equal(b3[0], b3[2]) and not np.array_equal(b3[1], b3[0])
+    assert np.max(np.abs(b3[0].astype(np.complex128) - a1[0])) <= 1e-5 * np.max(np.abs(a1[0]))
