@@ -781,30 +781,33 @@ struct HotArgs {
 __global__ __launch_bounds__(256) void hot_columns_kernel(HotArgs a)
 {
   extern __shared__ double2 hs[]; // W[nD], column[nD]
-  __shared__ double sred[256];
+  __shared__ double sred[4];
   __shared__ int candLag[HOT_CAND];
   __shared__ float candDb[HOT_CAND];
   __shared__ int waveCnt[4], hot[HOT_MAX], nHot;
   __shared__ double2 red[8][HOT_ROWS];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int cpi = blockIdx.y, nD = a.nD, nDelay = a.nDelay;
+  // (the roots are requested first: they travel while the candidates are looked for, 8 KB a workgroup that finds none)
+  double2 *W = hs, *col = hs + nD;
+  for (int i = t; i < nD; i += 256) W[i] = a.W[i];
   // mean level (dB) of the map, from the partials in index order (every workgroup of the CPI: the same bits)
   double levelDb;
   if (a.nParts > 0) {
     double s = 0.0;
     for (int i = t; i < a.nParts; i += 256) s += a.partSum[(size_t)cpi * a.partStride + i];
-    sred[t] = s;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) sred[wave] = s;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (t < off) sred[t] += sred[t + off];
-      __syncthreads();
-    }
-    levelDb = sred[0] / ((double)nD * (double)nDelay);
+    levelDb = ((sred[0] + sred[1]) + (sred[2] + sred[3])) / ((double)nD * (double)nDelay);
   } else {
     levelDb = a.metrics[2 * cpi];
   }
   const float thr = (float)levelDb + a.ratioDb - 10.f * log10f((float)nD);
-  // candidates in lag order: wave w scans its quarter of the lags
+  // candidates in lag order: wave w scans its quarter of the lags.  (Eight groups of 64 lags with all their loads in flight
+  // together changed nothing: a launch that finds nothing runs 4.5 us on a lone CPI, what every small dependent kernel of the
+  // chain runs -- metrics_kernel, clutter_reduce_kernel, the gated solve.)
   const int per = ((nDelay + 3) / 4 + 63) & ~63;
   int mine = 0;
   for (int j0 = wave * per; j0 < min(nDelay, (wave + 1) * per); j0 += 64) {
@@ -851,8 +854,6 @@ __global__ __launch_bounds__(256) void hot_columns_kernel(HotArgs a)
   __syncthreads();
   const int nh = nHot;
   if (nh == 0) return;
-  double2 *W = hs, *col = hs + nD;
-  for (int i = t; i < nD; i += 256) W[i] = a.W[i];
   const int r = t & (HOT_ROWS - 1), part = t / HOT_ROWS; // 8 parts of the pulse axis
   const int chunk = (nD + 7) / 8;
   const int i0 = part * chunk, i1 = min(nD, i0 + chunk);
@@ -867,26 +868,22 @@ __global__ __launch_bounds__(256) void hot_columns_kernel(HotArgs a)
     for (int gi = 0; gi < a.groups; gi++) {
       const int o = (blockIdx.x * a.groups + gi) * HOT_ROWS + r;
       const int src = ((o < nD ? o : nD - 1) + nD / 2 + 1) % nD; // Ambiguity.cpp:165
-      int idx = (int)(((int64_t)src * i0) % nD);
-      double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
-      int i = i0;
-      for (; i + 1 < i1; i += 2) {
-        const double2 w0 = W[idx], v0 = col[i];
-        idx += src; if (idx >= nD) idx -= nD;
-        const double2 w1 = W[idx], v1 = col[i + 1];
-        idx += src; if (idx >= nD) idx -= nD;
-        ar = fma(v0.x, w0.x, ar); ar = fma(-v0.y, w0.y, ar);
-        ai = fma(v0.x, w0.y, ai); ai = fma(v0.y, w0.x, ai);
-        br = fma(v1.x, w1.x, br); br = fma(-v1.y, w1.y, br);
-        bi = fma(v1.x, w1.y, bi); bi = fma(v1.y, w1.x, bi);
-      }
-      if (i < i1) {
-        const double2 w0 = W[idx], v0 = col[i];
-        ar = fma(v0.x, w0.x, ar); ar = fma(-v0.y, w0.y, ar);
-        ai = fma(v0.x, w0.y, ai); ai = fma(v0.y, w0.x, ai);
+      // exp(-2 pi i src i / nD) along the thread's part of the pulse axis by recurrence from two table entries (<= nD / 8 steps
+      // in fp64: 6e-14 at nD = 4096; a table read per pulse was the loop's latency: random 16-byte LDS reads.  Four interleaved
+      // recurrences of step ws^4 were slower: 9.2 against 8.1 us on a lone CPI, 52 against 40 per 32 CPIs of configs[2])
+      const double2 w0 = W[(int)(((int64_t)src * i0) % nD)], ws = W[src];
+      double wr = w0.x, wi = w0.y;
+      double ar = 0.0, ai = 0.0;
+#pragma unroll 8
+      for (int i = i0; i < i1; i++) { // (unrolled: the LDS reads of eight pulses travel together; the recurrence is the chain)
+        const double2 v0 = col[i];
+        ar = fma(v0.x, wr, ar); ar = fma(-v0.y, wi, ar);
+        ai = fma(v0.x, wi, ai); ai = fma(v0.y, wr, ai);
+        const double nr = fma(wr, ws.x, -wi * ws.y), ni = fma(wr, ws.y, wi * ws.x);
+        wr = nr; wi = ni;
       }
       if (gi) __syncthreads(); // the previous group's sums have been read
-      red[part][r] = make_double2(ar + br, ai + bi);
+      red[part][r] = make_double2(ar, ai);
       __syncthreads();
       if (t < HOT_ROWS && o < nD) {
         double2 s = red[0][t];

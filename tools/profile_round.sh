@@ -58,7 +58,9 @@ mkdir -p $OUT/prof/solve
 # the lone-CPI chain (small-launch kernels) under the profiler
 mkdir -p $OUT/prof/b1
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof/b1/trace -o bench --output-format csv -- python $REPO/bench.py --batch 1 --steps 500 --warmup 20 --no-cpu-baseline --no-parity --no-configs > $OUT/prof/b1/trace.log 2>&1)
-prune $OUT/prof/solve; prune $OUT/prof/b1
+mkdir -p $OUT/prof/b1full
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof/b1full/trace -o bench --output-format csv -- python $REPO/bench.py --chain full --cfar 1d --batch 1 --steps 500 --warmup 20 --no-cpu-baseline --no-parity --no-configs --no-replay --long-s 0 > $OUT/prof/b1full/trace.log 2>&1)
+prune $OUT/prof/solve; prune $OUT/prof/b1; prune $OUT/prof/b1full
 # the fused FIR + range kernel beside the two kernels it replaces (configs[2], 16 CPIs per launch)
 bash $REPO/tools/prof_fused_ab.sh 16 10 > $OUT/fused_fir_ab.txt 2>&1
 # the spread of the full chain's gates over 16 CPIs of configs[2] and configs[1]
