@@ -125,6 +125,7 @@ struct blah2hip_amb_s {
   const cf *firW = nullptr; // [max_batch][firBins]; nullptr: the plain range kernels
   int firBins = 0, firDmin = 0;
   cf *d_H = nullptr;        // [max_batch][16][256]: the taps' spectrum in the transform's register layout (taps_spectrum_kernel)
+  int32_t *d_firK0 = nullptr; // [max_batch]: the largest tap's index (left out of d_H, applied in the time domain)
 
   // Fixed-pattern leak compensation (see leak_calibrate): per (range kernel, Doppler kernel) the lags of the zero-Doppler row
   // into which the fp32 transform chain leaks a fixed fraction g of the lag-0 cell, measured once on a synthetic CPI
@@ -1190,7 +1191,7 @@ int blah2hip_amb_destroy(blah2hip_amb_t h)
                   (void *)h->d_partSum, (void *)h->d_partMax, (void *)h->d_tickets, (void *)h->d_metrics,
                   (void *)h->d_doppler, h->d_in, (void *)h->d_rot,
                   (void *)h->d_hits, (void *)h->d_count, (void *)h->d_sat, (void *)h->d_dtw, (void *)h->d_chirp,
-                  (void *)h->d_bf, (void *)h->d_bfn, (void *)h->d_H, (void *)h->d_dopW64, (void *)h->d_hotCount})
+                  (void *)h->d_bf, (void *)h->d_bfn, (void *)h->d_H, (void *)h->d_dopW64, (void *)h->d_hotCount, (void *)h->d_firK0})
     if (p) (void)hipFree(p);
   for (auto &t : h->alphaTables)
     if (t.d) (void)hipFree(t.d);
@@ -1356,6 +1357,7 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     if (why) return fail(BLAH2HIP_ERR_UNSUPPORTED, why);
     if (n_cpi > 1 && cpi_stride < h->dims.n_samples) return fail(BLAH2HIP_ERR_INVALID, "fused FIR: cpi_stride < nSamples");
     if (!h->d_H) HIPCHK(hipMalloc(&h->d_H, (size_t)h->dims.max_batch * 16 * 256 * sizeof(cf)));
+    if (!h->d_firK0) HIPCHK(hipMalloc(&h->d_firK0, (size_t)h->dims.max_batch * sizeof(int32_t)));
   }
   // the fixed-pattern leak of the kernel pair this launch will run (calibrated at the pair's first launch)
   const blah2hip_amb_s::LeakCal *leak = nullptr;
@@ -1424,12 +1426,12 @@ int blah2hip_amb_process_dev(blah2hip_amb_t h, int fmt, const void *d_x, const v
     using W = WgFft<16>;
     const size_t lds = (size_t)(W::A_ELEMS + W::B_ELEMS) * sizeof(cf);
     LDSCFG(taps_spectrum_kernel, lds);
-    hipLaunchKernelGGL(taps_spectrum_kernel, dim3(n_cpi), dim3(256), lds, st, h->firW, h->firBins, h->d_tw, h->d_H);
+    hipLaunchKernelGGL(taps_spectrum_kernel, dim3(n_cpi), dim3(256), lds, st, h->firW, h->firBins, h->d_tw, h->d_H, h->d_firK0);
     RangeFirArgs fa;
     fa.plan = h->plan;
     fa.plan.delayMin = h->chunks[0].lag0; fa.plan.nDelay = h->chunks[0].count; fa.plan.colOff = h->chunks[0].col0;
     fa.tw = h->d_tw; fa.out = h->d_R; fa.cpiStride = (int64_t)cpi_stride; fa.nPulses = (int32_t)(n_cpi * nD);
-    fa.H = h->d_H; fa.N = h->dims.n_samples; fa.w = h->firW; fa.nBins = h->firBins;
+    fa.H = h->d_H; fa.N = h->dims.n_samples; fa.w = h->firW; fa.nBins = h->firBins; fa.k0 = h->d_firK0;
     const size_t ldsf = lds + 240 * sizeof(cf); // + the stage-3 twiddle table
     const int grid = std::min<int>(fa.nPulses, range_grid_cap(h, ldsf, 4, 8));
     if (fmt == BLAH2HIP_FMT_C32) {

@@ -186,13 +186,16 @@ struct RangeFirArgs {
   int64_t cpiStride;
   int32_t nPulses;
   const cf *H;        // [nCpi][16][256]: the taps' spectrum / F in the transform's register layout (taps_spectrum_kernel)
-  const cf *w;        // [nCpi][nBins]: the taps themselves (the few direct products at a pulse's edges)
+  const cf *w;        // [nCpi][nBins]: the taps themselves (the few direct products at a pulse's edges, and the largest tap)
   int32_t nBins;
+  const int32_t *k0;  // [nCpi]: the largest tap's index -- left out of H and applied in the time domain (clutter_fir_kernel does the same)
   uint32_t N;         // samples per CPI
 };
 
-// grid nCpi x 256: H[cpi][e][t] = register e of thread t of FFT_4096(w zero-padded) / F
-__global__ __launch_bounds__(256) void taps_spectrum_kernel(const cf *w, int nBins, const cf *tw, cf *H)
+// grid nCpi x 256: H[cpi][e][t] = register e of thread t of FFT_4096(w zero-padded, its LARGEST tap left out) / F; k0[cpi] = that
+// tap's index (ties to the lower index).  The largest tap is applied in the time domain by range_fir_kernel: with a direct path
+// far above the noise its product is nearly all of w * xs, and one fma rounds it once where the transform rounds it 3.5 eps.
+__global__ __launch_bounds__(256) void taps_spectrum_kernel(const cf *w, int nBins, const cf *tw, cf *H, int32_t *k0)
 {
   using W = WgFft<16>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -203,12 +206,39 @@ __global__ __launch_bounds__(256) void taps_spectrum_kernel(const cf *w, int nBi
   W::load_twiddles(t, tw, tw1, tw3);
   cf v[16];
   const float sc = 1.0f / (float)W::F;
+  float bestMag = -1.f;
+  int bestIdx = 0;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     const int m = t + 256 * k;
     const cf x = w[(size_t)cpi * nBins + min(m, nBins - 1)];
     v[k] = m < nBins ? cmake(x.x * sc, x.y * sc) : cmake(0.f, 0.f);
+    const float mag = m < nBins ? x.x * x.x + x.y * x.y : -1.f;
+    if (mag > bestMag) { bestMag = mag; bestIdx = m; }
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float mu = __shfl_xor(bestMag, off);
+    const int iu = __shfl_xor(bestIdx, off);
+    if (mu > bestMag || (mu == bestMag && iu < bestIdx)) { bestMag = mu; bestIdx = iu; }
+  }
+  {
+    float *sm = reinterpret_cast<float *>(P);
+    int *si = reinterpret_cast<int *>(P) + 4;
+    if ((t & 63) == 0) { sm[t >> 6] = bestMag; si[t >> 6] = bestIdx; }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const float mu = sm[u];
+      const int iu = si[u];
+      if (mu > bestMag || (mu == bestMag && iu < bestIdx)) { bestMag = mu; bestIdx = iu; }
+    }
+    __syncthreads();
+  }
+  if (t == 0) k0[cpi] = bestIdx;
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+    if (t + 256 * k == bestIdx) v[k] = cmake(0.f, 0.f);
   W::fwd_s1(t, v, tw1, P);
   __syncthreads();
   W::fwd_s2(t, v, P, Q);
@@ -264,6 +294,8 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
     const __amdgpu_buffer_rsrc_t xpd = make_rsrc_b(BufLoad<In>::xp(in, (int64_t)cpi * a.cpiStride + p0), p.nCorr * CX::STRIDE);
     const cf *Hc = a.H + (size_t)cpi * 16 * 256 + t;
     const cf *wc = a.w + (size_t)cpi * a.nBins;
+    const int k0 = __builtin_amdgcn_readfirstlane(a.k0[cpi]); // the largest tap: in the time domain, on the filter's TRUE stream
+    const cf w0 = wc[k0];
     // Three arrays (+ the twiddles): what range_kernel holds.  V = the spectrum of the filter's WINDOW
     // [segment g-1 | segment g] of x masked to the pulse, wk = the work array, acc = the correlation's accumulator.
     // Where the filter's stream differs from the masked x -- it looks |delayMin| samples past the pulse's end, and it is zero
@@ -278,12 +310,16 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
 #define B2_FIR_YPOS 1
 #endif
     typename RY::raw yr[8];
-    auto y_request = [&](int g, int k0 = 0, int k1 = 8) {
+    typename RX::raw xr0[8]; // x[n - delayMin - k0] of the block's samples n: the largest tap's operand
+    auto y_request = [&](int g, int ka = 0, int kb = 8) {
 #pragma unroll
-      for (int k = k0; k < k1; k++) {
+      for (int k = ka; k < kb; k++) {
         int vo = (g * L + dmin + t + T * k) * CY::STRIDE; // may be negative: the whole offset in the VGPR (bufload.hpp)
         asm volatile("" : "+v"(vo));
         yr[k] = RY::ld(yd, vo, 0);
+        int uo = (p0 + g * L + t + T * k - k0) * CX::STRIDE; // CPI index n - delayMin - k0 + p0; negative (pulse 0): reads as zero
+        asm volatile("" : "+v"(uo));
+        xr0[k] = RX::ld(xd, uo, 0);
       }
     };
     auto block_out = [&](int g) {
@@ -297,6 +333,12 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
       if (B2_FIR_YPOS == 3) y_request(g, 4, 8);
       W::inv_s3(t, wk, tw1, P);
       __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 8; k++) { // the largest tap: w0 xs[n - k0], xs zero on the CPI's first |delayMin| samples (WienerHopf.cpp:125-160)
+        const int u = p0 + g * L + t + T * k - k0;
+        const cf x = RX::cvt(xr0[k]);
+        wk[8 + k] = cadd(wk[8 + k], u >= -dmin ? cmul(w0, x) : cmake(0.f, 0.f));
+      }
       const bool tail = (g + 1) * L > p.nCorr;                      // the block holds the pulse's last |delayMin| samples
       const bool head = i == 0 && g * L + dmin < a.nBins + (-dmin); // pulse 0: samples the CPI's first |delayMin| reach
       if (tail || head) { // (workgroup-uniform) the edges, through LDS so that the register arrays keep static indices
@@ -310,12 +352,12 @@ __global__ __launch_bounds__(256, 2) void range_fir_kernel(RangeFirArgs a, In in
           if (tail) // past the pulse's end: the taps kk <= n - delayMin - nCorr reach x[p0 + nCorr ...], masked out of the window
             for (int kk = 0; kk <= min(n - dmin - p.nCorr, a.nBins - 1) && n < p.nCorr; kk++) {
               const cf x = RX::cvt(RX::ld(xd, (p0 + n - dmin - kk) * CX::STRIDE, 0));
-              c = cadd(c, cmul(wc[kk], x));
+              if (kk != k0) c = cadd(c, cmul(wc[kk], x)); // (the largest tap already runs on the true stream)
             }
           if (head && n >= 0) // the CPI's first |delayMin| samples: in the window of pulse 0, zero in the filter's stream
             for (int kk = max(n + 1, 0); kk <= n - dmin && kk < a.nBins; kk++) {
               const cf x = RX::cvt(RX::ld(xd, (n - dmin - kk) * CX::STRIDE, 0));
-              c = csub(c, cmul(wc[kk], x));
+              if (kk != k0) c = csub(c, cmul(wc[kk], x));
             }
           E[k * T] = c;
         }
