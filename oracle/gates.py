@@ -38,7 +38,8 @@ FLOOR_DB = 20.0
 CELL_TOL = 1e-4      # north_star: "map values within 1e-4 rel"
 MARGIN_K = 4.0       # d(margin)/margin <= 2 eps (cell power) + 2 eps (training mean), to first order
 MARGIN_EPS_MIN = 1e-7  # never size a margin band below fp32's own resolution of |z|^2
-NOTCH_ABS = 1e-2     # |dM| <= 1 % of the mean level on the cancelled zero-Doppler cells (where the gate cannot be relative)
+NOTCH_ABS = 5e-3     # |dM| <= 0.5 % of the mean level on the cancelled zero-Doppler cells (where the gate cannot be relative;
+                     # measured <= 0.24 % over 80 CPIs of the BASELINE chains and the deep-cancellation fixture)
 
 
 def mean_level(ref_noise_db):
@@ -57,10 +58,11 @@ def map_cell_gate(got_map, ref_map, ref_noise=None, tol=CELL_TOL, peak_tol=None,
     ``notch`` (the cells a clutter filter cancelled exactly, :func:`notch_mask`): the gate is then the figure WITHOUT them
     (``cell_rel_above_mean_outside_notch``); the figure over all cells is reported beside it, and the notch cells are held
     to the absolute bound of :func:`db_map_gate` (NOTCH_ABS of the mean level).  Why: what the reference leaves on those
-    cells is the residue of an exact cancellation, ours in addition the coherent residue of a 1e-7 error of the dominant tap
-    (fp32 taps through an fp32 overlap-save transform; tools/gpu_chain_diag.py) -- 0.1-0.6 % of the mean level whatever the
-    cell holds, i.e. 2e-4 ... 9e-4 of a notch cell that happens to stand above the mean level (a target's Doppler sidelobe),
-    measured on 3 of 10 CPIs at configs[1] / configs[2].  The error a detection margin is sized from leaves the notch out
+    cells is the residue of an exact cancellation, ours in addition the coherent residue of the taps' own error (fp32 storage;
+    r, b accumulated in fp32 partials; tools/gpu_chain_diag.py) -- up to 0.24 % of the mean level whatever the cell holds
+    (0.6 % while the dominant tap still went through the overlap-save transform), i.e. up to 3e-4 of a notch cell that
+    happens to stand above the mean level (a target's Doppler sidelobe).  The error a detection margin is sized from leaves
+    the notch out
     too (no detector window reaches the zero-Doppler row: CfarDetector1D.cpp:40 skips |doppler| < minDoppler)."""
     ref = np.asarray(ref_map, dtype=np.complex128)
     got = np.asarray(got_map).astype(np.complex128)
@@ -91,7 +93,7 @@ def map_cell_gate(got_map, ref_map, ref_noise=None, tol=CELL_TOL, peak_tol=None,
 def db_map_gate(got_map, got_noise, ref_map, ref_noise=None, notch=None, db_gate=DB_GATE):
     """Returns a dict of what was measured; ``ok`` is the gate.  ``notch``: boolean mask of the cells the clutter
     filter cancelled exactly (see the module docstring); None for maps with no filter in front.  ``db_gate``: 0.005
-    everywhere but on the one fixture built to find fp32's limit (tests/golden `deep_cancel`, stated where it is used)."""
+    everywhere (a parameter for experiments; no test loosens it)."""
     ref = np.asarray(ref_map, dtype=np.complex128)
     got = np.asarray(got_map).astype(np.complex128)
     a_ref = np.abs(ref)
